@@ -1,0 +1,136 @@
+/* linefront.h -- C ABI of liblinefront.so, the MI355X (gfx950) line front end and pairwise
+ * motion solver that drops in behind LineSLAM's Node / GraphManager surface.
+ *
+ * Every entry point states the reference interface it replaces (paths relative to the
+ * yan-lu/LineSLAM tree).  Plain pointers and sizes only; no C++/torch/OpenCV types.  Functions
+ * return 0 (LF_OK) or a negative lf_status; nothing calls exit() (the reference does:
+ * external/lsd/lsd.cpp:138-142, src/line/lineslam.cpp:272-275).
+ *
+ * The library has NO CPU compute path: every lf_* compute call runs hand-written HIP kernels and
+ * fails with LF_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef LINEFRONT_H
+#define LINEFRONT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define LF_API
+#else
+#define LF_API __attribute__((visibility("default")))
+#endif
+
+typedef enum lf_status {
+  LF_OK = 0,
+  LF_ERR_INVALID = -1,      /* bad argument */
+  LF_ERR_NO_DEVICE = -2,    /* no usable HIP device / kernel image */
+  LF_ERR_HIP = -3,          /* a HIP runtime call failed (see lf_last_error) */
+  LF_ERR_CAPACITY = -4,     /* a caller- or context-sized buffer was too small */
+  LF_ERR_UNSUPPORTED = -5   /* e.g. algorithm "EDLINES" (binary-only in the reference) */
+} lf_status;
+
+/* Mirror of the reference's global `SystemParameters sysPara` (src/line/lineslam.h:215-275,
+ * filled by SystemParameters::init, src/line/lineslam.cpp:577-640) -- only the members the hot
+ * path reads.  lf_params_init() stores the ParameterServer defaults
+ * (src/parameter_server.cpp:162-198); lf_params_init_launch() additionally applies the overrides
+ * of launch/lineslam.launch (lsd_angle_thres 40, min_matches 10). */
+typedef struct lf_params {
+  /* LSD (external/lsd/lsd.cpp:2070-2100) */
+  double lsd_angle_th;            /* 22.5 */
+  double lsd_density_th;          /* 0.7  */
+  double lsd_scale;               /* 0.8  (lsd.cpp:2097) */
+  double lsd_sigma_scale;         /* 0.6  */
+  double lsd_quant;               /* 2.0  */
+  double lsd_log_eps;             /* 0.0  */
+  int    lsd_n_bins;              /* 1024 */
+  double lsd_max_grad;            /* 255  */
+  /* 2D / 3D line extraction (src/line/lineslam.cpp:200-357) */
+  double line_segment_len_thresh; /* 10 px   line_2d_len_thres */
+  double line3d_length_thresh;    /* 0.02 m  line_3d_len_thres_m */
+  double ratio_of_collinear_pts;  /* 0.6     collin_pts_ratio */
+  int    line_sample_max_num;     /* 100 */
+  int    line_sample_min_num;     /* 10  */
+  double line_sample_interval;    /* 1   */
+  int    line3d_mle_iter_num;     /* 100 */
+  double pt2line_mahdist_extractline; /* 1.5 */
+  int    ransac_iters_extract_line;   /* 100 */
+  int    num_cells_lineseg_range;     /* 10  */
+  double ratio_support_pts_on_line;   /* 0.7 */
+  double stdev_sample_pt_imgline;     /* 3 px */
+  double depth_stdev_coeff_c1;        /* 0.00273  */
+  double depth_stdev_coeff_c2;        /* 0.00074  */
+  double depth_stdev_coeff_c3;        /* -0.00058 */
+  double msld_sample_interval;        /* 1 */
+  double depth_scaling;               /* 1.0 (Node::Node passes 1.0, src/node.cpp:214) */
+  /* pair solver (src/line/motion.cpp:605-849, src/node.cpp:1494-1694) */
+  int    ransac_iters_line_motion;    /* 500 */
+  int    adjacent_linematch_window;   /* 3   */
+  int    line_match_number_weight;    /* 1   */
+  int    min_feature_matches;         /* 20 (launch file: 10) */
+  int    min_matches_loopclose;       /* 20  */
+  double max_mah_dist_for_inliers;    /* 3   */
+  double g2o_line_error_weight;       /* 1   */
+  int    g2o_BA_use_kernel;           /* 1   (lineslam.cpp:629) */
+  double g2o_BA_kernel_delta;         /* 10  (lineslam.cpp:630) */
+  /* the reference draws from the unseeded global rand(); this library uses a counter-based
+   * generator keyed by (seed, frame id, line id / pair id, draw index)               */
+  uint64_t rng_seed;                  /* 0 */
+} lf_params;
+
+typedef struct lf_ctx lf_ctx;
+
+LF_API void lf_params_init(lf_params *p);
+LF_API void lf_params_init_launch(lf_params *p);
+LF_API const char *lf_version(void);
+LF_API const char *lf_status_str(int status);
+LF_API const char *lf_last_error(const lf_ctx *ctx);   /* text of the last failing HIP call */
+
+/* A context owns one HIP stream and all device buffers for batches of up to `max_batch` frames of
+ * width x height pixels; it replaces the reference's process-wide globals (`sysPara`, `K`, nfa's
+ * static table lsd.cpp:982).  One context per host thread; contexts are independent.
+ * `hip_stream` may be NULL (the context creates its own) or an existing hipStream_t to launch on
+ * (e.g. torch.cuda.current_stream().cuda_stream). */
+LF_API int lf_ctx_create(lf_ctx **out, int device, void *hip_stream, int width, int height,
+                         int max_batch, const lf_params *params);
+LF_API void lf_ctx_destroy(lf_ctx *ctx);
+LF_API int lf_ctx_set_params(lf_ctx *ctx, const lf_params *params);
+LF_API int lf_ctx_synchronize(lf_ctx *ctx);
+
+/* ---- a1-a8: LSD line-segment detection ------------------------------------------------------
+ * Replaces  ntuple_list callLsd(IplImage*)  (src/line/utils.cpp:112-135) -> lsd() ->
+ * LineSegmentDetection()  (external/lsd/lsd.cpp:1931-2065; interface external/lsd/lsd.h:210-243)
+ * for a batch of frames.
+ *
+ * lf_lsd_batch_device: `d_gray` is a DEVICE pointer to n_frames 8-bit grey images
+ * (frame f, row y at d_gray + f*frame_stride + y*row_stride).  Asynchronous on the context
+ * stream; results stay in device memory until fetched. */
+LF_API int lf_lsd_batch_device(lf_ctx *ctx, const uint8_t *d_gray, size_t frame_stride,
+                               int row_stride, int n_frames);
+/* Size of the scaled image in which regions are grown (lsd.cpp:549-550): N = floor(0.8 w) etc. */
+LF_API int lf_lsd_dims(const lf_ctx *ctx, int *N, int *M);
+/* Segments of frame `frame` of the last batch, rows {x1,y1,x2,y2,width} exactly as the reference's
+ * ntuple_list (lsd.cpp:2037-2046).  *n_out = number found (if > cap: LF_ERR_CAPACITY, cap rows
+ * written).  Synchronises the stream. */
+LF_API int lf_lsd_get_segments(lf_ctx *ctx, int frame, double *segs, int cap, int *n_out);
+/* Region label image (the integer line-pixel support, `image_int *region`, lsd.cpp:1989-1990,
+ * 2050-2052): M*N values, 0 = no segment, k = k-th segment. */
+LF_API int lf_lsd_get_labels(lf_ctx *ctx, int frame, uint16_t *labels);
+/* Intermediate products for kernel-level parity tests.  which: 0 scaled image (double M*N),
+ * 1 angles (double), 2 modgrad (double), 3 seed list (uint32 addresses y*N+x; *count = length),
+ * 4 work counters (8 x uint64: region_grow calls, grow steps, rect_nfa calls, rect pixels,
+ * region pixels, seeds, 0, 0). */
+LF_API int lf_lsd_get_debug(lf_ctx *ctx, int frame, int which, void *out, size_t out_bytes,
+                            int *count);
+/* Host-buffer convenience with the signature shape of callLsd: one image in, segments out. */
+LF_API int lf_lsd(lf_ctx *ctx, const uint8_t *gray, int row_stride, int width, int height,
+                  double *segs, int cap, int *n_out, uint16_t *labels_or_null);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINEFRONT_H */

@@ -1,0 +1,173 @@
+"""ctypes binding of the C ABI in include/linefront.h (liblinefront.so, HIP / gfx950).
+
+There is no Python or CPU implementation behind these calls: if the shared library is missing the
+import fails loudly, and every compute call returns LF_ERR_NO_DEVICE without a usable GPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblinefront.so")
+
+LF_OK, LF_ERR_INVALID, LF_ERR_NO_DEVICE, LF_ERR_HIP, LF_ERR_CAPACITY, LF_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+
+class LfParams(C.Structure):
+    """struct lf_params (include/linefront.h) == the hot-path members of the reference's sysPara."""
+    _fields_ = [
+        ("lsd_angle_th", C.c_double), ("lsd_density_th", C.c_double), ("lsd_scale", C.c_double),
+        ("lsd_sigma_scale", C.c_double), ("lsd_quant", C.c_double), ("lsd_log_eps", C.c_double),
+        ("lsd_n_bins", C.c_int), ("lsd_max_grad", C.c_double),
+        ("line_segment_len_thresh", C.c_double), ("line3d_length_thresh", C.c_double),
+        ("ratio_of_collinear_pts", C.c_double), ("line_sample_max_num", C.c_int),
+        ("line_sample_min_num", C.c_int), ("line_sample_interval", C.c_double),
+        ("line3d_mle_iter_num", C.c_int), ("pt2line_mahdist_extractline", C.c_double),
+        ("ransac_iters_extract_line", C.c_int), ("num_cells_lineseg_range", C.c_int),
+        ("ratio_support_pts_on_line", C.c_double), ("stdev_sample_pt_imgline", C.c_double),
+        ("depth_stdev_coeff_c1", C.c_double), ("depth_stdev_coeff_c2", C.c_double),
+        ("depth_stdev_coeff_c3", C.c_double), ("msld_sample_interval", C.c_double),
+        ("depth_scaling", C.c_double),
+        ("ransac_iters_line_motion", C.c_int), ("adjacent_linematch_window", C.c_int),
+        ("line_match_number_weight", C.c_int), ("min_feature_matches", C.c_int),
+        ("min_matches_loopclose", C.c_int), ("max_mah_dist_for_inliers", C.c_double),
+        ("g2o_line_error_weight", C.c_double), ("g2o_BA_use_kernel", C.c_int),
+        ("g2o_BA_kernel_delta", C.c_double), ("rng_seed", C.c_uint64),
+    ]
+
+
+class LinefrontError(RuntimeError):
+    def __init__(self, status, what, detail=""):
+        self.status = status
+        super().__init__("%s failed: %s%s" % (what, lib().lf_status_str(status).decode(),
+                                              (" [" + detail + "]") if detail else ""))
+
+
+_lib = None
+
+# every symbol include/linefront.h declares: (restype, argtypes)
+_vp, _i, _d = C.c_void_p, C.c_int, C.c_double
+_pi = C.POINTER(C.c_int)
+SYMBOLS = {
+    "lf_params_init": (None, [C.POINTER(LfParams)]),
+    "lf_params_init_launch": (None, [C.POINTER(LfParams)]),
+    "lf_version": (C.c_char_p, []),
+    "lf_status_str": (C.c_char_p, [_i]),
+    "lf_last_error": (C.c_char_p, [_vp]),
+    "lf_ctx_create": (_i, [C.POINTER(_vp), _i, _vp, _i, _i, _i, C.POINTER(LfParams)]),
+    "lf_ctx_destroy": (None, [_vp]),
+    "lf_ctx_set_params": (_i, [_vp, C.POINTER(LfParams)]),
+    "lf_ctx_synchronize": (_i, [_vp]),
+    "lf_lsd_batch_device": (_i, [_vp, _vp, C.c_size_t, _i, _i]),
+    "lf_lsd_dims": (_i, [_vp, _pi, _pi]),
+    "lf_lsd_get_segments": (_i, [_vp, _i, _vp, _i, _pi]),
+    "lf_lsd_get_labels": (_i, [_vp, _i, _vp]),
+    "lf_lsd_get_debug": (_i, [_vp, _i, _i, _vp, C.c_size_t, _pi]),
+    "lf_lsd": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _pi, _vp]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "liblinefront.so is not built (%s). Run `python -m lineslam_amd.build` "
+                "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(_lib, name)   # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def default_params(launch=False):
+    p = LfParams()
+    (lib().lf_params_init_launch if launch else lib().lf_params_init)(C.byref(p))
+    return p
+
+
+class Context:
+    """RAII wrapper of lf_ctx: one HIP stream + device buffers for batches of <= max_batch frames."""
+
+    def __init__(self, width, height, max_batch=1, params=None, device=0, stream=None):
+        self._h = _vp()
+        self.params = params if params is not None else default_params()
+        self.width, self.height, self.max_batch = width, height, max_batch
+        r = lib().lf_ctx_create(C.byref(self._h), device, _vp(stream) if stream else None, width,
+                                height, max_batch, C.byref(self.params))
+        if r != LF_OK:
+            self._h = _vp()
+            raise LinefrontError(r, "lf_ctx_create")
+        n, m = C.c_int(), C.c_int()
+        lib().lf_lsd_dims(self._h, C.byref(n), C.byref(m))
+        self.N, self.M = n.value, m.value
+
+    def close(self):
+        if self._h:
+            lib().lf_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r, what, ok=(LF_OK,)):
+        if r not in ok:
+            raise LinefrontError(r, what, lib().lf_last_error(self._h).decode())
+        return r
+
+    def set_params(self, params):
+        self._chk(lib().lf_ctx_set_params(self._h, C.byref(params)), "lf_ctx_set_params")
+        self.params = params
+
+    def synchronize(self):
+        self._chk(lib().lf_ctx_synchronize(self._h), "lf_ctx_synchronize")
+
+    # ---- LSD -----------------------------------------------------------------------------
+    def lsd_batch_device(self, d_gray_ptr, n_frames, frame_stride=None, row_stride=None):
+        """Launch LSD on n_frames u8 images already resident in device memory (async)."""
+        rs = row_stride or self.width
+        fs = frame_stride or rs * self.height
+        self._chk(lib().lf_lsd_batch_device(self._h, _vp(d_gray_ptr), fs, rs, n_frames),
+                  "lf_lsd_batch_device")
+
+    def lsd_segments(self, frame, cap=4096):
+        segs = np.zeros((cap, 5), np.float64)
+        n = C.c_int()
+        self._chk(lib().lf_lsd_get_segments(self._h, frame, segs.ctypes.data, cap, C.byref(n)),
+                  "lf_lsd_get_segments")
+        return segs[:n.value].copy()
+
+    def lsd_labels(self, frame):
+        lab = np.zeros((self.M, self.N), np.uint16)
+        self._chk(lib().lf_lsd_get_labels(self._h, frame, lab.ctypes.data), "lf_lsd_get_labels")
+        return lab
+
+    def lsd_debug(self, frame, which):
+        n = C.c_int()
+        nm = self.N * self.M
+        if which in (0, 1, 2):
+            out = np.zeros((self.M, self.N), np.float64)
+        elif which == 3:
+            out = np.zeros(nm, np.uint32)
+        else:
+            out = np.zeros(8, np.uint64)
+        self._chk(lib().lf_lsd_get_debug(self._h, frame, which, out.ctypes.data, out.nbytes,
+                                         C.byref(n)), "lf_lsd_get_debug")
+        return out[:n.value].copy() if which == 3 else out
+
+    def lsd(self, gray_u8, want_labels=True, cap=4096):
+        """callLsd equivalent: one host image in, (segments[n,5], labels[M,N]) out."""
+        g = np.ascontiguousarray(gray_u8, dtype=np.uint8)
+        h, w = g.shape
+        segs = np.zeros((cap, 5), np.float64)
+        lab = np.zeros((self.M, self.N), np.uint16) if want_labels else None
+        n = C.c_int()
+        self._chk(lib().lf_lsd(self._h, g.ctypes.data, w, w, h, segs.ctypes.data, cap, C.byref(n),
+                               lab.ctypes.data if want_labels else None), "lf_lsd")
+        return segs[:n.value].copy(), lab

@@ -1,0 +1,423 @@
+// lf_api.hip -- host side of the C ABI declared in include/linefront.h.
+//
+// Owns the context (HIP stream, device buffers sized for 288 GB HBM3E: every per-frame product of
+// a whole batch stays resident), builds the small host tables the reference computes with libm on
+// the CPU (Gaussian taps lsd.cpp:461-487, log-gamma lsd.cpp:886-934, log p), and launches the
+// kernels.  There is no CPU compute path in this file.
+#include "../../include/linefront.h"
+#include "lf_lsd.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#define LF_VERSION_STR "linefront-mi355x 0.1 (gfx950)"
+
+struct lf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int W = 0, H = 0, maxB = 0;
+  lf_params params;
+  LsdConsts lc;
+  LsdBuffers lb;
+  std::vector<void *> allocs;
+  uint8_t *d_gray_stage = nullptr;   // staging for the host-pointer convenience entry points
+  int last_batch = 0;
+  std::string err;
+};
+
+// ------------------------------------------------------------------------------------------------
+static int fail_hip(lf_ctx *c, hipError_t e, const char *what) {
+  if (c) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    c->err = buf;
+  }
+  return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorNoBinaryForGpu ||
+          e == hipErrorInsufficientDriver)
+             ? LF_ERR_NO_DEVICE
+             : LF_ERR_HIP;
+}
+#define HIPCHK(ctx, call)                                   \
+  do {                                                      \
+    hipError_t e_ = (call);                                 \
+    if (e_ != hipSuccess) return fail_hip(ctx, e_, #call);  \
+  } while (0)
+
+template <typename T>
+static int dev_alloc(lf_ctx *c, T **p, size_t count) {
+  void *q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
+  if (e != hipSuccess) return fail_hip(c, e, "hipMalloc");
+  c->allocs.push_back(q);
+  *p = reinterpret_cast<T *>(q);
+  return LF_OK;
+}
+#define ALLOC(ctx, ptr, count)                          \
+  do {                                                  \
+    int r_ = dev_alloc(ctx, &(ptr), (size_t)(count));   \
+    if (r_ != LF_OK) return r_;                         \
+  } while (0)
+
+extern "C" {
+
+void lf_params_init(lf_params *p) {
+  if (!p) return;
+  memset(p, 0, sizeof *p);
+  p->lsd_angle_th = 22.5;            // parameter_server.cpp:162
+  p->lsd_density_th = 0.7;           // :163
+  p->lsd_scale = 0.8;                // lsd.cpp:2097
+  p->lsd_sigma_scale = 0.6;          // lsd.cpp:2073
+  p->lsd_quant = 2.0;                // lsd.cpp:2075
+  p->lsd_log_eps = 0.0;              // lsd.cpp:2078
+  p->lsd_n_bins = 1024;              // lsd.cpp:2080
+  p->lsd_max_grad = 255.0;           // lsd.cpp:2082
+  p->line_segment_len_thresh = 10;   // :164
+  p->line3d_length_thresh = 0.02;    // :169
+  p->ratio_of_collinear_pts = 0.6;   // :170
+  p->line_sample_max_num = 100;      // :171
+  p->line_sample_min_num = 10;       // :172
+  p->line_sample_interval = 1;       // :173
+  p->line3d_mle_iter_num = 100;      // :174
+  p->pt2line_mahdist_extractline = 1.5;   // :176
+  p->ransac_iters_extract_line = 100;     // :177
+  p->num_cells_lineseg_range = 10;        // :178
+  p->ratio_support_pts_on_line = 0.7;     // :179
+  p->stdev_sample_pt_imgline = 3;         // :182
+  p->depth_stdev_coeff_c1 = 0.00273;      // :183
+  p->depth_stdev_coeff_c2 = 0.00074;      // :184
+  p->depth_stdev_coeff_c3 = -0.00058;     // :185
+  p->msld_sample_interval = 1;            // :166
+  p->depth_scaling = 1.0;                 // node.cpp:214
+  p->ransac_iters_line_motion = 500;      // :190
+  p->adjacent_linematch_window = 3;       // :191
+  p->line_match_number_weight = 1;        // :197
+  p->min_feature_matches = 20;            // parameter_server.cpp:82
+  p->min_matches_loopclose = 20;          // :198
+  p->max_mah_dist_for_inliers = 3;        // :193
+  p->g2o_line_error_weight = 1;           // :194
+  p->g2o_BA_use_kernel = 1;               // lineslam.cpp:629
+  p->g2o_BA_kernel_delta = 10;            // lineslam.cpp:630
+  p->rng_seed = 0;
+}
+void lf_params_init_launch(lf_params *p) {
+  lf_params_init(p);
+  if (!p) return;
+  p->lsd_angle_th = 40;          // launch/lineslam.launch:39
+  p->min_feature_matches = 10;   // launch/lineslam.launch (min_matches)
+}
+const char *lf_version(void) { return LF_VERSION_STR; }
+const char *lf_status_str(int s) {
+  switch (s) {
+    case LF_OK: return "ok";
+    case LF_ERR_INVALID: return "invalid argument";
+    case LF_ERR_NO_DEVICE: return "no usable gfx950 HIP device (this library has no CPU path)";
+    case LF_ERR_HIP: return "HIP runtime error";
+    case LF_ERR_CAPACITY: return "buffer capacity exceeded";
+    case LF_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+  }
+}
+const char *lf_last_error(const lf_ctx *c) { return c ? c->err.c_str() : ""; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Host tables.  These are the quantities the reference evaluates with the host libm; they depend
+// only on the image size and the parameters, not on pixel data.
+static double host_log_gamma(double x) {   // lsd.cpp:886-934
+  if (x > 15.0)
+    return 0.918938533204673 + (x - 0.5) * log(x) - x +
+           0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
+  static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705,
+                              1168.92649479, 83.8676043424, 2.50662827511};
+  double a = (x + 0.5) * log(x + 5.5) - (x + 5.5), b = 0.0;
+  for (int n = 0; n < 7; n++) {
+    a -= log(x + (double)n);
+    b += q[n] * pow(x, (double)n);
+  }
+  return a + log(b);
+}
+static void host_gauss_taps(double sigma, double mean, int n, double *k) {   // lsd.cpp:461-487
+  double sum = 0.0;
+  for (int i = 0; i < n; i++) {
+    double val = ((double)i - mean) / sigma;
+    k[i] = exp(-0.5 * val * val);
+    sum += k[i];
+  }
+  if (sum >= 0.0)
+    for (int i = 0; i < n; i++) k[i] /= sum;
+}
+
+static int build_lsd_consts(lf_ctx *c) {
+  const lf_params &p = c->params;
+  LsdConsts &lc = c->lc;
+  memset(&lc, 0, sizeof lc);
+  if (!(p.lsd_scale > 0.0) || !(p.lsd_sigma_scale > 0.0) || p.lsd_quant < 0.0 ||
+      !(p.lsd_angle_th > 0.0 && p.lsd_angle_th < 180.0) || p.lsd_density_th < 0.0 ||
+      p.lsd_density_th > 1.0 || p.lsd_n_bins <= 0 || p.lsd_n_bins > 1024 || !(p.lsd_max_grad > 0.0))
+    return LF_ERR_INVALID;   // the checks of lsd.cpp:1949-1960 (reference: exit())
+  lc.W = c->W; lc.H = c->H;
+  lc.scale = p.lsd_scale;
+  if (p.lsd_scale != 1.0) {
+    lc.N = (int)(unsigned int)floor(c->W * p.lsd_scale);   // lsd.cpp:549-550
+    lc.M = (int)(unsigned int)floor(c->H * p.lsd_scale);
+  } else { lc.N = c->W; lc.M = c->H; }
+  if (lc.N < 2 || lc.M < 2 || lc.N > 65535 || lc.M > 65535) return LF_ERR_INVALID;
+  double sigma = p.lsd_scale < 1.0 ? p.lsd_sigma_scale / p.lsd_scale : p.lsd_sigma_scale;
+  int h = (int)(unsigned int)ceil(sigma * sqrt(2.0 * 3.0 * log(10.0)));   // lsd.cpp:564-565
+  lc.ntaps = 1 + 2 * h;
+  lc.n_bins = p.lsd_n_bins;
+  lc.max_grad = p.lsd_max_grad;
+  lc.prec = M_PI * p.lsd_angle_th / 180.0;                  // lsd.cpp:1963
+  lc.p = p.lsd_angle_th / 180.0;                            // lsd.cpp:1964
+  lc.rho = p.lsd_quant / sin(lc.prec);                      // lsd.cpp:1965
+  lc.logNT = 5.0 * (log10((double)lc.N) + log10((double)lc.M)) / 2.0;   // lsd.cpp:1983
+  lc.min_reg_size = (int)(-lc.logNT / log10(lc.p));         // lsd.cpp:1984
+  lc.density_th = p.lsd_density_th;
+  lc.eps = p.lsd_log_eps;
+  double pk = lc.p;
+  for (int k = 0; k < LF_MAX_PLEVEL; k++) {   // rect_improve halves p (lsd.cpp:1677,1755)
+    lc.logp[k] = log(pk);
+    lc.log1mp[k] = log(1.0 - pk);
+    lc.log10p[k] = log10(pk);
+    pk /= 2.0;
+  }
+  lc.seg_cap = 4096;
+  return LF_OK;
+}
+
+static int upload_lsd_tables(lf_ctx *c) {
+  const lf_params &p = c->params;
+  const LsdConsts &lc = c->lc;
+  const int n = lc.ntaps, h = (n - 1) / 2;
+  double sigma = p.lsd_scale < 1.0 ? p.lsd_sigma_scale / p.lsd_scale : p.lsd_sigma_scale;
+  std::vector<double> kx((size_t)lc.N * n), ky((size_t)lc.M * n);
+  std::vector<int> jx((size_t)lc.N * n), jy((size_t)lc.M * n);
+  for (int x = 0; x < lc.N; x++) {   // lsd.cpp:573-604
+    double xx = (double)x / p.lsd_scale;
+    int xc = (int)floor(xx + 0.5);
+    host_gauss_taps(sigma, (double)h + xx - (double)xc, n, &kx[(size_t)x * n]);
+    for (int i = 0; i < n; i++) {
+      int j = xc - h + i, d = 2 * lc.W;
+      while (j < 0) j += d;
+      while (j >= d) j -= d;
+      if (j >= lc.W) j = d - 1 - j;
+      jx[(size_t)x * n + i] = j;
+    }
+  }
+  for (int y = 0; y < lc.M; y++) {   // lsd.cpp:607-638
+    double yy = (double)y / p.lsd_scale;
+    int yc = (int)floor(yy + 0.5);
+    host_gauss_taps(sigma, (double)h + yy - (double)yc, n, &ky[(size_t)y * n]);
+    for (int i = 0; i < n; i++) {
+      int j = yc - h + i, d = 2 * lc.H;
+      while (j < 0) j += d;
+      while (j >= d) j -= d;
+      if (j >= lc.H) j = d - 1 - j;
+      jy[(size_t)y * n + i] = j;
+    }
+  }
+  if (p.lsd_scale == 1.0) {   // no sampling: identity taps (lsd.cpp:1968-1978 skips the sampler)
+    for (int x = 0; x < lc.N; x++) for (int i = 0; i < n; i++) { kx[(size_t)x * n + i] = (i == h); jx[(size_t)x * n + i] = x; }
+    for (int y = 0; y < lc.M; y++) for (int i = 0; i < n; i++) { ky[(size_t)y * n + i] = (i == h); jy[(size_t)y * n + i] = y; }
+  }
+  const size_t NM = (size_t)lc.N * lc.M;
+  std::vector<double> lg(NM + 2);
+  lg[0] = 0.0;
+  for (size_t i = 1; i < NM + 2; i++) lg[i] = host_log_gamma((double)i);
+  HIPCHK(c, hipMemcpyAsync((void *)c->lb.kx, kx.data(), kx.size() * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync((void *)c->lb.ky, ky.data(), ky.size() * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync((void *)c->lb.jx, jx.data(), jx.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync((void *)c->lb.jy, jy.data(), jy.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync((void *)c->lb.lgam, lg.data(), lg.size() * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync((void *)c->lb.dconsts, &c->lc, sizeof(LsdConsts), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // host vectors go out of scope
+  return LF_OK;
+}
+
+static int alloc_lsd(lf_ctx *c) {
+  const LsdConsts &lc = c->lc;
+  LsdBuffers &b = c->lb;
+  memset(&b, 0, sizeof b);
+  const size_t B = (size_t)c->maxB, NM = (size_t)lc.N * lc.M;
+  // size tables for the worst case over parameter changes of the same context (scale fixed)
+  double *kx, *ky, *lgam; int *jx, *jy; LsdConsts *dc;
+  ALLOC(c, kx, (size_t)lc.N * lc.ntaps); ALLOC(c, ky, (size_t)lc.M * lc.ntaps);
+  ALLOC(c, jx, (size_t)lc.N * lc.ntaps); ALLOC(c, jy, (size_t)lc.M * lc.ntaps);
+  ALLOC(c, lgam, NM + 2); ALLOC(c, dc, 1);
+  b.kx = kx; b.ky = ky; b.jx = jx; b.jy = jy; b.lgam = lgam; b.dconsts = dc;
+  ALLOC(c, b.aux, B * lc.H * lc.N);
+  ALLOC(c, b.scaled, B * NM);
+  ALLOC(c, b.angles, B * NM);
+  ALLOC(c, b.modgrad, B * NM);
+  ALLOC(c, b.bins, B * NM);
+  int nch = (lc.N - 1 + LF_SORT_CHUNK_COLS - 1) / LF_SORT_CHUNK_COLS;
+  ALLOC(c, b.cnt, B * nch * 1024);
+  ALLOC(c, b.seeds, B * NM);
+  ALLOC(c, b.nseeds, B);
+  ALLOC(c, b.used, B * NM);
+  ALLOC(c, b.reg, B * NM);
+  ALLOC(c, b.tmp, B * NM);
+  ALLOC(c, b.labels, B * NM);
+  ALLOC(c, b.segs, B * (size_t)lc.seg_cap * LF_SEG_STRIDE);
+  ALLOC(c, b.nsegs, B);
+  ALLOC(c, b.stats, B * 8);
+  ALLOC(c, c->d_gray_stage, (size_t)c->W * c->H);
+  return LF_OK;
+}
+
+extern "C" {
+
+int lf_ctx_create(lf_ctx **out, int device, void *hip_stream, int width, int height, int max_batch,
+                  const lf_params *params) {
+  if (!out || width < 8 || height < 8 || max_batch < 1) return LF_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return LF_ERR_NO_DEVICE;
+  lf_ctx *c = new lf_ctx();
+  c->device = device;
+  c->W = width; c->H = height; c->maxB = max_batch;
+  if (params) c->params = *params; else lf_params_init(&c->params);
+  int r = LF_OK;
+  do {
+    if ((e = hipSetDevice(device)) != hipSuccess) { r = fail_hip(c, e, "hipSetDevice"); break; }
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    else {
+      if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { r = fail_hip(c, e, "hipStreamCreate"); break; }
+      c->own_stream = true;
+    }
+    if ((r = build_lsd_consts(c)) != LF_OK) break;
+    if ((r = alloc_lsd(c)) != LF_OK) break;
+    if ((r = upload_lsd_tables(c)) != LF_OK) break;
+  } while (0);
+  if (r != LF_OK) { lf_ctx_destroy(c); return r; }
+  *out = c;
+  return LF_OK;
+}
+
+void lf_ctx_destroy(lf_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (void *p : c->allocs) (void)hipFree(p);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int lf_ctx_set_params(lf_ctx *c, const lf_params *p) {
+  if (!c || !p) return LF_ERR_INVALID;
+  if (p->lsd_scale != c->params.lsd_scale || p->lsd_sigma_scale != c->params.lsd_sigma_scale)
+    return LF_ERR_UNSUPPORTED;   // buffer geometry is fixed at creation
+  lf_params old = c->params;
+  c->params = *p;
+  int r = build_lsd_consts(c);
+  if (r != LF_OK) { c->params = old; build_lsd_consts(c); return r; }
+  HIPCHK(c, hipSetDevice(c->device));
+  return upload_lsd_tables(c);
+}
+
+int lf_ctx_synchronize(lf_ctx *c) {
+  if (!c) return LF_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LF_OK;
+}
+
+int lf_lsd_batch_device(lf_ctx *c, const uint8_t *d_gray, size_t frame_stride, int row_stride,
+                        int n_frames) {
+  if (!c || !d_gray || n_frames < 1 || row_stride < c->W) return LF_ERR_INVALID;
+  if (n_frames > c->maxB) return LF_ERR_CAPACITY;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->lb.gray = d_gray;
+  c->lb.gray_frame_stride = frame_stride;
+  c->lb.gray_row_stride = row_stride;
+  lf_lsd_launch(c->lc, c->lb, n_frames, c->stream);
+  HIPCHK(c, hipGetLastError());
+  c->last_batch = n_frames;
+  return LF_OK;
+}
+
+int lf_lsd_dims(const lf_ctx *c, int *N, int *M) {
+  if (!c) return LF_ERR_INVALID;
+  if (N) *N = c->lc.N;
+  if (M) *M = c->lc.M;
+  return LF_OK;
+}
+
+int lf_lsd_get_segments(lf_ctx *c, int frame, double *segs, int cap, int *n_out) {
+  if (!c || frame < 0 || frame >= c->last_batch || !n_out || cap < 0 || (cap > 0 && !segs)) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int n = 0;
+  HIPCHK(c, hipMemcpyAsync(&n, c->lb.nsegs + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_out = n;
+  int m = n < cap ? n : cap;
+  if (m > c->lc.seg_cap) m = c->lc.seg_cap;
+  if (m > 0) {
+    HIPCHK(c, hipMemcpyAsync(segs, c->lb.segs + (size_t)frame * c->lc.seg_cap * LF_SEG_STRIDE,
+                             (size_t)m * LF_SEG_STRIDE * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return (n > cap || n > c->lc.seg_cap) ? LF_ERR_CAPACITY : LF_OK;
+}
+
+int lf_lsd_get_labels(lf_ctx *c, int frame, uint16_t *labels) {
+  if (!c || frame < 0 || frame >= c->last_batch || !labels) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t NM = (size_t)c->lc.N * c->lc.M;
+  HIPCHK(c, hipMemcpyAsync(labels, c->lb.labels + frame * NM, NM * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LF_OK;
+}
+
+int lf_lsd_get_debug(lf_ctx *c, int frame, int which, void *out, size_t out_bytes, int *count) {
+  if (!c || frame < 0 || frame >= c->last_batch || !out) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t NM = (size_t)c->lc.N * c->lc.M;
+  const void *src = nullptr;
+  size_t bytes = 0;
+  int cnt = 0;
+  switch (which) {
+    case 0: src = c->lb.scaled + frame * NM; bytes = NM * 8; cnt = (int)NM; break;
+    case 1: src = c->lb.angles + frame * NM; bytes = NM * 8; cnt = (int)NM; break;
+    case 2: src = c->lb.modgrad + frame * NM; bytes = NM * 8; cnt = (int)NM; break;
+    case 3: {
+      HIPCHK(c, hipMemcpyAsync(&cnt, c->lb.nseeds + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      src = c->lb.seeds + frame * NM; bytes = (size_t)cnt * 4; break;
+    }
+    case 4: src = c->lb.stats + (size_t)frame * 8; bytes = 64; cnt = 8; break;
+    default: return LF_ERR_INVALID;
+  }
+  if (count) *count = cnt;
+  if (out_bytes < bytes) return LF_ERR_CAPACITY;
+  if (bytes) {
+    HIPCHK(c, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return LF_OK;
+}
+
+int lf_lsd(lf_ctx *c, const uint8_t *gray, int row_stride, int width, int height, double *segs, int cap,
+           int *n_out, uint16_t *labels) {
+  if (!c || !gray || width != c->W || height != c->H || row_stride < width) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpy2DAsync(c->d_gray_stage, (size_t)width, gray, (size_t)row_stride, (size_t)width,
+                             (size_t)height, hipMemcpyHostToDevice, c->stream));
+  int r = lf_lsd_batch_device(c, c->d_gray_stage, (size_t)width * height, width, 1);
+  if (r != LF_OK) return r;
+  r = lf_lsd_get_segments(c, 0, segs, cap, n_out);
+  if (r != LF_OK && r != LF_ERR_CAPACITY) return r;
+  if (labels) {
+    int r2 = lf_lsd_get_labels(c, 0, labels);
+    if (r2 != LF_OK) return r2;
+  }
+  return r;
+}
+
+}  // extern "C"

@@ -1,0 +1,773 @@
+// lf_lsd.hip -- LSD line-segment detection for gfx950 (MI355X), hand-written HIP.
+//
+// Replaces, bit for bit, the CPU path  callLsd (src/line/utils.cpp:112-135) ->
+// lsd() -> LineSegmentDetection (external/lsd/lsd.cpp:1931-2065) for a BATCH of frames.
+//
+// Kernel map (reference lines each one follows):
+//   k_gauss_x / k_gauss_y   gaussian_sampler          lsd.cpp:529-646   data-parallel, HBM-bound
+//   k_ll_angle              ll_angle (gradient part)  lsd.cpp:717-770   data-parallel, HBM-bound
+//   k_seed_hist/scan/scatter  ll_angle pseudo-ordering lsd.cpp:757-786  stable counting sort that
+//                            reproduces the linked-list order (bin desc; x outer, y inner)
+//   k_lsd_sweep             the seed loop             lsd.cpp:1996-2053 ONE WAVEFRONT PER FRAME:
+//        region_grow :1610-1656, region2rect :1517-1604, get_theta :1474-1512, refine :1853-1921,
+//        reduce_region_radius :1775-1841, rect_improve :1662-1768, rect_nfa :1388-1410 (+ the
+//        rectangle iterator :1231-1383), nfa :980-1065.
+//
+// Why one wavefront per frame: the reference is order dependent (one shared `used` mask, seeds
+// visited in pseudo-sorted order, reg_angle updated after every accepted pixel).  The sweep keeps
+// that order exactly and uses the 64 lanes for everything that is order independent or can be
+// speculated and committed in order: 64 seed probes at a time, 64 neighbour tests (7 region
+// pixels x 9 neighbours) per region-growing step with first-hit commit, lane-parallel operand
+// preparation for the order-dependent fp64 sums (summed serially through readlane in reference
+// order), lane-parallel rectangle rasterisation (integer counts), lane-parallel binomial-tail
+// terms.  Throughput comes from frames in flight (one per SIMD slot), see DESIGN.md section 4.
+//
+// All fp64 arithmetic is IEEE without contraction (-ffp-contract=off); the transcendental
+// functions evaluated on the device come from lf_math.h.
+#include "lf_lsd.h"
+#include "lf_math.h"
+#include <float.h>
+
+typedef unsigned long long u64;
+
+// ----------------------------------------------------------------------------------------------
+// small wave-level helpers (wave = 64 lanes on gfx950)
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ double rl64(double v, int l) {   // value of lane l (l wave-uniform)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int rl32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  return v;
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+  return v;
+}
+// compiler-level ordering of this wave's own memory traffic (hardware keeps a wave's vector
+// memory operations to one address in program order)
+__device__ __forceinline__ void wave_mem_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+// ----------------------------------------------------------------------------------------------
+// gaussian_sampler (lsd.cpp:529-646).  Taps kx/ky and boundary-folded source indices jx/jy are
+// host tables (gaussian_kernel :461-487 uses exp(); the symmetric boundary :597-600 is integer).
+// Summation order i = 0..n-1 starting from 0.0, exactly as :590-603 / :622-635.
+__global__ void __launch_bounds__(256) k_gauss_x(LsdConsts c, LsdBuffers b) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y, f = blockIdx.z;
+  if (x >= c.N) return;
+  const uint8_t *row = b.gray + (size_t)f * b.gray_frame_stride + (size_t)y * b.gray_row_stride;
+  const double *k = b.kx + (size_t)x * c.ntaps;
+  const int *j = b.jx + (size_t)x * c.ntaps;
+  double sum = 0.0;
+  for (int i = 0; i < c.ntaps; i++) sum += (double)row[j[i]] * k[i];   // u8 -> double: utils.cpp:124-129
+  b.aux[((size_t)f * c.H + y) * c.N + x] = sum;
+}
+__global__ void __launch_bounds__(256) k_gauss_y(LsdConsts c, LsdBuffers b) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y, f = blockIdx.z;
+  if (x >= c.N) return;
+  const double *aux = b.aux + (size_t)f * c.H * c.N;
+  const double *k = b.ky + (size_t)y * c.ntaps;
+  const int *j = b.jy + (size_t)y * c.ntaps;
+  double sum = 0.0;
+  for (int i = 0; i < c.ntaps; i++) sum += aux[(size_t)j[i] * c.N + x] * k[i];
+  b.scaled[((size_t)f * c.M + y) * c.N + x] = sum;
+}
+
+// ll_angle, gradient part (lsd.cpp:717-770).  One thread per pixel of the scaled image.
+__global__ void __launch_bounds__(256) k_ll_angle(LsdConsts c, LsdBuffers b) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y, f = blockIdx.z;
+  if (x >= c.N) return;
+  const size_t NM = (size_t)c.N * c.M;
+  const double *in = b.scaled + f * NM;
+  size_t adr = (size_t)y * c.N + x;
+  double ang = LF_NOTDEF, norm = 0.0;
+  uint16_t bin = LF_BIN_NONE;
+  if (x < c.N - 1 && y < c.M - 1) {
+    double com1 = in[adr + c.N + 1] - in[adr];
+    double com2 = in[adr + 1] - in[adr + c.N];
+    double gx = com1 + com2;
+    double gy = com1 - com2;
+    double norm2 = gx * gx + gy * gy;
+    norm = lf_sqrt(norm2 / 4.0);
+    if (!(norm <= c.rho)) {
+      ang = lf_atan2(gx, -gy);
+      unsigned int i = (unsigned int)(norm * (double)c.n_bins / c.max_grad);
+      if (i >= (unsigned int)c.n_bins) i = (unsigned int)c.n_bins - 1;
+      bin = (uint16_t)i;
+    }
+  }
+  b.angles[f * NM + adr] = ang;
+  b.modgrad[f * NM + adr] = norm;
+  b.bins[f * NM + adr] = bin;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Pseudo-ordering of the seeds (lsd.cpp:757-786) as a stable counting sort.  The reference appends
+// pixels to per-bin linked lists while scanning x outer / y inner and concatenates the lists from
+// the highest non-empty bin down to bin 1.  Here: chunks of LF_SORT_CHUNK_COLS columns; per-chunk
+// bin histograms; scan; in-order scatter.
+__device__ __forceinline__ int sort_nchunks(const LsdConsts &c) {
+  return (c.N - 1 + LF_SORT_CHUNK_COLS - 1) / LF_SORT_CHUNK_COLS;
+}
+__global__ void __launch_bounds__(256) k_seed_hist(LsdConsts c, LsdBuffers b) {
+  extern __shared__ unsigned int hist[];   // n_bins
+  int chunk = blockIdx.x, f = blockIdx.y;
+  for (int i = threadIdx.x; i < c.n_bins; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  const size_t NM = (size_t)c.N * c.M;
+  const uint16_t *bins = b.bins + f * NM;
+  int x0 = chunk * LF_SORT_CHUNK_COLS;
+  int ncol = min(LF_SORT_CHUNK_COLS, c.N - 1 - x0);
+  int rows = c.M - 1;
+  for (int t = threadIdx.x; t < ncol * rows; t += blockDim.x) {
+    int x = x0 + t / rows, y = t % rows;
+    unsigned int bn = bins[(size_t)y * c.N + x];
+    if (bn != LF_BIN_NONE) atomicAdd(&hist[bn], 1u);
+  }
+  __syncthreads();
+  unsigned int *out = b.cnt + ((size_t)f * sort_nchunks(c) + chunk) * c.n_bins;
+  for (int i = threadIdx.x; i < c.n_bins; i += blockDim.x) out[i] = hist[i];
+}
+// one block of n_bins (<= 1024) threads per frame
+__global__ void __launch_bounds__(1024) k_seed_scan(LsdConsts c, LsdBuffers b) {
+  __shared__ unsigned int tot[1024];
+  __shared__ unsigned int suf[1024];
+  __shared__ int top_s;
+  int f = blockIdx.x, bin = threadIdx.x;
+  int nch = sort_nchunks(c);
+  unsigned int *cnt = b.cnt + (size_t)f * nch * c.n_bins;
+  unsigned int run = 0;
+  if (bin < c.n_bins)
+    for (int ch = 0; ch < nch; ch++) {
+      unsigned int t = cnt[(size_t)ch * c.n_bins + bin];
+      cnt[(size_t)ch * c.n_bins + bin] = run;
+      run += t;
+    }
+  tot[bin] = (bin < c.n_bins) ? run : 0;
+  if (bin == 0) top_s = 0;
+  __syncthreads();
+  if (bin > 0 && bin < c.n_bins && tot[bin] != 0) atomicMax(&top_s, bin);
+  __syncthreads();
+  int top = top_s;   // highest non-empty bin >= 1, or 0                      (lsd.cpp:777)
+  // included bins: top..1 (top > 0)  or  {0} (top == 0)                      (lsd.cpp:778-786)
+  bool incl = (top > 0) ? (bin >= 1 && bin <= top) : (bin == 0);
+  suf[bin] = incl ? tot[bin] : 0;
+  __syncthreads();
+  // inclusive suffix sum: suf[bin] = sum_{b' >= bin} included totals
+  for (int o = 1; o < 1024; o <<= 1) {
+    unsigned int v = (bin + o < 1024) ? suf[bin + o] : 0;
+    __syncthreads();
+    suf[bin] += v;
+    __syncthreads();
+  }
+  unsigned int base = incl ? (suf[bin] - tot[bin]) : 0xFFFFFFFFu;   // seeds of higher bins come first
+  if (bin < c.n_bins)
+    for (int ch = 0; ch < nch; ch++) {
+      size_t k = (size_t)ch * c.n_bins + bin;
+      cnt[k] = incl ? (cnt[k] + base) : 0xFFFFFFFFu;
+    }
+  if (bin == 0) b.nseeds[f] = (int)suf[top > 0 ? 1 : 0];
+}
+// one wavefront per (chunk, frame): in-order scatter
+__global__ void __launch_bounds__(64) k_seed_scatter(LsdConsts c, LsdBuffers b) {
+  extern __shared__ unsigned int ctr[];   // n_bins running positions
+  int chunk = blockIdx.x, f = blockIdx.y, lane = lane_id();
+  const size_t NM = (size_t)c.N * c.M;
+  const unsigned int *cnt = b.cnt + ((size_t)f * sort_nchunks(c) + chunk) * c.n_bins;
+  for (int i = lane; i < c.n_bins; i += 64) ctr[i] = cnt[i];
+  __syncthreads();
+  const uint16_t *bins = b.bins + f * NM;
+  uint32_t *seeds = b.seeds + f * NM;
+  int x0 = chunk * LF_SORT_CHUNK_COLS;
+  int ncol = min(LF_SORT_CHUNK_COLS, c.N - 1 - x0);
+  int rows = c.M - 1, total = ncol * rows;
+  for (int t0 = 0; t0 < total; t0 += 64) {
+    int t = t0 + lane;
+    bool v = t < total;
+    int x = x0 + (v ? t / rows : 0), y = v ? t % rows : 0;
+    unsigned int bn = v ? bins[(size_t)y * c.N + x] : LF_BIN_NONE;
+    bool pending = v && bn != LF_BIN_NONE;
+    unsigned int pos = 0xFFFFFFFFu;
+    u64 m;
+    while ((m = __ballot(pending)) != 0) {
+      int leader = __builtin_ctzll(m);
+      unsigned int lb = (unsigned int)rl32((int)bn, leader);
+      bool mine = pending && bn == lb;
+      u64 same = __ballot(mine);
+      unsigned int base = ctr[lb];
+      if (mine) { pos = (base == 0xFFFFFFFFu) ? base : base + (unsigned int)__popcll(same & lanemask_lt()); pending = false; }
+      __syncthreads();   // single wave: orders the LDS read above against the update below
+      if (lane == leader && base != 0xFFFFFFFFu) ctr[lb] = base + (unsigned int)__popcll(same);
+      __syncthreads();
+    }
+    if (pos != 0xFFFFFFFFu) seeds[pos] = (uint32_t)(y * c.N + x);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// The sweep.
+struct Rect {   // lsd.cpp:1075-1084, plus the precision level (p = p0 / 2^plev) for the log tables
+  double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p;
+  int plev;
+};
+struct FrameView {
+  int N, M, lane;
+  const double *angles, *modgrad, *lgam;
+  const LsdConsts *dc;
+  uint8_t *used;
+  uint32_t *reg, *tmp;
+};
+
+// lsd.cpp:147-165
+__device__ __forceinline__ bool d_double_equal(double a, double b) {
+  if (a == b) return true;
+  double abs_diff = lf_fabs(a - b), aa = lf_fabs(a), bb = lf_fabs(b);
+  double abs_max = aa > bb ? aa : bb;
+  if (abs_max < DBL_MIN) abs_max = DBL_MIN;
+  return (abs_diff / abs_max) <= (100.0 * DBL_EPSILON);
+}
+__device__ __forceinline__ double d_dist(double x1, double y1, double x2, double y2) {   // :170-173
+  return lf_sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1));
+}
+// lsd.cpp:799-832
+__device__ __forceinline__ bool d_isaligned(double a, double theta, double prec) {
+  if (a == LF_NOTDEF) return false;
+  theta -= a;
+  if (theta < 0.0) theta = -theta;
+  if (theta > LF_M_3_2_PI) {
+    theta -= LF_M_2__PI;
+    if (theta < 0.0) theta = -theta;
+  }
+  return theta < prec;
+}
+__device__ __forceinline__ double d_angle_diff_signed(double a, double b) {   // :850-857
+  a -= b;
+  while (a <= -LF_PI) a += LF_M_2__PI;
+  while (a > LF_PI) a -= LF_M_2__PI;
+  return a;
+}
+__device__ __forceinline__ double d_angle_diff(double a, double b) {          // :837-845
+  a = d_angle_diff_signed(a, b);
+  if (a < 0.0) a = -a;
+  return a;
+}
+
+// region_grow (lsd.cpp:1610-1656).  Slot s = 9*i + nb enumerates the reference's test order
+// (region pixel i; neighbour nb = 3*(xx-x+1) + (yy-y+1), xx outer, yy inner).  Each step tests the
+// next 64 slots against the CURRENT reg_angle; every slot before the first hit is a final "no";
+// the first hit is committed (used, reg[], sums, reg_angle = atan2) and the step restarts right
+// after it -- exactly the sequential semantics.
+__device__ int d_region_grow(const FrameView &f, int sx, int sy, double prec, double *reg_angle_io,
+                             u64 *n_steps) {
+  const int N = f.N, M = f.M, lane = f.lane;
+  const int seed = sy * N + sx;
+  double reg_angle = f.angles[seed];
+  double sn, cs;
+  lf_sincos(reg_angle, &sn, &cs);
+  double sumdx = cs, sumdy = sn;
+  if (lane == 0) { f.reg[0] = (uint32_t)sx | ((uint32_t)sy << 16); f.used[seed] = 1; }
+  wave_mem_order();
+  int size = 1, cur = 0;
+  for (;;) {
+    int total = size * 9;
+    if (cur >= total) break;
+    (*n_steps)++;
+    int slot = cur + lane;
+    bool act = slot < total;
+    int pi = slot / 9, nb = slot - pi * 9;
+    uint32_t pk = act ? f.reg[pi] : 0u;
+    int ox = nb / 3;
+    int cx = (int)(pk & 0xffffu) + ox - 1, cy = (int)(pk >> 16) + (nb - ox * 3) - 1;
+    bool inb = act && cx >= 0 && cy >= 0 && cx < N && cy < M;
+    int ca = inb ? cy * N + cx : 0;
+    bool cand = inb && (f.used[ca] == 0);
+    double a = cand ? f.angles[ca] : LF_NOTDEF;
+    bool ok = cand && d_isaligned(a, reg_angle, prec);
+    u64 mask = __ballot(ok);
+    if (mask == 0) { cur += min(64, total - cur); continue; }
+    int L = __builtin_ctzll(mask);
+    double aL = rl64(a, L);
+    int caL = rl32(ca, L), cxL = rl32(cx, L), cyL = rl32(cy, L);
+    if (lane == 0) { f.used[caL] = 1; f.reg[size] = (uint32_t)cxL | ((uint32_t)cyL << 16); }
+    wave_mem_order();
+    size++;
+    lf_sincos(aL, &sn, &cs);
+    sumdx += cs;
+    sumdy += sn;
+    reg_angle = lf_atan2(sumdy, sumdx);
+    cur += L + 1;
+  }
+  *reg_angle_io = reg_angle;
+  return size;
+}
+
+// region2rect + get_theta (lsd.cpp:1517-1604, 1474-1512).  The three weighted sums and the three
+// inertia sums are accumulated in the reference's pixel order: lanes prepare the 64 next operands,
+// a uniform loop adds them one by one.
+__device__ void d_region2rect(const FrameView &f, int n, double reg_angle, double prec, double p,
+                              int plev, Rect *rec) {
+  const int N = f.N, lane = f.lane;
+  double x = 0.0, y = 0.0, sum = 0.0;
+  for (int base = 0; base < n; base += 64) {
+    int i = base + lane;
+    bool v = i < n;
+    uint32_t pk = v ? f.reg[i] : 0u;
+    int rx = (int)(pk & 0xffffu), ry = (int)(pk >> 16);
+    double w = v ? f.modgrad[ry * N + rx] : 0.0;
+    double xw = (double)rx * w, yw = (double)ry * w;
+    int cnt = min(64, n - base);
+    for (int j = 0; j < cnt; j++) {
+      x += rl64(xw, j);
+      y += rl64(yw, j);
+      sum += rl64(w, j);
+    }
+  }
+  x /= sum;
+  y /= sum;
+  double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
+  for (int base = 0; base < n; base += 64) {
+    int i = base + lane;
+    bool v = i < n;
+    uint32_t pk = v ? f.reg[i] : 0u;
+    int rx = (int)(pk & 0xffffu), ry = (int)(pk >> 16);
+    double w = v ? f.modgrad[ry * N + rx] : 0.0;
+    double ey = (double)ry - y, ex = (double)rx - x;
+    double txx = ey * ey * w, tyy = ex * ex * w, txy = ex * ey * w;
+    int cnt = min(64, n - base);
+    for (int j = 0; j < cnt; j++) {
+      Ixx += rl64(txx, j);
+      Iyy += rl64(tyy, j);
+      Ixy -= rl64(txy, j);
+    }
+  }
+  double lambda = 0.5 * (Ixx + Iyy - lf_sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+  double theta = lf_fabs(Ixx) > lf_fabs(Iyy) ? lf_atan2(lambda - Ixx, Ixy) : lf_atan2(Ixy, lambda - Iyy);
+  if (d_angle_diff(theta, reg_angle) > prec) theta += LF_PI;
+  double dy, dx;
+  lf_sincos(theta, &dy, &dx);
+  // extents: max/min over the region including 0 (lsd.cpp:1571-1580); order independent
+  double l_min = 0.0, l_max = 0.0, w_min = 0.0, w_max = 0.0;
+  for (int base = 0; base < n; base += 64) {
+    int i = base + lane;
+    if (i < n) {
+      uint32_t pk = f.reg[i];
+      double ex = (double)(int)(pk & 0xffffu) - x, ey = (double)(int)(pk >> 16) - y;
+      double l = ex * dx + ey * dy;
+      double w = -ex * dy + ey * dx;
+      if (l > l_max) l_max = l;
+      if (l < l_min) l_min = l;
+      if (w > w_max) w_max = w;
+      if (w < w_min) w_min = w;
+    }
+  }
+  l_max = wave_max_f64(l_max);
+  l_min = wave_min_f64(l_min);
+  w_max = wave_max_f64(w_max);
+  w_min = wave_min_f64(w_min);
+  rec->x1 = x + l_min * dx;
+  rec->y1 = y + l_min * dy;
+  rec->x2 = x + l_max * dx;
+  rec->y2 = y + l_max * dy;
+  rec->width = w_max - w_min;
+  rec->x = x;
+  rec->y = y;
+  rec->theta = theta;
+  rec->dx = dx;
+  rec->dy = dy;
+  rec->prec = prec;
+  rec->p = p;
+  rec->plev = plev;
+  if (rec->width < 1.0) rec->width = 1.0;
+}
+
+// nfa (lsd.cpp:980-1065).  log_gamma comes from the host table lgam[i] = log_gamma((double)i);
+// log(p), log(1-p), log10(p) from the per-level host tables.  The binomial tail is summed in the
+// reference order; the per-term truncation test (pow, log10) is evaluated for a chunk of terms in
+// parallel lanes and the first term that satisfies it ends the sum, as the sequential `break`.
+__device__ double d_nfa(const FrameView &f, int n, int k, double p, int plev, double logNT) {
+  const int lane = f.lane;
+  const double tolerance = 0.1;
+  if (n == 0 || k == 0) return -logNT;
+  if (n == k) return -logNT - (double)n * f.dc->log10p[plev];
+  double p_term = p / (1.0 - p);
+  double log1term = f.lgam[n + 1] - f.lgam[k + 1] - f.lgam[n - k + 1] + (double)k * f.dc->logp[plev] +
+                    (double)(n - k) * f.dc->log1mp[plev];
+  double term = lf_exp(log1term);
+  if (d_double_equal(term, 0.0)) {
+    if ((double)k > (double)n * p) return -log1term / LF_LN10 - logNT;
+    else return -logNT;
+  }
+  double bin_tail = term;
+  int i0 = k + 1, chunk = 8;
+  while (i0 <= n) {
+    int cnt = min(chunk, n - i0 + 1);
+    int i = i0 + lane;
+    bool v = lane < cnt;
+    double bin_term = v ? (double)(n - i + 1) * (1.0 / (double)i) : 0.0;
+    double mult_term = bin_term * p_term;
+    double my_term = 0.0, my_tail = 0.0;
+    for (int j = 0; j < cnt; j++) {
+      term *= rl64(mult_term, j);
+      bin_tail += term;
+      if (lane == j) { my_term = term; my_tail = bin_tail; }
+    }
+    bool stop = false;
+    if (v && bin_term < 1.0) {
+      double err = my_term * ((1.0 - lf_pow(mult_term, (double)(n - i + 1))) / (1.0 - mult_term) - 1.0);
+      stop = err < tolerance * lf_fabs(-lf_log10(my_tail) - logNT) * my_tail;
+    }
+    u64 m = __ballot(stop);
+    if (m) { bin_tail = rl64(my_tail, __builtin_ctzll(m)); break; }
+    i0 += cnt;
+    if (chunk < 64) chunk <<= 1;
+  }
+  return -lf_log10(bin_tail) - logNT;
+}
+
+// lsd.cpp:1183-1215
+__device__ __forceinline__ double d_inter_low(double x, double x1, double y1, double x2, double y2) {
+  if (d_double_equal(x1, x2) && y1 < y2) return y1;
+  if (d_double_equal(x1, x2) && y1 > y2) return y2;
+  return y1 + (x - x1) * (y2 - y1) / (x2 - x1);
+}
+__device__ __forceinline__ double d_inter_hi(double x, double x1, double y1, double x2, double y2) {
+  if (d_double_equal(x1, x2) && y1 < y2) return y2;
+  if (d_double_equal(x1, x2) && y1 > y2) return y1;
+  return y1 + (x - x1) * (y2 - y1) / (x2 - x1);
+}
+__device__ __forceinline__ double pick4(int i, double a0, double a1, double a2, double a3) {
+  i &= 3;
+  return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3));
+}
+
+// rect_nfa (lsd.cpp:1388-1410) with the rectangle iterator (ri_ini :1317-1383, ri_inc :1247-1310,
+// ri_end :1231-1240) turned into a rasteriser: column x = ceil(vx[0]).. while x <= vx[2]; inside a
+// column y = ceil(ys).. while y <= ye.  Only in-image pixels are counted by the reference, so both
+// ranges are clipped to the image before any int conversion.  Lanes take (column, row-phase) pairs;
+// the two counters are integers, so their reduction order is irrelevant.
+__device__ double d_rect_nfa(const FrameView &f, const Rect &r, double logNT, u64 *n_px) {
+  const int N = f.N, M = f.M, lane = f.lane;
+  double hw = r.width / 2.0;
+  double rx0 = r.x1 - r.dy * hw, ry0 = r.y1 + r.dx * hw;
+  double rx1 = r.x2 - r.dy * hw, ry1 = r.y2 + r.dx * hw;
+  double rx2 = r.x2 + r.dy * hw, ry2 = r.y2 - r.dx * hw;
+  double rx3 = r.x1 + r.dy * hw, ry3 = r.y1 - r.dx * hw;
+  int offset;
+  if (r.x1 < r.x2 && r.y1 <= r.y2) offset = 0;
+  else if (r.x1 >= r.x2 && r.y1 < r.y2) offset = 1;
+  else if (r.x1 > r.x2 && r.y1 >= r.y2) offset = 2;
+  else offset = 3;
+  double vx0 = pick4(offset, rx0, rx1, rx2, rx3), vy0 = pick4(offset, ry0, ry1, ry2, ry3);
+  double vx1 = pick4(offset + 1, rx0, rx1, rx2, rx3), vy1 = pick4(offset + 1, ry0, ry1, ry2, ry3);
+  double vx2 = pick4(offset + 2, rx0, rx1, rx2, rx3), vy2 = pick4(offset + 2, ry0, ry1, ry2, ry3);
+  double vx3 = pick4(offset + 3, rx0, rx1, rx2, rx3), vy3 = pick4(offset + 3, ry0, ry1, ry2, ry3);
+  int pts = 0, alg = 0;
+  double xlo_d = __builtin_ceil(vx0), xhi_d = __builtin_floor(vx2);
+  if (xlo_d < 0.0) xlo_d = 0.0;
+  if (xhi_d > (double)(N - 1)) xhi_d = (double)(N - 1);
+  if (xlo_d <= xhi_d) {
+    int xlo = (int)xlo_d, ncols = (int)xhi_d - xlo + 1;
+    // lanes per column: 64 / (smallest power of two >= ncols), at least 1
+    int cpp = 1;                       // columns per pass
+    while (cpp < ncols && cpp < 64) cpp <<= 1;
+    int lpc = 64 / cpp;                // lanes (row phases) per column
+    int col = lane & (cpp - 1), phase = lane / cpp;
+    for (int cb = 0; cb < ncols; cb += cpp) {
+      int ci = cb + col;
+      if (ci < ncols) {
+        int x = xlo + ci;
+        double xd = (double)x, ys, ye;
+        if (xd < vx3) ys = d_inter_low(xd, vx0, vy0, vx3, vy3);
+        else ys = d_inter_low(xd, vx3, vy3, vx2, vy2);
+        if (xd < vx1) ye = d_inter_hi(xd, vx0, vy0, vx1, vy1);
+        else ye = d_inter_hi(xd, vx1, vy1, vx2, vy2);
+        double ylo_d = __builtin_ceil(ys), yhi_d = __builtin_floor(ye);
+        if (ylo_d < 0.0) ylo_d = 0.0;
+        if (yhi_d > (double)(M - 1)) yhi_d = (double)(M - 1);
+        if (ylo_d <= yhi_d) {
+          int yhi = (int)yhi_d;
+          for (int y = (int)ylo_d + phase; y <= yhi; y += lpc) {
+            ++pts;
+            if (d_isaligned(f.angles[y * N + x], r.theta, r.prec)) ++alg;
+          }
+        }
+      }
+    }
+  }
+  pts = wave_sum_i32(pts);
+  alg = wave_sum_i32(alg);
+  *n_px += (u64)pts;
+  return d_nfa(f, pts, alg, r.p, r.plev, logNT);
+}
+
+// rect_improve (lsd.cpp:1662-1768)
+__device__ double d_rect_improve(const FrameView &f, Rect *rec, double logNT, double eps, u64 *n_nfa,
+                                 u64 *n_px) {
+  Rect r;
+  const double delta = 0.5, delta_2 = delta / 2.0;
+  double log_nfa, log_nfa_new;
+  ++*n_nfa;
+  log_nfa = d_rect_nfa(f, *rec, logNT, n_px);
+  if (log_nfa > eps) return log_nfa;
+  r = *rec;
+  for (int n = 0; n < 5; n++) {   // finer precisions
+    r.p /= 2.0; r.plev++;
+    r.prec = r.p * LF_PI;
+    ++*n_nfa;
+    log_nfa_new = d_rect_nfa(f, r, logNT, n_px);
+    if (log_nfa_new > log_nfa) { log_nfa = log_nfa_new; *rec = r; }
+  }
+  if (log_nfa > eps) return log_nfa;
+  r = *rec;
+  for (int n = 0; n < 5; n++) {   // reduce width
+    if ((r.width - delta) >= 0.5) {
+      r.width -= delta;
+      ++*n_nfa;
+      log_nfa_new = d_rect_nfa(f, r, logNT, n_px);
+      if (log_nfa_new > log_nfa) { *rec = r; log_nfa = log_nfa_new; }
+    }
+  }
+  if (log_nfa > eps) return log_nfa;
+  r = *rec;
+  for (int n = 0; n < 5; n++) {   // reduce one side
+    if ((r.width - delta) >= 0.5) {
+      r.x1 += -r.dy * delta_2;
+      r.y1 += r.dx * delta_2;
+      r.x2 += -r.dy * delta_2;
+      r.y2 += r.dx * delta_2;
+      r.width -= delta;
+      ++*n_nfa;
+      log_nfa_new = d_rect_nfa(f, r, logNT, n_px);
+      if (log_nfa_new > log_nfa) { *rec = r; log_nfa = log_nfa_new; }
+    }
+  }
+  if (log_nfa > eps) return log_nfa;
+  r = *rec;
+  for (int n = 0; n < 5; n++) {   // reduce the other side
+    if ((r.width - delta) >= 0.5) {
+      r.x1 -= -r.dy * delta_2;
+      r.y1 -= r.dx * delta_2;
+      r.x2 -= -r.dy * delta_2;
+      r.y2 -= r.dx * delta_2;
+      r.width -= delta;
+      ++*n_nfa;
+      log_nfa_new = d_rect_nfa(f, r, logNT, n_px);
+      if (log_nfa_new > log_nfa) { *rec = r; log_nfa = log_nfa_new; }
+    }
+  }
+  if (log_nfa > eps) return log_nfa;
+  r = *rec;
+  for (int n = 0; n < 5; n++) {   // even finer precisions
+    r.p /= 2.0; r.plev++;
+    r.prec = r.p * LF_PI;
+    ++*n_nfa;
+    log_nfa_new = d_rect_nfa(f, r, logNT, n_px);
+    if (log_nfa_new > log_nfa) { log_nfa = log_nfa_new; *rec = r; }
+  }
+  return log_nfa;
+}
+
+// reduce_region_radius (lsd.cpp:1775-1841).  The reference removes far pixels with
+// "reg[i] = reg[last]; --size; --i".  Its result is: every position i < #keep that holds a far
+// pixel ("hole", ascending i) receives the kept pixels found at positions >= #keep, taken from the
+// END backwards.  That permutation is reproduced with two ballot-ranked passes over the list.
+__device__ bool d_reduce_region_radius(const FrameView &f, int *reg_size, double reg_angle, double prec,
+                                       double p, Rect *rec, double density_th) {
+  const int N = f.N, lane = f.lane;
+  const int NM = f.N * f.M;
+  int size = *reg_size;
+  double density = (double)size / (d_dist(rec->x1, rec->y1, rec->x2, rec->y2) * rec->width);
+  if (density >= density_th) return true;
+  uint32_t pk0 = f.reg[0];
+  double xc = (double)(int)(pk0 & 0xffffu), yc = (double)(int)(pk0 >> 16);
+  double rad1 = d_dist(xc, yc, rec->x1, rec->y1);
+  double rad2 = d_dist(xc, yc, rec->x2, rec->y2);
+  double rad = rad1 > rad2 ? rad1 : rad2;
+  while (density < density_th) {
+    rad *= 0.75;
+    int nkeep = 0;
+    for (int base = 0; base < size; base += 64) {
+      int i = base + lane;
+      bool v = i < size;
+      uint32_t pk = v ? f.reg[i] : 0u;
+      bool keep = v && !(d_dist(xc, yc, (double)(int)(pk & 0xffffu), (double)(int)(pk >> 16)) > rad);
+      nkeep += __popcll(__ballot(keep));
+    }
+    int nh = 0, nf = 0;
+    for (int base = 0; base < size; base += 64) {
+      int i = base + lane;
+      bool v = i < size;
+      uint32_t pk = v ? f.reg[i] : 0u;
+      int rx = (int)(pk & 0xffffu), ry = (int)(pk >> 16);
+      bool far = v && (d_dist(xc, yc, (double)rx, (double)ry) > rad);
+      if (far) f.used[ry * N + rx] = 0;
+      bool hole = far && i < nkeep;
+      bool fill = v && !far && i >= nkeep;
+      u64 mh = __ballot(hole), mf = __ballot(fill);
+      if (hole) f.tmp[nh + __popcll(mh & lanemask_lt())] = (uint32_t)i;
+      if (fill) f.tmp[NM - 1 - (nf + __popcll(mf & lanemask_lt()))] = pk;
+      nh += __popcll(mh);
+      nf += __popcll(mf);
+    }
+    wave_mem_order();
+    // hole j (ascending position) <- fillers from the end: filler k (ascending) sits at tmp[NM-1-k]
+    for (int base = 0; base < nh; base += 64) {
+      int j = base + lane;
+      if (j < nh) f.reg[f.tmp[j]] = f.tmp[NM - nf + j];
+    }
+    wave_mem_order();
+    size = nkeep;
+    if (size < 2) { *reg_size = size; return false; }
+    d_region2rect(f, size, reg_angle, prec, p, 0, rec);
+    density = (double)size / (d_dist(rec->x1, rec->y1, rec->x2, rec->y2) * rec->width);
+  }
+  *reg_size = size;
+  return true;
+}
+
+// refine (lsd.cpp:1853-1921)
+__device__ bool d_refine(const FrameView &f, int *reg_size, double reg_angle, double prec, double p,
+                         Rect *rec, double density_th, u64 *n_steps) {
+  const int N = f.N, lane = f.lane;
+  int size = *reg_size;
+  double density = (double)size / (d_dist(rec->x1, rec->y1, rec->x2, rec->y2) * rec->width);
+  if (density >= density_th) return true;
+  uint32_t pk0 = f.reg[0];
+  int sx = (int)(pk0 & 0xffffu), sy = (int)(pk0 >> 16);
+  double xc = (double)sx, yc = (double)sy;
+  double ang_c = f.angles[sy * N + sx];
+  double sum = 0.0, s_sum = 0.0;
+  int n = 0;
+  for (int base = 0; base < size; base += 64) {
+    int i = base + lane;
+    bool v = i < size;
+    uint32_t pk = v ? f.reg[i] : 0u;
+    int rx = (int)(pk & 0xffffu), ry = (int)(pk >> 16);
+    if (v) f.used[ry * N + rx] = 0;
+    bool q = v && d_dist(xc, yc, (double)rx, (double)ry) < rec->width;
+    double ang_d = q ? d_angle_diff_signed(f.angles[ry * N + rx], ang_c) : 0.0;
+    u64 m = __ballot(q);
+    while (m) {               // reference order: ascending i
+      int j = __builtin_ctzll(m);
+      m &= m - 1;
+      double d = rl64(ang_d, j);
+      sum += d;
+      s_sum += d * d;
+      ++n;
+    }
+  }
+  wave_mem_order();
+  double mean_angle = sum / (double)n;
+  double tau = 2.0 * lf_sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
+  size = d_region_grow(f, sx, sy, tau, &reg_angle, n_steps);
+  *reg_size = size;
+  if (size < 2) return false;
+  d_region2rect(f, size, reg_angle, prec, p, 0, rec);
+  density = (double)size / (d_dist(rec->x1, rec->y1, rec->x2, rec->y2) * rec->width);
+  if (density < density_th) return d_reduce_region_radius(f, reg_size, reg_angle, prec, p, rec, density_th);
+  return true;
+}
+
+// LineSegmentDetection main loop (lsd.cpp:1996-2053): one wavefront per frame.
+__global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *dc, LsdBuffers b) {
+  const int fidx = blockIdx.x, lane = lane_id();
+  const size_t NM = (size_t)c.N * c.M;
+  FrameView f;
+  f.N = c.N; f.M = c.M; f.lane = lane;
+  f.angles = b.angles + fidx * NM;
+  f.modgrad = b.modgrad + fidx * NM;
+  f.lgam = b.lgam;
+  f.dc = dc;
+  f.used = b.used + fidx * NM;
+  f.reg = b.reg + fidx * NM;
+  f.tmp = b.tmp + fidx * NM;
+  uint16_t *labels = b.labels + fidx * NM;
+  const uint32_t *seeds = b.seeds + fidx * NM;
+  double *segs = b.segs + (size_t)fidx * c.seg_cap * LF_SEG_STRIDE;
+  const int nseeds = b.nseeds[fidx];
+  u64 n_grow = 0, n_steps = 0, n_nfa = 0, n_px = 0, n_regpx = 0;
+  int ls_count = 0;
+  int s = 0;
+  while (s < nseeds) {
+    int idx = s + lane;
+    bool v = idx < nseeds;
+    uint32_t addr = v ? seeds[idx] : 0u;
+    bool isfree = v && f.used[addr] == 0;      // angles != NOTDEF holds for every listed pixel
+    u64 m = __ballot(isfree);
+    if (m == 0) { s += 64; continue; }
+    int L = __builtin_ctzll(m);
+    int sa = rl32((int)addr, L);
+    s += L + 1;
+    int sx = sa % c.N, sy = sa / c.N;
+    double reg_angle;
+    ++n_grow;
+    int reg_size = d_region_grow(f, sx, sy, c.prec, &reg_angle, &n_steps);
+    n_regpx += (u64)reg_size;
+    if (reg_size < c.min_reg_size) continue;
+    Rect rec;
+    d_region2rect(f, reg_size, reg_angle, c.prec, c.p, 0, &rec);
+    if (!d_refine(f, &reg_size, reg_angle, c.prec, c.p, &rec, c.density_th, &n_steps)) continue;
+    double log_nfa = d_rect_improve(f, &rec, c.logNT, c.eps, &n_nfa, &n_px);
+    if (log_nfa <= c.eps) continue;
+    ++ls_count;
+    rec.x1 += 0.5; rec.y1 += 0.5;
+    rec.x2 += 0.5; rec.y2 += 0.5;
+    if (c.scale != 1.0) {
+      rec.x1 /= c.scale; rec.y1 /= c.scale;
+      rec.x2 /= c.scale; rec.y2 /= c.scale;
+      rec.width /= c.scale;
+    }
+    if (ls_count <= c.seg_cap && lane == 0) {
+      double *o = segs + (size_t)(ls_count - 1) * LF_SEG_STRIDE;
+      o[0] = rec.x1; o[1] = rec.y1; o[2] = rec.x2; o[3] = rec.y2; o[4] = rec.width;
+    }
+    for (int base = 0; base < reg_size; base += 64) {
+      int i = base + lane;
+      if (i < reg_size) {
+        uint32_t pk = f.reg[i];
+        labels[(int)(pk >> 16) * c.N + (int)(pk & 0xffffu)] = (uint16_t)ls_count;
+      }
+    }
+  }
+  if (lane == 0) {
+    b.nsegs[fidx] = ls_count;
+    if (b.stats) {
+      unsigned long long *st = b.stats + (size_t)fidx * 8;
+      st[0] = n_grow; st[1] = n_steps; st[2] = n_nfa; st[3] = n_px; st[4] = n_regpx;
+      st[5] = (u64)nseeds; st[6] = 0; st[7] = 0;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int B, hipStream_t st) {
+  const size_t NM = (size_t)c.N * c.M;
+  dim3 blk(256);
+  hipLaunchKernelGGL(k_gauss_x, dim3((c.N + 255) / 256, c.H, B), blk, 0, st, c, b);
+  hipLaunchKernelGGL(k_gauss_y, dim3((c.N + 255) / 256, c.M, B), blk, 0, st, c, b);
+  hipLaunchKernelGGL(k_ll_angle, dim3((c.N + 255) / 256, c.M, B), blk, 0, st, c, b);
+  int nch = (c.N - 1 + LF_SORT_CHUNK_COLS - 1) / LF_SORT_CHUNK_COLS;
+  size_t lds = sizeof(unsigned int) * (size_t)c.n_bins;
+  hipLaunchKernelGGL(k_seed_hist, dim3(nch, B), blk, lds, st, c, b);
+  hipLaunchKernelGGL(k_seed_scan, dim3(B), dim3(1024), 0, st, c, b);
+  hipLaunchKernelGGL(k_seed_scatter, dim3(nch, B), dim3(64), lds, st, c, b);
+  (void)hipMemsetAsync(b.used, 0, NM * (size_t)B, st);
+  (void)hipMemsetAsync(b.labels, 0, NM * (size_t)B * sizeof(uint16_t), st);
+  hipLaunchKernelGGL(k_lsd_sweep, dim3(B), dim3(64), 0, st, c, b.dconsts, b);
+}

@@ -1,0 +1,225 @@
+/* lf_math.h -- deterministic fp64 elementary functions for the line front end.
+ *
+ * Why this exists: LSD (reference external/lsd/lsd.cpp) calls atan2/sin/cos/exp/
+ * log10/pow from the host libm.  glibc (CPU) and OCML (gfx950) disagree in the
+ * last ulp, so neither can be used on both sides of a parity test.  These
+ * functions use ONLY IEEE-754 +,-,*,/ and sqrt on doubles (no fma, no table
+ * look-ups, no libm), so the same source compiled by gcc (-ffp-contract=off)
+ * and by hipcc (--offload-arch=gfx950 -ffp-contract=off) returns bit-identical
+ * results.  Accuracy is <= 2 ulp against glibc (tests/test_lf_math.py), which
+ * is far below anything that can flip an LSD decision.
+ *
+ * Polynomial coefficients are the classical minimax sets published with
+ * FreeBSD msun / fdlibm (Sun Microsystems, "freely granted" licence); the
+ * argument reductions below are written for this project (single-division
+ * atan2, double-double pi/2 reduction).
+ *
+ * This header is product code.  oracle/ includes it only for its
+ * "lfmath" build flavour (see oracle/README in DESIGN.md section 3).
+ */
+#ifndef LF_MATH_H
+#define LF_MATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define LF_HD __host__ __device__ static inline
+#else
+#define LF_HD static inline
+#endif
+
+#define LF_PI      3.14159265358979323846   /* M_PI, as lsd.cpp:99-101 */
+#define LF_PI_LO   1.2246467991473532e-16   /* pi - (double)pi */
+#define LF_PIO2    1.5707963267948966
+#define LF_LN10    2.30258509299404568402   /* M_LN10, lsd.cpp:94-96 */
+
+LF_HD uint64_t lf_bits(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
+LF_HD double lf_from_bits(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
+LF_HD double lf_fabs(double x) { return lf_from_bits(lf_bits(x) & 0x7fffffffffffffffULL); }
+LF_HD double lf_copysign(double m, double s) {
+  return lf_from_bits((lf_bits(m) & 0x7fffffffffffffffULL) | (lf_bits(s) & 0x8000000000000000ULL));
+}
+LF_HD double lf_sqrt(double x) { return __builtin_sqrt(x); }  /* IEEE correctly rounded on both sides */
+LF_HD double lf_pow2i(int k) { return lf_from_bits((uint64_t)(k + 1023) << 52); } /* -1022<=k<=1023 */
+
+/* ------------------------------------------------------------------ atan2 */
+/* atan(t) for the reduced argument t, |t| <= 7/16 (approximately).          */
+LF_HD double lf_atan_poly(double t) {
+  const double a0 = 3.33333333333329318027e-01, a1 = -1.99999999998764832476e-01,
+               a2 = 1.42857142725034663711e-01, a3 = -1.11111104054623557880e-01,
+               a4 = 9.09088713343650656196e-02, a5 = -7.69187620504482999495e-02,
+               a6 = 6.66107313738753120669e-02, a7 = -5.83357013379057348645e-02,
+               a8 = 4.97687799461593236017e-02, a9 = -3.65315727442169155270e-02,
+               a10 = 1.62858201153657823623e-02;
+  double z = t * t, w = z * z;
+  double s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
+  double s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
+  return t * (s1 + s2); /* atan(t) = t - this */
+}
+
+/* atan2(y,x) with one division.  With u = |y|/|x| the breakpoints are those
+ * of the classical 4-interval scheme (7/16, 11/16, 19/16, 39/16) but the
+ * reduced argument (u-c)/(1+c u) is formed as (|y| - c|x|)/(|x| + c|y|). */
+LF_HD double lf_atan2(double y, double x) {
+  if (x != x || y != y) return x + y;
+  double ax = lf_fabs(x), ay = lf_fabs(y);
+  int xneg = (int)(lf_bits(x) >> 63);
+  if (ay == 0.0) return xneg ? lf_copysign(LF_PI, y) : y;
+  if (ax == 0.0) return lf_copysign(LF_PIO2, y);
+  /* bring the larger magnitude near 1 so products cannot over/underflow */
+  {
+    double m = ax > ay ? ax : ay;
+    int e = (int)((lf_bits(m) >> 52) & 0x7ff) - 1023;
+    if (e > 500 || e < -500) {
+      if (e == 1024) { /* infinities */
+        ax = (ax > 1.7e308) ? 1.0 : 0.0;
+        ay = (ay > 1.7e308) ? 1.0 : 0.0;
+      } else {
+        int h = -e / 2; double s = lf_pow2i(h);
+        ax = ax * s * s; ay = ay * s * s; /* exact unless a denormal operand is lost: irrelevant at ratio 2^-500 */
+        if (e & 1) { double s2 = lf_pow2i(-e - 2 * h); ax *= s2; ay *= s2; }
+      }
+      if (ax == 0.0) return lf_copysign(LF_PIO2, y);
+      if (ay == 0.0 && !xneg) return lf_copysign(0.0, y);
+    }
+  }
+  double num, den, hi, lo;
+  if (16.0 * ay < 7.0 * ax)        { num = ay;              den = ax;              hi = 0.0;                    lo = 0.0; }
+  else if (16.0 * ay < 11.0 * ax)  { num = 2.0 * ay - ax;   den = 2.0 * ax + ay;   hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
+  else if (16.0 * ay < 19.0 * ax)  { num = ay - ax;         den = ax + ay;         hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
+  else if (16.0 * ay < 39.0 * ax)  { num = ay - 1.5 * ax;   den = ax + 1.5 * ay;   hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
+  else                             { num = -ax;             den = ay;              hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
+  double t = num / den;
+  double z = hi - ((lf_atan_poly(t) - lo) - t);   /* atan(|y/x|) in [0, pi/2] */
+  if (xneg) z = LF_PI - (z - LF_PI_LO);
+  return lf_copysign(z, y);
+}
+
+/* ---------------------------------------------------------------- sin/cos */
+LF_HD double lf_ksin(double x, double y) {
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  double z = x * x, v = z * x;
+  double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+LF_HD double lf_kcos(double x, double y) {
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double z = x * x, w = z * z;
+  double r = z * (C1 + z * (C2 + z * C3)) + (w * w) * (C4 + z * (C5 + z * C6));
+  double hz = 0.5 * z, u = 1.0 - hz;
+  return u + (((1.0 - u) - hz) + (z * r - x * y));
+}
+/* sin and cos of x, valid for |x| < 2^20 (the front end needs |x| <= 2 pi). */
+LF_HD void lf_sincos(double x, double *s, double *c) {
+  const double INVPIO2 = 6.36619772367581382433e-01;
+  const double P1 = 1.5707963267341256, P2 = 6.077100506303966e-11, P3 = 2.0222662487959506e-21;
+  double q = x * INVPIO2;
+  int n = (int)(q + (q < 0.0 ? -0.5 : 0.5));
+  double fn = (double)n;
+  double r0 = x - fn * P1;            /* exact: P1 has 33 significant bits */
+  double w1 = fn * P2;                /* exact */
+  double r1 = r0 - w1;                /* TwoDiff */
+  double bb = r1 - r0;
+  double e1 = (r0 - (r1 - bb)) - (w1 + bb);
+  double w2 = fn * P3;
+  double yh = r1 - w2;
+  double yl = ((r1 - yh) - w2) + e1;
+  double ks = lf_ksin(yh, yl), kc = lf_kcos(yh, yl);
+  switch (n & 3) {
+    case 0:  *s = ks;  *c = kc;  break;
+    case 1:  *s = kc;  *c = -ks; break;
+    case 2:  *s = -ks; *c = -kc; break;
+    default: *s = -kc; *c = ks;  break;
+  }
+}
+LF_HD double lf_sin(double x) { double s, c; lf_sincos(x, &s, &c); return s; }
+LF_HD double lf_cos(double x) { double s, c; lf_sincos(x, &s, &c); return c; }
+
+/* -------------------------------------------------------------------- exp */
+LF_HD double lf_exp(double x) {
+  const double LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10,
+               INVLN2 = 1.44269504088896338700e+00;
+  const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+               P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+               P5 = 4.13813679705723846039e-08;
+  if (x != x) return x;
+  if (x > 709.782712893383973096) return lf_from_bits(0x7ff0000000000000ULL);
+  if (x < -745.2) return 0.0;
+  double q = x * INVLN2;
+  int k = (int)(q + (q < 0.0 ? -0.5 : 0.5));
+  double fk = (double)k;
+  double hi = x - fk * LN2HI, lo = fk * LN2LO;
+  double r = hi - lo;
+  double t = r * r;
+  double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  int k1 = k / 2, k2 = k - k1;
+  return (y * lf_pow2i(k1)) * lf_pow2i(k2);
+}
+
+/* -------------------------------------------------------------------- log */
+/* returns k and f with x = 2^k (1+f), sqrt(2)/2 <= 1+f < sqrt(2) */
+LF_HD double lf_log_reduce(double x, int *kout) {
+  int k = 0;
+  uint64_t u = lf_bits(x);
+  if ((u >> 52) == 0) { x *= 18014398509481984.0; k -= 54; u = lf_bits(x); } /* subnormal */
+  k += (int)(u >> 52) - 1023;
+  u = (u & 0x000fffffffffffffULL);
+  /* mantissa above sqrt(2) -> halve */
+  if (u >= 0x6a09e667f3bcdULL) { k += 1; u |= 0x3fe0000000000000ULL; }
+  else u |= 0x3ff0000000000000ULL;
+  *kout = k;
+  return lf_from_bits(u) - 1.0;
+}
+/* log(1+f) - f, i.e. the part after the leading term */
+LF_HD double lf_log_tail(double f, double *hfsq_out) {
+  const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01,
+               L3 = 2.857142874366239149e-01, L4 = 2.222219843214978396e-01,
+               L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+               L7 = 1.479819860511658591e-01;
+  double s = f / (2.0 + f);
+  double z = s * s, w = z * z;
+  double t1 = w * (L2 + w * (L4 + w * L6));
+  double t2 = z * (L1 + w * (L3 + w * (L5 + w * L7)));
+  double R = t2 + t1;
+  double hfsq = 0.5 * f * f;
+  *hfsq_out = hfsq;
+  return s * (hfsq + R);
+}
+LF_HD double lf_log(double x) {
+  const double LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10;
+  if (x != x) return x;
+  if (x < 0.0) return lf_from_bits(0x7ff8000000000000ULL);
+  if (x == 0.0) return lf_from_bits(0xfff0000000000000ULL);
+  if (lf_bits(x) == 0x7ff0000000000000ULL) return x;
+  int k; double f = lf_log_reduce(x, &k);
+  double hfsq, t = lf_log_tail(f, &hfsq);
+  double dk = (double)k;
+  return dk * LN2HI - ((hfsq - (t + dk * LN2LO)) - f);
+}
+LF_HD double lf_log10(double x) {
+  const double IVLN10 = 4.34294481903251816668e-01, LG2HI = 3.01029995663611771306e-01,
+               LG2LO = 3.69423907715893078616e-13;
+  if (x != x) return x;
+  if (x < 0.0) return lf_from_bits(0x7ff8000000000000ULL);
+  if (x == 0.0) return lf_from_bits(0xfff0000000000000ULL);
+  if (lf_bits(x) == 0x7ff0000000000000ULL) return x;
+  int k; double f = lf_log_reduce(x, &k);
+  double hfsq, t = lf_log_tail(f, &hfsq);
+  double lg = f - (hfsq - t);              /* log(1+f) */
+  double dk = (double)k;
+  return (dk * LG2LO + IVLN10 * lg) + dk * LG2HI;
+}
+/* x^y for x > 0 (LSD only needs a ratio in (0,1) to an integer-valued power,
+ * inside an error bound).  Relative error ~ |y log x| * 1e-16. */
+LF_HD double lf_pow(double x, double y) {
+  if (y == 0.0) return 1.0;
+  if (x == 1.0) return 1.0;
+  return lf_exp(y * lf_log(x));
+}
+
+#endif /* LF_MATH_H */

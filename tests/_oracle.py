@@ -1,0 +1,131 @@
+"""ctypes bindings to the TEST-ONLY checkers under oracle/ (never imported by the product).
+
+  oracle_lib("ref") -> oracle/_build/liboracle_ref.so  (CPU restatement, host libm)
+  oracle_lib("lf")  -> oracle/_build/liboracle_lf.so   (CPU restatement, lf_math.h)
+  ref_lsd_lib()     -> oracle/_ref/liblsd_ref.so       (the reference's own lsd.c, built
+                                                        by oracle/Makefile; may be absent)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+_libs = {}
+
+
+def build_oracle():
+    """(Re)build the oracle libraries if sources are newer; cheap no-op otherwise."""
+    subprocess.run(["make", "-s", "-C", ODIR], check=True, stdout=subprocess.DEVNULL)
+
+
+def oracle_lib(flavour="ref"):
+    if flavour not in _libs:
+        path = os.path.join(ODIR, "_build", "liboracle_%s.so" % flavour)
+        if not os.path.exists(path):
+            build_oracle()
+        lib = C.CDLL(path)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        lib.oracle_lsd.restype = C.c_int
+        lib.oracle_lsd.argtypes = [dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                   C.c_double, C.c_double, C.c_double, C.c_int, C.c_double,
+                                   dp, C.c_int, ip, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   dp, dp, dp, ip, C.POINTER(C.c_int), C.POINTER(C.c_long)]
+        lib.oracle_log_gamma.restype = C.c_double
+        lib.oracle_log_gamma.argtypes = [C.c_double]
+        _libs[flavour] = lib
+    return _libs[flavour]
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def lsd_oracle(gray_u8, ang_th=22.5, density_th=0.7, flavour="ref", scale=0.8, debug=False,
+               cap=20000):
+    """Run the restated LSD on a u8 image exactly as callLsd would (u8 -> double)."""
+    lib = oracle_lib(flavour)
+    g = np.ascontiguousarray(gray_u8, dtype=np.uint8)
+    h, w = g.shape
+    img = g.astype(np.float64)
+    N, M = int(np.floor(w * scale)), int(np.floor(h * scale))
+    if scale == 1.0:
+        N, M = w, h
+    segs = np.zeros((cap, 5), np.float64)
+    labels = np.zeros((M, N), np.int32)
+    n_, m_ = C.c_int(), C.c_int()
+    dbg = {}
+    args_dbg = [None, None, None, None, None, None]
+    if debug:
+        dbg["scaled"] = np.zeros((M, N), np.float64)
+        dbg["angles"] = np.zeros((M, N), np.float64)
+        dbg["modgrad"] = np.zeros((M, N), np.float64)
+        dbg["seeds"] = np.zeros(M * N, np.int32)
+        ns = C.c_int()
+        st = (C.c_long * 5)()
+        args_dbg = [_dp(dbg["scaled"]), _dp(dbg["angles"]), _dp(dbg["modgrad"]),
+                    _ip(dbg["seeds"]), C.byref(ns), st]
+    n = lib.oracle_lsd(_dp(img), w, h, scale, 0.6, 2.0, ang_th, 0.0, density_th, 1024, 255.0,
+                       _dp(segs), cap, _ip(labels), C.byref(n_), C.byref(m_), *args_dbg)
+    assert n <= cap and n_.value == N and m_.value == M
+    if debug:
+        dbg["seeds"] = dbg["seeds"][:ns.value].copy()
+        dbg["stats"] = dict(zip(["region_grow", "isaligned_tests", "rect_nfa", "rect_pixels",
+                                 "accepted_px"], list(st)))
+        return segs[:n].copy(), labels, dbg
+    return segs[:n].copy(), labels
+
+
+# ------------------------------------------------------------------ the reference itself
+class _ImageDouble(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_double)), ("xsize", C.c_uint), ("ysize", C.c_uint)]
+
+
+class _ImageInt(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_int)), ("xsize", C.c_uint), ("ysize", C.c_uint)]
+
+
+class _NTuple(C.Structure):
+    _fields_ = [("size", C.c_uint), ("max_size", C.c_uint), ("dim", C.c_uint),
+                ("values", C.POINTER(C.c_double))]
+
+
+def ref_lsd_lib():
+    path = os.path.join(ODIR, "_ref", "liblsd_ref.so")
+    if not os.path.exists(path):
+        return None
+    if "reflsd" not in _libs:
+        lib = C.CDLL(path)
+        lib.LineSegmentDetection.restype = C.POINTER(_NTuple)
+        lib.LineSegmentDetection.argtypes = [C.POINTER(_ImageDouble), C.c_double, C.c_double,
+                                             C.c_double, C.c_double, C.c_double, C.c_double,
+                                             C.c_int, C.c_double,
+                                             C.POINTER(C.POINTER(_ImageInt))]
+        _libs["reflsd"] = lib
+    return _libs["reflsd"]
+
+
+def lsd_reference(gray_u8, ang_th=22.5, density_th=0.7, scale=0.8):
+    """The reference's LineSegmentDetection (external/lsd/lsd-1.5/lsd.c compiled as-is) with the
+    fixed parameters of lsd_scale() (lsd.cpp:2070-2090) and the u8->double copy of callLsd."""
+    lib = ref_lsd_lib()
+    assert lib is not None, "oracle/_ref/liblsd_ref.so not built (needs /root/reference)"
+    g = np.ascontiguousarray(gray_u8, dtype=np.uint8)
+    h, w = g.shape
+    img = g.astype(np.float64)
+    im = _ImageDouble(_dp(img), w, h)
+    reg = C.POINTER(_ImageInt)()
+    out = lib.LineSegmentDetection(C.byref(im), scale, 0.6, 2.0, ang_th, 0.0, density_th, 1024,
+                                   255.0, C.byref(reg))
+    o = out.contents
+    assert o.dim == 5
+    segs = np.ctypeslib.as_array(o.values, shape=(o.size * 5,)).reshape(-1, 5).copy()
+    r = reg.contents
+    labels = np.ctypeslib.as_array(r.data, shape=(r.ysize, r.xsize)).astype(np.int32).copy()
+    return segs, labels  # (leaks the two small reference allocations; test process only)

@@ -1,0 +1,71 @@
+"""GPU parity (run with -m gpu on the MI355X box): HIP LSD vs the oracle, through the C ABI.
+
+The oracle flavour "lf" evaluates the device-side transcendentals with the same lf_math.h source as
+the kernels, so EVERYTHING must agree bit for bit: scaled image, angles, gradient magnitudes, seed
+order, segments (doubles) and the integer region labels.  The "ref" flavour (host libm, pinned to the
+reference) must agree on the integer support.
+"""
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("tum", 22.5), ("tum", 40.0), ("chairs", 22.5), ("chairs", 40.0)]
+
+
+def _ctx(img, ang, batch=1):
+    from lineslam_amd import capi
+    p = capi.default_params()
+    p.lsd_angle_th = ang
+    h, w = img.shape
+    return capi.Context(w, h, max_batch=batch, params=p)
+
+
+@pytest.mark.parametrize("name,ang", CASES)
+def test_lsd_bit_exact_vs_oracle(built_lib, fixtures_lsd, name, ang):
+    img = fixtures_lsd[name]
+    ctx = _ctx(img, ang)
+    segs, labels = ctx.lsd(img)
+    so, lo, dbg = O.lsd_oracle(img, ang, flavour="lf", debug=True)
+    assert np.array_equal(ctx.lsd_debug(0, 0), dbg["scaled"])
+    assert np.array_equal(ctx.lsd_debug(0, 2)[:-1, :-1], dbg["modgrad"][:-1, :-1])
+    assert np.array_equal(ctx.lsd_debug(0, 1), dbg["angles"])
+    assert np.array_equal(ctx.lsd_debug(0, 3).astype(np.int64), dbg["seeds"].astype(np.int64))
+    assert np.array_equal(labels.astype(np.int32), lo)
+    assert segs.shape == so.shape and np.array_equal(segs, so)
+    # integer support also identical to the libm flavour == the reference's golden labels
+    key = "%s_a%g" % (name, ang)
+    assert np.array_equal(labels, fixtures_lsd[key + "_labels"])
+    ctx.close()
+
+
+def test_lsd_batch_of_shifted_frames(built_lib, fixtures_lsd):
+    """Frames of one batch are independent: 6 different crops/shifts in one launch."""
+    import torch
+    base = fixtures_lsd["tum"]
+    frames = [np.roll(base, (3 * k, 5 * k), axis=(0, 1)) for k in range(6)]
+    frames[3] = np.ascontiguousarray(frames[3][::-1])
+    batch = np.stack(frames)
+    ctx = _ctx(base, 40.0, batch=6)
+    d = torch.from_numpy(batch).cuda()
+    ctx.lsd_batch_device(d.data_ptr(), 6)
+    for k in range(6):
+        so, lo = O.lsd_oracle(frames[k], 40.0, flavour="lf")
+        assert np.array_equal(ctx.lsd_labels(k).astype(np.int32), lo), k
+        assert np.array_equal(ctx.lsd_segments(k), so), k
+    ctx.close()
+
+
+def test_lsd_flat_and_noise_images(built_lib):
+    """Edge cases: a constant image (no seeds, no segments) and pure noise."""
+    from lineslam_amd import capi
+    rng = np.random.default_rng(7)
+    for img in (np.full((480, 640), 128, np.uint8), rng.integers(0, 256, (480, 640), dtype=np.uint8)):
+        ctx = capi.Context(640, 480)
+        segs, labels = ctx.lsd(img)
+        so, lo = O.lsd_oracle(img, 22.5, flavour="lf")
+        assert segs.shape == so.shape and np.array_equal(segs, so)
+        assert np.array_equal(labels.astype(np.int32), lo)
+        ctx.close()
