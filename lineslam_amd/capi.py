@@ -75,6 +75,13 @@ def lib():
             raise ImportError(
                 "liblinefront.so is not built (%s). Run `python -m lineslam_amd.build` "
                 "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        try:
+            # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; two HIP runtimes in one process
+            # cannot both own the device.  Loading torch first makes this library bind to the same
+            # runtime (plumbing only: device tensors, streams, torch.distributed).
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(_lib, name)   # AttributeError if the library does not export it
