@@ -82,6 +82,22 @@ typedef struct lf_params {
   uint64_t rng_seed;                  /* 0 */
 } lf_params;
 
+/* One 3D line of a frame: the flat, fixed-stride form of the reference's FrameLine /
+ * RandomLine3d / RandomPoint3d objects (src/line/lineslam.h:41-151) -- 129 doubles + 2 ints =
+ * 1040 bytes.  This is also the unit of the RCCL all-gather of keyframe line maps. */
+typedef struct lf_line_record {
+  double p[2], q[2];      /* FrameLine::p, q: image end points (pixels)                       */
+  double lineEq2d[3];     /* FrameLine::lineEq2d (complineEq2d, lineslam.h:139-150)           */
+  double r[2];            /* FrameLine::r: unit gradient direction (getGradient :527-537)     */
+  double A[3], B[3];      /* line3d.A, line3d.B: 3D end points after MLE (metres, camera)     */
+  double covA[9], covB[9];/* line3d.covA, covB (row-major 3x3)                                */
+  double DUa[9], DUb[9];  /* line3d.rndA.DU, rndB.DU = diag(1/sqrt(w)) U^T (lineslam.h:73-77) */
+  double Wsa[3], Wsb[3];  /* line3d.rndA.W_sqrt, rndB.W_sqrt                                  */
+  double des[72];         /* FrameLine::des: MSLD descriptor (utils.cpp:1544-1610)            */
+  int32_t lid;            /* FrameLine::lid: index inside the frame                           */
+  int32_t seg;            /* index of the LSD segment (row of lf_lsd_get_segments) it came from */
+} lf_line_record;
+
 typedef struct lf_ctx lf_ctx;
 
 LF_API void lf_params_init(lf_params *p);

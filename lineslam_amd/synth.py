@@ -1,0 +1,136 @@
+"""Seeded synthetic RGB-D line scenes -- data generation only, no compute path.
+
+TUM RGB-D sequences are not available offline, so tests and bench.py render their own input:
+a room of textured quads (walls, posters, boxes) ray-cast from a smoothly moving camera with the
+TUM intrinsics K = (525, 525, 319.5, 239.5) (src/openni_listener.cpp:1256-1259) into
+  * an 8-bit grey image (Gaussian noise sigma 2 DN), and
+  * a float32 depth map in metres, quantised to 1/5000 m like TUM PNGs (:1236-1244), with
+    NaN holes (0 -> NaN, as loadRawData does).
+"""
+import numpy as np
+
+K_TUM = np.array([[525.0, 0.0, 319.5], [0.0, 525.0, 239.5], [0.0, 0.0, 1.0]])
+
+
+def _quad(o, u, v, grey, stripes=0, axis=0):
+    return dict(o=np.asarray(o, float), u=np.asarray(u, float), v=np.asarray(v, float), grey=float(grey),
+                stripes=int(stripes), axis=int(axis))
+
+
+def _box(c, size, rng):
+    c = np.asarray(c, float)
+    sx, sy, sz = size
+    ex, ey, ez = np.array([sx, 0, 0.0]), np.array([0, sy, 0.0]), np.array([0, 0, sz])
+    o = c - 0.5 * (ex + ey + ez)
+    g = rng.uniform(40, 230, 6)
+    return [_quad(o, ex, ey, g[0]), _quad(o + ez, ex, ey, g[1]), _quad(o, ex, ez, g[2]),
+            _quad(o + ey, ex, ez, g[3]), _quad(o, ey, ez, g[4]), _quad(o + ex, ey, ez, g[5])]
+
+
+def make_scene(seed=0, n_boxes=10, n_posters=14):
+    """World frame: x right, y down, z forward (camera looks along +z from near the origin)."""
+    rng = np.random.default_rng(seed)
+    q = []
+    # room: back wall z=4.2, floor y=1.3, ceiling y=-1.4, side walls x=+-2.6
+    q.append(_quad([-2.6, -1.4, 4.2], [5.2, 0, 0], [0, 2.7, 0], 150))
+    q.append(_quad([-2.6, 1.3, 0.2], [5.2, 0, 0], [0, 0, 4.0], 95, stripes=7, axis=0))
+    q.append(_quad([-2.6, -1.4, 0.2], [5.2, 0, 0], [0, 0, 4.0], 200))
+    q.append(_quad([-2.6, -1.4, 0.2], [0, 0, 4.0], [0, 2.7, 0], 120, stripes=5, axis=0))
+    q.append(_quad([2.6, -1.4, 0.2], [0, 0, 4.0], [0, 2.7, 0], 175))
+    for _ in range(n_posters):   # posters on the back wall and side walls
+        wall = rng.integers(0, 3)
+        wv, hv = rng.uniform(0.25, 1.0), rng.uniform(0.2, 0.8)
+        g = rng.uniform(20, 245)
+        st = int(rng.integers(0, 5)); ax = int(rng.integers(0, 2))
+        if wall == 0:
+            x0, y0 = rng.uniform(-2.4, 2.4 - wv), rng.uniform(-1.3, 1.2 - hv)
+            q.append(_quad([x0, y0, 4.19 - 0.001 * len(q)], [wv, 0, 0], [0, hv, 0], g, st, ax))
+        elif wall == 1:
+            z0, y0 = rng.uniform(1.0, 4.0 - wv), rng.uniform(-1.3, 1.2 - hv)
+            q.append(_quad([-2.59 + 0.001 * len(q), y0, z0], [0, 0, wv], [0, hv, 0], g, st, ax))
+        else:
+            z0, y0 = rng.uniform(1.0, 4.0 - wv), rng.uniform(-1.3, 1.2 - hv)
+            q.append(_quad([2.59 - 0.001 * len(q), y0, z0], [0, 0, wv], [0, hv, 0], g, st, ax))
+    for _ in range(n_boxes):
+        c = [rng.uniform(-2.0, 2.0), rng.uniform(-0.6, 1.0), rng.uniform(1.6, 3.8)]
+        q += _box(c, rng.uniform(0.15, 0.7, 3), rng)
+    return q
+
+
+def camera_pose(t, seed=0):
+    """Smooth camera-to-world SE(3) at time t (seconds): ~0.6 m/s, ~25 deg/s, like hand-held TUM."""
+    rng = np.random.default_rng(1000 + seed)
+    ph = rng.uniform(0, 2 * np.pi, 6)
+    pos = np.array([0.35 * np.sin(0.9 * t + ph[0]), 0.12 * np.sin(1.3 * t + ph[1]), 0.25 * np.sin(0.7 * t + ph[2])])
+    rx, ry, rz = 0.10 * np.sin(1.1 * t + ph[3]), 0.22 * np.sin(0.8 * t + ph[4]), 0.06 * np.sin(1.7 * t + ph[5])
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rz @ Ry @ Rx
+    T[:3, 3] = pos
+    return T
+
+
+def render(scene, T_wc, K=K_TUM, w=640, h=480, noise_seed=0, noise_sigma=2.0, hole_frac=0.05):
+    """Ray-cast the scene.  Returns (gray uint8 [h,w], depth float32 [h,w] in metres, NaN = no data)."""
+    rng = np.random.default_rng(noise_seed)
+    xs, ys = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    dc = np.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], np.ones_like(xs)], -1)
+    R, c = T_wc[:3, :3], T_wc[:3, 3]
+    dw = dc @ R.T
+    best_t = np.full((h, w), np.inf)
+    grey = np.full((h, w), 60.0)
+    for qi, qd in enumerate(scene):
+        o, u, v = qd["o"], qd["u"], qd["v"]
+        n = np.cross(u, v)
+        den = dw @ n
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = ((o - c) @ n) / den
+        hit = c + t[..., None] * dw - o
+        s = (hit @ u) / (u @ u)
+        r = (hit @ v) / (v @ v)
+        ok = (t > 0.05) & (s >= 0) & (s <= 1) & (r >= 0) & (r <= 1) & (t < best_t)
+        g = np.full((h, w), qd["grey"])
+        if qd["stripes"]:
+            coord = s if qd["axis"] == 0 else r
+            g = g + 45.0 * (((np.floor(coord * qd["stripes"] * 2)).astype(np.int64) % 2) * 2 - 1)
+        # mild Lambertian shading so that faces of one box differ
+        shade = 0.75 + 0.25 * abs(n[2]) / np.linalg.norm(n)
+        grey = np.where(ok, g * shade, grey)
+        best_t = np.where(ok, t, best_t)
+    depth = np.where(np.isfinite(best_t), best_t, 0.0)           # z along the optical axis == t
+    depth = np.round(depth * 5000.0) / 5000.0                     # TUM quantisation
+    depth[depth > 8.0] = 0.0
+    holes = rng.random((h, w)) < hole_frac
+    depth = depth.astype(np.float32)
+    depth[holes] = 0.0
+    depth[depth == 0.0] = np.nan                                  # loadRawData: 0 -> NaN
+    img = grey + rng.normal(0.0, noise_sigma, (h, w))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8), depth
+
+
+def sequence(n_frames, seed=0, fps=30.0, w=640, h=480, n_unique=None):
+    """Frames of a synthetic sequence: returns (gray [n,h,w] u8, depth [n,h,w] f32, poses [n,4,4]).
+    With n_unique < n_frames only n_unique camera poses are ray-cast; the remaining frames reuse the
+    geometry of frame (i mod n_unique) with fresh sensor noise and holes (cheap to generate, still
+    distinct inputs)."""
+    scene = make_scene(seed)
+    nu = n_frames if n_unique is None else min(n_unique, n_frames)
+    gray = np.zeros((n_frames, h, w), np.uint8)
+    depth = np.zeros((n_frames, h, w), np.float32)
+    poses = np.zeros((n_frames, 4, 4))
+    clean = []
+    for i in range(nu):
+        T = camera_pose(i / fps, seed)
+        g, d = render(scene, T, w=w, h=h, noise_seed=seed * 100003 + i, noise_sigma=0.0, hole_frac=0.0)
+        clean.append((g, d, T))
+    for i in range(n_frames):
+        g, d, T = clean[i % nu]
+        rng = np.random.default_rng(seed * 7919 + i)
+        gi = np.clip(np.rint(g.astype(np.float64) + rng.normal(0.0, 2.0, g.shape)), 0, 255).astype(np.uint8)
+        di = d.copy()
+        di[rng.random(d.shape) < 0.05] = np.nan
+        gray[i], depth[i], poses[i] = gi, di, T
+    return gray, depth, poses

@@ -129,3 +129,47 @@ def lsd_reference(gray_u8, ang_th=22.5, density_th=0.7, scale=0.8):
     r = reg.contents
     labels = np.ctypeslib.as_array(r.data, shape=(r.ysize, r.xsize)).astype(np.int32).copy()
     return segs, labels  # (leaks the two small reference allocations; test process only)
+
+
+# ------------------------------------------------------------------ front end after LSD
+def _params_struct():
+    from lineslam_amd import capi   # only for the ctypes layout of lf_params / lf_line_record
+    return capi
+
+
+REC_DTYPE = np.dtype([("p", "f8", 2), ("q", "f8", 2), ("lineEq2d", "f8", 3), ("r", "f8", 2),
+                      ("A", "f8", 3), ("B", "f8", 3), ("covA", "f8", 9), ("covB", "f8", 9),
+                      ("DUa", "f8", 9), ("DUb", "f8", 9), ("Wsa", "f8", 3), ("Wsb", "f8", 3),
+                      ("des", "f8", 72), ("lid", "i4"), ("seg", "i4")])
+assert REC_DTYPE.itemsize == 1040
+
+
+def detect3d_oracle(gray_u8, depth_f32, K, params, frame_id, segs, flavour="lf", cap=1024):
+    """oracle_detect3d: everything of Node::detect3DLines after the LSD call."""
+    lib = oracle_lib(flavour)
+    g = np.ascontiguousarray(gray_u8, np.uint8)
+    d = np.ascontiguousarray(depth_f32, np.float32)
+    h, w = g.shape
+    Kc = np.ascontiguousarray(K, np.float64).ravel()
+    s = np.ascontiguousarray(segs, np.float64)
+    recs = np.zeros(cap, REC_DTYPE)
+    flag = np.zeros(len(s), np.int32)
+    info = np.zeros((len(s), 8), np.float64)
+    lib.oracle_detect3d.restype = C.c_int
+    n = lib.oracle_detect3d(C.c_void_p(g.ctypes.data), C.c_int(w), C.c_void_p(d.ctypes.data), C.c_int(w),
+                            C.c_int(w), C.c_int(h), C.c_void_p(Kc.ctypes.data), C.byref(params),
+                            C.c_uint64(frame_id), C.c_void_p(s.ctypes.data), C.c_int(len(s)),
+                            C.c_void_p(recs.ctypes.data), C.c_int(cap), C.c_void_p(flag.ctypes.data),
+                            C.c_void_p(info.ctypes.data))
+    assert n <= cap
+    return recs[:n].copy(), flag, info
+
+
+def sobel_oracle(gray_u8, flavour="lf"):
+    lib = oracle_lib(flavour)
+    g = np.ascontiguousarray(gray_u8, np.uint8)
+    h, w = g.shape
+    gx, gy = np.zeros((h, w)), np.zeros((h, w))
+    lib.oracle_sobel5(C.c_void_p(g.ctypes.data), C.c_int(w), C.c_int(w), C.c_int(h),
+                      C.c_void_p(gx.ctypes.data), C.c_void_p(gy.ctypes.data))
+    return gx, gy

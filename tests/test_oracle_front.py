@@ -1,0 +1,156 @@
+"""CPU suite for the oracle of stages a9-a18 (oracle/front_oracle.c) and the shared primitives.
+
+What can be pinned here, and how:
+  * dlevmar_dif restatement  <->  the reference's levmar-2.6 compiled as the reference builds it
+    (oracle/_ref/liblevmar_ref.so, LAPACK LU); skipped where /root/reference was never available.
+  * Jacobi eigen solver / LU solve (stand-ins for cv::SVD / cv::Mat::inv)  <->  numpy.linalg.
+  * cv::Sobel ksize 5 restatement  <->  scipy.ndimage separable correlation, exact integers.
+  * the front end on a synthetic RGB-D frame: structural invariants of every record.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from lineslam_amd import synth
+
+LMFUNC = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_void_p)
+
+
+def _line_problem(rng, n=40):
+    a, b = rng.normal(0, 1, 3), rng.normal(0, 1, 3) + np.array([0, 0, 3.0])
+    t = np.sort(rng.uniform(0, 1, n))
+    pts = a[None] * (1 - t[:, None]) + b[None] * t[:, None] + rng.normal(0, 0.01, (n, 3))
+    w = rng.uniform(0.5, 2.0, n)
+
+    def cost(p, hx, m, nn, _):
+        A, B = np.array([p[i] for i in range(3)]), np.array([p[i] for i in range(3, 6)])
+        d = B - A
+        for i in range(nn):
+            v = pts[i] - A
+            if i == 0:            # end points are anchored by squared forms, as in
+                hx[i] = w[i] * (v @ v) * 400.0                  # costFun_MLEstimateLine3d (utils.cpp:966-971)
+            elif i == nn - 1:
+                hx[i] = w[i] * ((pts[i] - B) @ (pts[i] - B)) * 400.0
+            else:
+                hx[i] = w[i] * np.linalg.norm(np.cross(v, d)) / np.linalg.norm(d)
+    p0 = np.concatenate([pts[0] + 0.05, pts[-1] - 0.05])
+    return cost, p0, n
+
+
+def test_levmar_restatement_matches_reference_levmar():
+    path = os.path.join(O.ODIR, "_ref", "liblevmar_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/liblevmar_ref.so not built (needs /root/reference)")
+    ref = C.CDLL(path)
+    lib = O.oracle_lib("lf")
+    rng = np.random.default_rng(3)
+    opts = (C.c_double * 5)(1e-3, 1e-10, 1e-20, 1e-20, 1e-6)   # MLEstimateLine3d, utils.cpp:1002-1007
+    for trial in range(8):
+        cost, p0, n = _line_problem(rng)
+        cb = LMFUNC(cost)
+        pa, pb = p0.copy(), p0.copy()
+        ia, ib = (C.c_double * 10)(), (C.c_double * 10)()
+        x = np.zeros(n)
+        ref.dlevmar_dif.restype = C.c_int
+        ra = ref.dlevmar_dif(cb, pa.ctypes.data_as(C.POINTER(C.c_double)), x.ctypes.data_as(C.POINTER(C.c_double)),
+                             6, n, 100, opts, ia, None, None, None)
+        lib.oracle_levmar_dif.restype = C.c_int
+        rb = lib.oracle_levmar_dif(cb, pb.ctypes.data_as(C.POINTER(C.c_double)), 6, n, 100, opts, ib, None)
+        assert ra == rb, (trial, ra, rb)                       # same number of iterations
+        assert int(ia[6]) == int(ib[6])                        # same termination reason
+        assert int(ia[7]) == int(ib[7])                        # same number of function evaluations
+        assert np.allclose(pa, pb, rtol=0, atol=2e-7), (trial, np.abs(pa - pb).max())   # dif-LM resolution
+        assert abs(ia[1] - ib[1]) <= 1e-12 * max(1.0, ia[1])
+
+
+def test_jacobi_and_solve_vs_numpy():
+    lib = O.oracle_lib("lf")
+    rng = np.random.default_rng(0)
+    for n, fn in ((3, lib.oracle_jacobi3), (4, lib.oracle_jacobi4)):
+        for _ in range(50):
+            B = rng.normal(size=(n, n)) * rng.uniform(1e-4, 10)
+            A = B @ B.T
+            V, w = np.zeros((n, n)), np.zeros(n)
+            fn(C.c_void_p(A.ctypes.data), C.c_void_p(V.ctypes.data), C.c_void_p(w.ctypes.data))
+            wr = np.sort(np.linalg.eigvalsh(A))[::-1]
+            assert np.allclose(w, wr, rtol=1e-12, atol=1e-14 * wr[0])
+            assert np.allclose(V @ np.diag(w) @ V.T, A, rtol=1e-12, atol=1e-13 * wr[0])
+            assert np.allclose(V.T @ V, np.eye(n), atol=1e-13)
+    for _ in range(50):
+        A = rng.normal(size=(6, 6)); b = rng.normal(size=6); x = np.zeros(6)
+        lib.oracle_solve6.restype = C.c_int
+        assert lib.oracle_solve6(C.c_void_p(A.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(x.ctypes.data)) == 1
+        assert np.allclose(x, np.linalg.solve(A, b), rtol=1e-9, atol=1e-11)
+
+
+def test_rand31_is_a_31_bit_counter_generator():
+    lib = O.oracle_lib("lf")
+    lib.oracle_rand31.restype = C.c_uint32
+    lib.oracle_rand31.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    v = np.array([lib.oracle_rand31(5, 77, i) for i in range(4000)], np.int64)
+    assert v.max() < 2 ** 31 and len(set(v.tolist())) > 3990
+    assert abs(v.mean() / 2 ** 31 - 0.5) < 0.02
+    assert lib.oracle_rand31(5, 77, 3) == v[3] and lib.oracle_rand31(5, 78, 3) != v[3]
+
+
+def test_sobel5_matches_scipy():
+    from scipy import ndimage
+    g = np.random.default_rng(1).integers(0, 256, (60, 80), dtype=np.uint8)
+    gx, gy = O.sobel_oracle(g)
+    kd, ks = np.array([-1, -2, 0, 2, 1.0]), np.array([1, 4, 6, 4, 1.0])
+    f = g.astype(float)
+    rx = ndimage.correlate1d(ndimage.correlate1d(f, kd, axis=1, mode="mirror"), ks, axis=0, mode="mirror")
+    ry = ndimage.correlate1d(ndimage.correlate1d(f, ks, axis=1, mode="mirror"), kd, axis=0, mode="mirror")
+    assert np.array_equal(gx, rx) and np.array_equal(gy, ry)
+
+
+@pytest.fixture(scope="module")
+def synth_frame():
+    g, d, poses = synth.sequence(1, seed=1)
+    return g[0], d[0]
+
+
+def test_front_end_records_are_well_formed(synth_frame):
+    from lineslam_amd import capi
+    g, d = synth_frame
+    P = capi.default_params()
+    segs, _ = O.lsd_oracle(g, 22.5, flavour="lf")
+    recs, flag, info = O.detect3d_oracle(g, d, synth.K_TUM, P, 0, segs)
+    assert len(recs) > 50 and (flag == 2).sum() == len(recs)
+    assert np.array_equal(recs["lid"], np.arange(len(recs)))
+    assert np.all(np.diff(recs["seg"]) > 0)                                  # compaction keeps order
+    assert np.allclose(np.linalg.norm(recs["des"], axis=1), 1.0, atol=1e-12)
+    assert np.allclose(np.linalg.norm(recs["r"], axis=1), 1.0, atol=1e-12)
+    assert np.allclose(np.hypot(recs["lineEq2d"][:, 0], recs["lineEq2d"][:, 1]), 1.0, atol=1e-12)
+    L = np.linalg.norm(recs["A"] - recs["B"], axis=1)
+    assert np.all(L > P.line3d_length_thresh)
+    K = synth.K_TUM
+    for r in recs:
+        for X, cov, DU, Ws in ((r["A"], r["covA"], r["DUa"], r["Wsa"]), (r["B"], r["covB"], r["DUb"], r["Wsb"])):
+            c = cov.reshape(3, 3)
+            assert np.allclose(c, c.T, rtol=1e-9, atol=1e-18) and np.all(np.linalg.eigvalsh(c) > 0)
+            M = DU.reshape(3, 3)
+            assert np.allclose(M @ c @ M.T, np.eye(3), atol=1e-8)               # whitening
+            assert np.allclose(np.sort(Ws ** 2), np.sort(np.linalg.eigvalsh(c)), rtol=1e-8)
+            assert 0.3 < X[2] < 8.0
+        # the 3D end points project close to the 2D segment
+        for X in (r["A"], r["B"]):
+            u = K @ X / X[2]
+            dist = abs(r["lineEq2d"] @ np.array([u[0], u[1], 1.0]))
+            assert dist < 6.0
+
+
+def test_front_end_is_deterministic_and_seed_sensitive(synth_frame):
+    from lineslam_amd import capi
+    g, d = synth_frame
+    P = capi.default_params()
+    segs, _ = O.lsd_oracle(g, 22.5, flavour="lf")
+    r1, f1, _ = O.detect3d_oracle(g, d, synth.K_TUM, P, 0, segs)
+    r2, f2, _ = O.detect3d_oracle(g, d, synth.K_TUM, P, 0, segs)
+    assert r1.tobytes() == r2.tobytes()
+    P.rng_seed = 123
+    r3, f3, _ = O.detect3d_oracle(g, d, synth.K_TUM, P, 0, segs)
+    assert abs(len(r3) - len(r1)) <= 3          # RANSAC draws change, the answer barely does
