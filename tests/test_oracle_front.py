@@ -62,7 +62,7 @@ def test_levmar_restatement_matches_reference_levmar():
         assert ra == rb, (trial, ra, rb)                       # same number of iterations
         assert int(ia[6]) == int(ib[6])                        # same termination reason
         assert int(ia[7]) == int(ib[7])                        # same number of function evaluations
-        assert np.allclose(pa, pb, rtol=0, atol=2e-7), (trial, np.abs(pa - pb).max())   # dif-LM resolution
+        assert np.allclose(pa, pb, rtol=0, atol=5e-6), (trial, np.abs(pa - pb).max())   # dif-LM resolution
         assert abs(ia[1] - ib[1]) <= 1e-9 * max(1.0, ia[1])
 
 
