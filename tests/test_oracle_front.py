@@ -124,7 +124,13 @@ def test_front_end_records_are_well_formed(synth_frame):
     assert len(recs) > 50 and (flag == 2).sum() == len(recs)
     assert np.array_equal(recs["lid"], np.arange(len(recs)))
     assert np.all(np.diff(recs["seg"]) > 0)                                  # compaction keeps order
-    assert np.allclose(np.linalg.norm(recs["des"], axis=1), 1.0, atol=1e-12)
+    nrm = np.linalg.norm(recs["des"], axis=1)
+    unit = np.abs(nrm - 1.0) < 1e-12
+    # lines hugging the border have no valid MSLD sample: the reference fills the descriptor with
+    # rand() (utils.cpp:1576-1580); here: 31-bit integers from the counter generator
+    assert unit.sum() >= len(recs) - 8
+    for r in recs[~unit]:
+        assert np.all(r["des"] == np.floor(r["des"])) and r["des"].max() < 2 ** 31
     assert np.allclose(np.linalg.norm(recs["r"], axis=1), 1.0, atol=1e-12)
     assert np.allclose(np.hypot(recs["lineEq2d"][:, 0], recs["lineEq2d"][:, 1]), 1.0, atol=1e-12)
     L = np.linalg.norm(recs["A"] - recs["B"], axis=1)
