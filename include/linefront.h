@@ -146,6 +146,35 @@ LF_API int lf_lsd_get_debug(lf_ctx *ctx, int frame, int which, void *out, size_t
 LF_API int lf_lsd(lf_ctx *ctx, const uint8_t *gray, int row_stride, int width, int height,
                   double *segs, int cap, int *n_out, uint16_t *labels_or_null);
 
+/* ---- a9-a18: the rest of the per-frame front end --------------------------------------------
+ * Replaces  void Node::detect3DLines(const cv::Mat& gray_uchar, const cv::Mat& depth_float,
+ *                double line2d_len_thres, const cv::Mat& K, double ratio_of_collinear_pts,
+ *                double line_3d_len_thres_m, double depth_scaling, std::string algorithm)
+ * (src/node.h:286-287, src/line/lineslam.cpp:200-357) with algorithm == "LSD"; the scalar
+ * arguments live in lf_params (line_segment_len_thresh, ratio_of_collinear_pts,
+ * line3d_length_thresh, depth_scaling).  The result is Node::lines (only lines with depth, lid =
+ * index) as lf_line_record rows.
+ *
+ * lf_detect3d_batch_device: device-resident batch, asynchronous on the context stream; runs LSD and
+ * the 3D-line stage.  `d_depth`: float32 metres, NaN or 0 = no measurement; strides in ELEMENTS.
+ * K: 3x3 row-major camera matrix.  frame_ids (host array or NULL = 0..n-1) key the counter-based
+ * random generator that replaces rand() in the RANSAC line fit (src/line/utils.h:49-60). */
+LF_API int lf_detect3d_batch_device(lf_ctx *ctx, const uint8_t *d_gray, size_t gray_frame_stride,
+                                    int gray_row_stride, const float *d_depth,
+                                    size_t depth_frame_stride, int depth_row_stride, int n_frames,
+                                    const double K[9], const uint64_t *frame_ids);
+/* Node::lines of frame `frame` of the last batch (synchronises). */
+LF_API int lf_frame_get_lines(lf_ctx *ctx, int frame, lf_line_record *out, int cap, int *n_out);
+/* Per-LSD-segment diagnostics for stage-level parity tests: flags[i] = 0 dropped by the 2D length
+ * filter, 1 no 3D line, 2 3D line; info[i][32] = A(3) B(3) covA(9) covB(9) numSmp #samples
+ * #inliers levmar-iterations levmar-stop RANSAC-A(3). */
+LF_API int lf_frame_get_candidates(lf_ctx *ctx, int frame, int32_t *flags, double *info, int cap,
+                                   int *n_out);
+/* Host-buffer convenience with the argument order of Node::detect3DLines. */
+LF_API int lf_detect3d(lf_ctx *ctx, const uint8_t *gray, int gray_row_stride, const float *depth_m,
+                       int depth_row_stride, int width, int height, const double K[9],
+                       uint64_t frame_id, lf_line_record *out, int cap, int *n_out);
+
 #ifdef __cplusplus
 }
 #endif

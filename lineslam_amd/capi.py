@@ -65,7 +65,19 @@ SYMBOLS = {
     "lf_lsd_get_labels": (_i, [_vp, _i, _vp]),
     "lf_lsd_get_debug": (_i, [_vp, _i, _i, _vp, C.c_size_t, _pi]),
     "lf_lsd": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _pi, _vp]),
+    "lf_detect3d_batch_device": (_i, [_vp, _vp, C.c_size_t, _i, _vp, C.c_size_t, _i, _i, _vp, _vp]),
+    "lf_frame_get_lines": (_i, [_vp, _i, _vp, _i, _pi]),
+    "lf_frame_get_candidates": (_i, [_vp, _i, _vp, _vp, _i, _pi]),
+    "lf_detect3d": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, C.c_uint64, _vp, _i, _pi]),
 }
+
+# numpy view of struct lf_line_record (1040 bytes)
+REC_DTYPE = np.dtype([("p", "f8", 2), ("q", "f8", 2), ("lineEq2d", "f8", 3), ("r", "f8", 2),
+                      ("A", "f8", 3), ("B", "f8", 3), ("covA", "f8", 9), ("covB", "f8", 9),
+                      ("DUa", "f8", 9), ("DUb", "f8", 9), ("Wsa", "f8", 3), ("Wsb", "f8", 3),
+                      ("des", "f8", 72), ("lid", "i4"), ("seg", "i4")])
+assert REC_DTYPE.itemsize == 1040
+CAND_STRIDE = 32
 
 
 def lib():
@@ -178,3 +190,41 @@ class Context:
         self._chk(lib().lf_lsd(self._h, g.ctypes.data, w, w, h, segs.ctypes.data, cap, C.byref(n),
                                lab.ctypes.data if want_labels else None), "lf_lsd")
         return segs[:n.value].copy(), lab
+
+    # ---- 3D lines (Node::detect3DLines) --------------------------------------------------
+    def detect3d_batch_device(self, d_gray_ptr, d_depth_ptr, n_frames, K, frame_ids=None):
+        """LSD + 3D-line stage on device-resident u8 grey / f32 depth batches (async)."""
+        Kc = np.ascontiguousarray(K, np.float64).ravel()
+        ids = None if frame_ids is None else np.ascontiguousarray(frame_ids, np.uint64)
+        w, h = self.width, self.height
+        self._chk(lib().lf_detect3d_batch_device(self._h, _vp(d_gray_ptr), w * h, w, _vp(d_depth_ptr),
+                                                 w * h, w, n_frames, Kc.ctypes.data,
+                                                 ids.ctypes.data if ids is not None else None),
+                  "lf_detect3d_batch_device")
+
+    def frame_lines(self, frame, cap=512):
+        recs = np.zeros(cap, REC_DTYPE)
+        n = C.c_int()
+        self._chk(lib().lf_frame_get_lines(self._h, frame, recs.ctypes.data, cap, C.byref(n)),
+                  "lf_frame_get_lines")
+        return recs[:n.value].copy()
+
+    def frame_candidates(self, frame, cap=1024):
+        flags = np.zeros(cap, np.int32)
+        info = np.zeros((cap, CAND_STRIDE), np.float64)
+        n = C.c_int()
+        self._chk(lib().lf_frame_get_candidates(self._h, frame, flags.ctypes.data, info.ctypes.data, cap,
+                                                C.byref(n)), "lf_frame_get_candidates")
+        return flags[:n.value].copy(), info[:n.value].copy()
+
+    def detect3d(self, gray_u8, depth_f32, K, frame_id=0, cap=512):
+        """Node::detect3DLines equivalent: host images in, Node::lines (records) out."""
+        g = np.ascontiguousarray(gray_u8, np.uint8)
+        d = np.ascontiguousarray(depth_f32, np.float32)
+        h, w = g.shape
+        Kc = np.ascontiguousarray(K, np.float64).ravel()
+        recs = np.zeros(cap, REC_DTYPE)
+        n = C.c_int()
+        self._chk(lib().lf_detect3d(self._h, g.ctypes.data, w, d.ctypes.data, w, w, h, Kc.ctypes.data,
+                                    frame_id, recs.ctypes.data, cap, C.byref(n)), "lf_detect3d")
+        return recs[:n.value].copy()

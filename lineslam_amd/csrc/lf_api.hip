@@ -6,6 +6,7 @@
 // kernels.  There is no CPU compute path in this file.
 #include "../../include/linefront.h"
 #include "lf_lsd.h"
+#include "lf_front.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -25,7 +26,11 @@ struct lf_ctx {
   LsdConsts lc;
   LsdBuffers lb;
   std::vector<void *> allocs;
+  FrontConsts fc;
+  FrontBuffers fb;
+  uint64_t *d_frame_ids = nullptr;
   uint8_t *d_gray_stage = nullptr;   // staging for the host-pointer convenience entry points
+  float *d_depth_stage = nullptr;
   int last_batch = 0;
   std::string err;
 };
@@ -268,6 +273,23 @@ static int alloc_lsd(lf_ctx *c) {
   ALLOC(c, b.nsegs, B);
   ALLOC(c, b.stats, B * 8);
   ALLOC(c, c->d_gray_stage, (size_t)c->W * c->H);
+  ALLOC(c, c->d_depth_stage, (size_t)c->W * c->H);
+  // ---- 3D-line stage
+  FrontConsts &fc = c->fc;
+  FrontBuffers &fb = c->fb;
+  memset(&fc, 0, sizeof fc);
+  memset(&fb, 0, sizeof fb);
+  fc.W = c->W; fc.H = c->H;
+  fc.cand_cap = 1024; fc.line_cap = 512; fc.seg_cap = lc.seg_cap;
+  ALLOC(c, fb.gx, B * (size_t)c->W * c->H);
+  ALLOC(c, fb.gy, B * (size_t)c->W * c->H);
+  ALLOC(c, c->d_frame_ids, B);
+  ALLOC(c, fb.cand_flag, B * fc.cand_cap);
+  ALLOC(c, fb.cand_out, B * (size_t)fc.cand_cap * LF_CAND_STRIDE);
+  ALLOC(c, fb.recs, B * (size_t)fc.line_cap);
+  ALLOC(c, fb.nlines, B);
+  fb.frame_ids = c->d_frame_ids;
+  fb.segs = b.segs; fb.nsegs = b.nsegs;
   return LF_OK;
 }
 
@@ -418,6 +440,88 @@ int lf_lsd(lf_ctx *c, const uint8_t *gray, int row_stride, int width, int height
     if (r2 != LF_OK) return r2;
   }
   return r;
+}
+
+// ---- a9-a18 ------------------------------------------------------------------------------------
+static void set_camera(lf_ctx *c, const double K[9]) {
+  FrontConsts &fc = c->fc;
+  for (int i = 0; i < 9; i++) fc.K[i] = K[i];
+  // Eigen::Matrix3d::inverse() as used at lineslam.cpp:238-242: cofactors / determinant
+  double c00 = K[4] * K[8] - K[5] * K[7], c10 = K[2] * K[7] - K[1] * K[8], c20 = K[1] * K[5] - K[2] * K[4];
+  double det = c00 * K[0] + c10 * K[3] + c20 * K[6], inv = 1.0 / det;
+  fc.Kinv[0] = c00 * inv; fc.Kinv[1] = c10 * inv; fc.Kinv[2] = c20 * inv;
+  fc.Kinv[3] = (K[5] * K[6] - K[3] * K[8]) * inv; fc.Kinv[4] = (K[0] * K[8] - K[2] * K[6]) * inv; fc.Kinv[5] = (K[2] * K[3] - K[0] * K[5]) * inv;
+  fc.Kinv[6] = (K[3] * K[7] - K[4] * K[6]) * inv; fc.Kinv[7] = (K[1] * K[6] - K[0] * K[7]) * inv; fc.Kinv[8] = (K[0] * K[4] - K[1] * K[3]) * inv;
+  fc.P = c->params;
+}
+
+int lf_detect3d_batch_device(lf_ctx *c, const uint8_t *d_gray, size_t gray_frame_stride, int gray_row_stride,
+                             const float *d_depth, size_t depth_frame_stride, int depth_row_stride,
+                             int n_frames, const double K[9], const uint64_t *frame_ids) {
+  if (!c || !d_gray || !d_depth || !K || n_frames < 1 || gray_row_stride < c->W || depth_row_stride < c->W)
+    return LF_ERR_INVALID;
+  if (n_frames > c->maxB) return LF_ERR_CAPACITY;
+  if (c->params.line_sample_max_num + 1 > LF_MAX_SAMPLES) return LF_ERR_UNSUPPORTED;
+  int r = lf_lsd_batch_device(c, d_gray, gray_frame_stride, gray_row_stride, n_frames);
+  if (r != LF_OK) return r;
+  std::vector<uint64_t> ids((size_t)n_frames);
+  for (int i = 0; i < n_frames; i++) ids[i] = frame_ids ? frame_ids[i] : (uint64_t)i;
+  HIPCHK(c, hipMemcpyAsync(c->d_frame_ids, ids.data(), ids.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // ids is a stack vector (tiny copy)
+  set_camera(c, K);
+  c->fb.gray = d_gray; c->fb.gray_frame_stride = gray_frame_stride; c->fb.gray_row_stride = gray_row_stride;
+  c->fb.depth = d_depth; c->fb.depth_frame_stride = depth_frame_stride; c->fb.depth_row_stride = depth_row_stride;
+  lf_front_launch(c->fc, c->fb, n_frames, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return LF_OK;
+}
+
+int lf_frame_get_lines(lf_ctx *c, int frame, lf_line_record *out, int cap, int *n_out) {
+  if (!c || frame < 0 || frame >= c->last_batch || !n_out || cap < 0 || (cap > 0 && !out)) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int n = 0;
+  HIPCHK(c, hipMemcpyAsync(&n, c->fb.nlines + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_out = n;
+  int m = n < cap ? n : cap;
+  if (m > c->fc.line_cap) m = c->fc.line_cap;
+  if (m > 0) {
+    HIPCHK(c, hipMemcpyAsync(out, c->fb.recs + (size_t)frame * c->fc.line_cap, (size_t)m * sizeof(lf_line_record),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return (n > cap || n > c->fc.line_cap) ? LF_ERR_CAPACITY : LF_OK;
+}
+
+int lf_frame_get_candidates(lf_ctx *c, int frame, int32_t *flags, double *info, int cap, int *n_out) {
+  if (!c || frame < 0 || frame >= c->last_batch || !n_out || cap < 0) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int n = 0;
+  HIPCHK(c, hipMemcpyAsync(&n, c->lb.nsegs + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n > c->fc.cand_cap) n = c->fc.cand_cap;
+  *n_out = n;
+  int m = n < cap ? n : cap;
+  if (m > 0 && flags) HIPCHK(c, hipMemcpyAsync(flags, c->fb.cand_flag + (size_t)frame * c->fc.cand_cap, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  if (m > 0 && info) HIPCHK(c, hipMemcpyAsync(info, c->fb.cand_out + (size_t)frame * c->fc.cand_cap * LF_CAND_STRIDE, (size_t)m * LF_CAND_STRIDE * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return n > cap ? LF_ERR_CAPACITY : LF_OK;
+}
+
+int lf_detect3d(lf_ctx *c, const uint8_t *gray, int gray_row_stride, const float *depth_m, int depth_row_stride,
+                int width, int height, const double K[9], uint64_t frame_id, lf_line_record *out, int cap,
+                int *n_out) {
+  if (!c || !gray || !depth_m || width != c->W || height != c->H || gray_row_stride < width || depth_row_stride < width)
+    return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpy2DAsync(c->d_gray_stage, (size_t)width, gray, (size_t)gray_row_stride, (size_t)width,
+                             (size_t)height, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(c->d_depth_stage, (size_t)width * 4, depth_m, (size_t)depth_row_stride * 4,
+                             (size_t)width * 4, (size_t)height, hipMemcpyHostToDevice, c->stream));
+  int r = lf_detect3d_batch_device(c, c->d_gray_stage, (size_t)width * height, width, c->d_depth_stage,
+                                   (size_t)width * height, width, 1, K, &frame_id);
+  if (r != LF_OK) return r;
+  return lf_frame_get_lines(c, 0, out, cap, n_out);
 }
 
 }  // extern "C"

@@ -1,0 +1,861 @@
+// lf_front.hip -- 3D-line stage for gfx950: everything Node::detect3DLines does after LSD
+// (src/line/lineslam.cpp:213-357), for a batch of frames.
+//
+//   k_sobel5     cv::Sobel(gray, CV_64F, ksize 5) x2         lineslam.cpp:311-314  (stored int16: the
+//                values are exact integers |v| <= 24480, 4x less HBM traffic than the reference's fp64)
+//   k_line3d     ONE WAVEFRONT PER 2D SEGMENT:
+//                  length filter + depth sampling             lineslam.cpp:213-221, 246-288
+//                  compPt3dCov + RandomPoint3d ctor           utils.cpp:671-722, lineslam.h:59-81
+//                  extract3dline_mahdist (RANSAC)             utils.cpp:343-427 (+570-624, 471-493)
+//                  acceptance                                 lineslam.cpp:302-307
+//                  MLEstimateLine3d (dlevmar_dif) + covariance utils.cpp:954-1050, 1086-1159
+//   k_records    ordered compaction into `lines` (+lid, complineEq2d, rndA/rndB)  lineslam.cpp:332-341
+//   k_describe   ONE WAVEFRONT PER 3D LINE: getGradient (lineslam.cpp:527-537) and computeMSLD
+//                (utils.cpp:1510-1610)
+//
+// Parallel mapping inside a wavefront: sample points / residuals live one or two per lane in LDS;
+// every floating-point SUM is accumulated in the reference's index order (one accumulator per lane
+// for J^T J, uniform loops elsewhere), so the results are bit-identical to the sequential oracle.
+#include "lf_front.h"
+#include "lf_linalg.h"
+#include <float.h>
+
+typedef unsigned long long u64;
+#define F_EPS 1e-10   // lineslam.h:37
+
+__device__ __forceinline__ int f_lane() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ u64 f_lt() { return (1ull << f_lane()) - 1ull; }
+__device__ __forceinline__ double f_rl64(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void f_sync() { __syncthreads(); }   // blocks are single wavefronts
+
+// ------------------------------------------------------------------------------ Sobel 5x5
+__device__ __forceinline__ int f_reflect101(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+__global__ void __launch_bounds__(256) k_sobel5(FrontConsts c, FrontBuffers b) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+  if (x >= c.W) return;
+  const uint8_t *g = b.gray + (size_t)f * b.gray_frame_stride;
+  const int kd[5] = {-1, -2, 0, 2, 1}, ks[5] = {1, 4, 6, 4, 1};
+  int sx = 0, sy = 0;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const uint8_t *row = g + (size_t)f_reflect101(y + j - 2, c.H) * b.gray_row_stride;
+    int rd = 0, rs = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      int v = row[f_reflect101(x + i - 2, c.W)];
+      rd += kd[i] * v;
+      rs += ks[i] * v;
+    }
+    sx += ks[j] * rd;
+    sy += kd[j] * rs;
+  }
+  size_t o = ((size_t)f * c.H + y) * c.W + x;
+  b.gx[o] = (int16_t)sx;
+  b.gy[o] = (int16_t)sy;
+}
+
+// ------------------------------------------------------------------------------ point helpers
+// depthStdDev + compPt3dCov (utils.cpp:671-722), same expression order as the oracle
+__device__ __forceinline__ void f_pt_cov(const double *pt, double f, const lf_params &P, double *cov) {
+  double sig = P.stdev_sample_pt_imgline;
+  double c1 = P.depth_stdev_coeff_c1, c2 = P.depth_stdev_coeff_c2 + 0.0 * 0.5, c3 = P.depth_stdev_coeff_c3;
+  double sz = c1 * pt[2] * pt[2] + c2 * pt[2] + c3;
+  double s2 = sig * sig, sz2 = sz * sz;
+  double j00 = pt[2] / f, j02 = pt[0] / pt[2], j11 = pt[2] / f, j12 = pt[1] / pt[2];
+  cov[0] = (j00 * s2) * j00 + (j02 * sz2) * j02;
+  cov[1] = (j02 * sz2) * j12;
+  cov[2] = (j02 * sz2);
+  cov[3] = (j12 * sz2) * j02;
+  cov[4] = (j11 * s2) * j11 + (j12 * sz2) * j12;
+  cov[5] = (j12 * sz2);
+  cov[6] = sz2 * j02;
+  cov[7] = sz2 * j12;
+  cov[8] = sz2;
+}
+// RandomPoint3d(pos, cov) ctor (lineslam.h:59-81): W_sqrt and DU = diag(1/W_sqrt) U^T
+__device__ __forceinline__ void f_whiten(const double *cov, double *DU, double *Wsq) {
+  double A[9], V[9], w[3];
+#pragma unroll
+  for (int i = 0; i < 9; i++) A[i] = cov[i];
+  lf_jacobi3(A, V, w);
+#pragma unroll
+  for (int i = 0; i < 3; i++) Wsq[i] = lf_sqrt(w[i]);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) DU[3 * i + j] = (1 / Wsq[i]) * V[3 * j + i];
+}
+// mah_dist3d_pt_line (utils.cpp:761-822)
+__device__ __forceinline__ double f_mah(const double *pos, const double *c, const double *q1, const double *q2) {
+  double x1 = pos[0], x2 = pos[1], x3 = pos[2];
+  double xa = q1[0], ya = q1[1], za = q1[2], xb = q2[0], yb = q2[1], zb = q2[2];
+  double a0 = c[0] * (x1 - xa) + c[1] * (x2 - ya) + c[2] * (x3 - za);
+  double a1 = c[3] * (x1 - xa) + c[4] * (x2 - ya) + c[5] * (x3 - za);
+  double a2 = c[6] * (x1 - xa) + c[7] * (x2 - ya) + c[8] * (x3 - za);
+  double b0 = c[0] * (x1 - xb) + c[1] * (x2 - yb) + c[2] * (x3 - zb);
+  double b1 = c[3] * (x1 - xb) + c[4] * (x2 - yb) + c[5] * (x3 - zb);
+  double b2 = c[6] * (x1 - xb) + c[7] * (x2 - yb) + c[8] * (x3 - zb);
+  double t1 = a0 * b1 - a1 * b0, t2 = a0 * b2 - a2 * b0, t3 = a1 * b2 - a2 * b1;
+  double t4 = c[0] * (x1 - xa) - c[0] * (x1 - xb) + c[1] * (x2 - ya) - c[1] * (x2 - yb) + c[2] * (x3 - za) - c[2] * (x3 - zb);
+  double t5 = c[3] * (x1 - xa) - c[3] * (x1 - xb) + c[4] * (x2 - ya) - c[4] * (x2 - yb) + c[5] * (x3 - za) - c[5] * (x3 - zb);
+  double t6 = c[6] * (x1 - xa) - c[6] * (x1 - xb) + c[7] * (x2 - ya) - c[7] * (x2 - yb) + c[8] * (x3 - za) - c[8] * (x3 - zb);
+  return lf_sqrt((t1 * t1 + t2 * t2 + t3 * t3) / (t4 * t4 + t5 * t5 + t6 * t6));
+}
+
+// first-occurrence arg-min / arg-max over the lanes' candidates (value, index); lower index wins ties
+__device__ __forceinline__ void f_argmin(double &v, int &i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_xor(v, o, 64);
+    int oi = __shfl_xor(i, o, 64);
+    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+__device__ __forceinline__ void f_argmax(double &v, int &i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_xor(v, o, 64);
+    int oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+__device__ __forceinline__ u64 f_or64(u64 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct L3State {          // LDS of one wavefront
+  double pos[LF_MAX_SAMPLES * 3];
+  double DU[LF_MAX_SAMPLES * 9];
+  double jac[LF_MAX_SAMPLES * 6];
+  double hx[LF_MAX_SAMPLES], e[LF_MAX_SAMPLES], wrk[LF_MAX_SAMPLES], wrk2[LF_MAX_SAMPLES];
+  int idx[LF_MAX_SAMPLES];
+  int sup[LF_MAX_SAMPLES];
+};
+
+// inlier masks of all points against the line (q1,q2); points lane and lane+64
+__device__ __forceinline__ void f_inliers(const L3State &S, int n, const double *q1, const double *q2, double thr,
+                                          u64 *m0, u64 *m1) {
+  int lane = f_lane();
+  bool i0 = false, i1 = false;
+  if (lane < n) i0 = f_mah(&S.pos[3 * lane], &S.DU[9 * lane], q1, q2) < thr;
+  if (lane + 64 < n) i1 = f_mah(&S.pos[3 * (lane + 64)], &S.DU[9 * (lane + 64)], q1, q2) < thr;
+  *m0 = __ballot(i0);
+  *m1 = __ballot(i1);
+}
+
+// verify3dLine (utils.cpp:570-624) on the inlier set (m0,m1)
+__device__ bool f_verify3d(const L3State &S, u64 m0, u64 m1, const double *A, const double *B, const lf_params &P) {
+  int lane = f_lane();
+  int nCells = P.num_cells_lineseg_range;
+  if (nCells > 64) nCells = 64;
+  double AB[3], mid[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { AB[k] = B[k] - A[k]; mid[k] = (A[k] + B[k]) * 0.5; }
+  bool in0 = (m0 >> lane) & 1ull, in1 = (m1 >> lane) & 1ull;
+  const double *x0 = &S.pos[3 * lane], *x1 = &S.pos[3 * (lane + 64)];
+  double d0 = in0 ? (x0[0] - A[0]) * AB[0] + (x0[1] - A[1]) * AB[1] + (x0[2] - A[2]) * AB[2] : 0.0;
+  double d1 = in1 ? (x1[0] - A[0]) * AB[0] + (x1[1] - A[1]) * AB[1] + (x1[2] - A[2]) * AB[2] : 0.0;
+  int first = m0 ? __builtin_ctzll(m0) : 64 + __builtin_ctzll(m1);   // list position 0
+  // arg-min with the reference's initial value 100 (idx 0 if nothing is below it)
+  double vmin = 100.0; int imin = 1 << 30;
+  if (in0 && d0 < vmin) { vmin = d0; imin = lane; }
+  if (in1 && d1 < vmin) { vmin = d1; imin = lane + 64; }
+  f_argmin(vmin, imin);
+  if (imin == (1 << 30)) imin = first;
+  double vmax = -100.0; int imax = 1 << 30;
+  if (in0 && d0 > vmax) { vmax = d0; imax = lane; }
+  if (in1 && d1 > vmax) { vmax = d1; imax = lane + 64; }
+  f_argmax(vmax, imax);
+  if (imax == (1 << 30)) imax = first;
+  double C[3], D[3];
+  {
+    double Bm[3], ab[3], ap[3], s;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { Bm[k] = mid[k] + AB[k]; ab[k] = Bm[k] - mid[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) ap[k] = S.pos[3 * imin + k] - mid[k];
+    s = (ab[0] * ap[0] + ab[1] * ap[1] + ab[2] * ap[2]) / (ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) C[k] = mid[k] + s * ab[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) ap[k] = S.pos[3 * imax + k] - mid[k];
+    s = (ab[0] * ap[0] + ab[1] * ap[1] + ab[2] * ap[2]) / (ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) D[k] = mid[k] + s * ab[k];
+  }
+  double cd = lf_sqrt((D[0] - C[0]) * (D[0] - C[0]) + (D[1] - C[1]) * (D[1] - C[1]) + (D[2] - C[2]) * (D[2] - C[2]));
+  if (cd < F_EPS) return false;
+  u64 cells = 0;
+  if (in0) {
+    double lambda = lf_fabs(((x0[0] - C[0]) * (D[0] - C[0]) + (x0[1] - C[1]) * (D[1] - C[1]) + (x0[2] - C[2]) * (D[2] - C[2])) / cd / cd);
+    if (lambda >= 1) cells |= 1ull << (nCells - 1);
+    else { unsigned int cidx = (unsigned int)__builtin_floor(lambda * 10); if (cidx < 64) cells |= 1ull << cidx; }
+  }
+  if (in1) {
+    double lambda = lf_fabs(((x1[0] - C[0]) * (D[0] - C[0]) + (x1[1] - C[1]) * (D[1] - C[1]) + (x1[2] - C[2]) * (D[2] - C[2])) / cd / cd);
+    if (lambda >= 1) cells |= 1ull << (nCells - 1);
+    else { unsigned int cidx = (unsigned int)__builtin_floor(lambda * 10); if (cidx < 64) cells |= 1ull << cidx; }
+  }
+  cells = f_or64(cells);
+  if (nCells < 64) cells &= (1ull << nCells) - 1ull;
+  double sum = (double)__popcll(cells);
+  return sum / nCells > P.ratio_support_pts_on_line;
+}
+
+// computeLine3d_svd on the index set (m0,m1) (utils.cpp:471-493): sums in ascending index order
+__device__ void f_line3d_svd(const L3State &S, u64 m0, u64 m1, int n, double *mean, double *drct) {
+  double Sm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, V[9], w[3];
+  mean[0] = mean[1] = mean[2] = 0;
+  for (int half = 0; half < 2; half++) {
+    u64 mm = half ? m1 : m0;
+    while (mm) {
+      int i = __builtin_ctzll(mm) + 64 * half;
+      mm &= mm - 1;
+#pragma unroll
+      for (int k = 0; k < 3; k++) mean[k] = mean[k] + S.pos[3 * i + k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) mean[k] = mean[k] * (1.0 / n);
+  for (int half = 0; half < 2; half++) {
+    u64 mm = half ? m1 : m0;
+    while (mm) {
+      int i = __builtin_ctzll(mm) + 64 * half;
+      mm &= mm - 1;
+      double d[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) d[k] = S.pos[3 * i + k] - mean[k];
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int l = 0; l < 3; l++) Sm[3 * k + l] += d[k] * d[l];
+    }
+  }
+  lf_jacobi3(Sm, V, w);
+#pragma unroll
+  for (int k = 0; k < 3; k++) drct[k] = V[3 * k + 0];
+}
+
+// costFun_MLEstimateLine3d (utils.cpp:954-978): residuals of support points lane and lane+64
+__device__ __forceinline__ void f_mle_cost(const L3State &S, int n, int e1, int e2, const double *ci1,
+                                           const double *ci2, const double *p, double *out) {
+  int lane = f_lane();
+  for (int h = 0; h < 2; h++) {
+    int i = lane + 64 * h;
+    if (i < n) {
+      int pi = S.sup[i];
+      double r;
+      if (i == e1 || i == e2) {
+        const double *ci = (i == e1) ? ci1 : ci2;
+        const double *e = (i == e1) ? p : p + 3;
+        double v[3], t[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] = e[k] - S.pos[3 * pi + k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) t[k] = v[0] * ci[0 * 3 + k] + v[1] * ci[1 * 3 + k] + v[2] * ci[2 * 3 + k];
+        r = t[0] * v[0] + t[1] * v[1] + t[2] * v[2];
+      } else
+        r = f_mah(&S.pos[3 * pi], &S.DU[9 * pi], p, p + 3);
+      out[i] = r;
+    }
+  }
+}
+
+// jac_rpt2ln_mahvec_wrt_ln (utils.cpp:1086-1116), closed form (see oracle/front_oracle.c o_jac_line)
+__device__ __forceinline__ void f_jac_line(const double *pos, const double *M, const double *l, double *J) {
+  double a[3], b[3], d[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    a[r] = M[3 * r] * (pos[0] - l[0]) + M[3 * r + 1] * (pos[1] - l[1]) + M[3 * r + 2] * (pos[2] - l[2]);
+    b[r] = M[3 * r] * (pos[0] - l[3]) + M[3 * r + 1] * (pos[1] - l[4]) + M[3 * r + 2] * (pos[2] - l[5]);
+    d[r] = a[r] - b[r];
+  }
+  double Sd = a[0] * d[0] + a[1] * d[1] + a[2] * d[2];
+  double D = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    double ma = M[j] * a[0] + M[3 + j] * a[1] + M[6 + j] * a[2];
+    double md = M[j] * d[0] + M[3 + j] * d[1] + M[6 + j] * d[2];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      double Mrj = M[3 * r + j];
+      J[r * 6 + j] = Mrj - Mrj * Sd / D - d[r] * (ma + md) / D + 2.0 * Sd * md * d[r] / (D * D);
+      J[r * 6 + 3 + j] = ma * d[r] / D + Mrj * Sd / D - 2.0 * Sd * md * d[r] / (D * D);
+    }
+  }
+}
+
+// dlevmar_dif (external/levmar-2.6/lm_core.c:438-846) for m = 6, x = 0, restated for one wavefront.
+// Residuals/Jacobian rows live in LDS; J^T J and J^T e use one accumulator per lane that walks
+// l = n-1 .. 0 exactly as lm_core.c:581-591.
+__device__ int f_levmar6(L3State &S, int n, int e1, int e2, const double *ci1, const double *ci2, double *p,
+                         int itmax, int *stop_out) {
+  const int m = 6, lane = f_lane();
+  const double tau = 1E-03, eps1 = 1E-10, eps2 = 1E-20, eps2_sq = 1E-20 * 1E-20, eps3 = 1E-20, delta = 1E-06;
+  double jacTe[6], jacTjac[36], Dp[6], diag[6], pDp[6];
+  double mu = 0, tmp, p_eL2, jacTe_inf = 0, pDp_eL2, p_L2 = 0, Dp_L2 = DBL_MAX, dF, dL;
+  int nu, nu2, stop = 0, K = 10, updjac = 0, updp = 1, newjac = 0, k;
+  // accumulator ownership: lanes 0..20 lower triangle (i,j), lanes 21..26 J^T e
+  int ai = 0, aj = 0;
+  if (lane < 21) { int a = lane; while ((ai + 1) * (ai + 2) / 2 <= a) ai++; aj = a - ai * (ai + 1) / 2; }
+  else if (lane < 27) { ai = lane - 21; aj = -1; }
+  f_mle_cost(S, n, e1, e2, ci1, ci2, p, S.hx);
+  f_sync();
+  p_eL2 = 0.0;
+  for (int i = lane; i < n; i += 64) S.e[i] = 0.0 - S.hx[i];
+  f_sync();
+  for (int i = 0; i < n; ++i) { tmp = S.e[i]; p_eL2 += tmp * tmp; }
+  if (!(lf_fabs(p_eL2) <= DBL_MAX)) stop = 7;
+  nu = 20;
+  for (k = 0; k < itmax && !stop; ++k) {
+    if (p_eL2 <= eps3) { stop = 6; break; }
+    if ((updp && nu > 16) || updjac == K) {
+      for (int j = 0; j < m; ++j) {           // forward differences (misc_core.c:137-171)
+        double d = 1E-04 * p[j], t;
+        d = lf_fabs(d);
+        if (d < delta) d = delta;
+        t = p[j]; p[j] += d;
+        f_mle_cost(S, n, e1, e2, ci1, ci2, p, S.wrk);
+        p[j] = t;
+        d = 1.0 / d;
+        f_sync();
+        for (int i = lane; i < n; i += 64) S.jac[i * m + j] = (S.wrk[i] - S.hx[i]) * d;
+      }
+      f_sync();
+      nu = 2; updjac = 0; updp = 0; newjac = 1;
+    }
+    if (newjac) {
+      newjac = 0;
+      double acc = 0.0;
+      if (lane < 27)
+        for (int l = n; l-- > 0;) {
+          double alpha = S.jac[l * m + ai];
+          acc += (aj >= 0) ? S.jac[l * m + aj] * alpha : alpha * S.e[l];
+        }
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) { double v = f_rl64(acc, i * (i + 1) / 2 + j); jacTjac[i * m + j] = v; jacTjac[j * m + i] = v; }
+#pragma unroll
+      for (int i = 0; i < 6; i++) jacTe[i] = f_rl64(acc, 21 + i);
+      p_L2 = jacTe_inf = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        if (jacTe_inf < (tmp = lf_fabs(jacTe[i]))) jacTe_inf = tmp;
+        diag[i] = jacTjac[i * m + i];
+        p_L2 += p[i] * p[i];
+      }
+    }
+    if (jacTe_inf <= eps1) { Dp_L2 = 0.0; stop = 1; break; }
+    if (k == 0) {
+      tmp = DBL_MIN;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) if (diag[i] > tmp) tmp = diag[i];
+      mu = tau * tmp;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) jacTjac[i * m + i] += mu;
+    int issolved;
+    {
+      double A[36], Bv[6];
+#pragma unroll
+      for (int i = 0; i < 36; i++) A[i] = jacTjac[i];
+#pragma unroll
+      for (int i = 0; i < 6; i++) Bv[i] = jacTe[i];
+      issolved = lf_solve6(A, Bv, 1);
+#pragma unroll
+      for (int i = 0; i < 6; i++) Dp[i] = Bv[i];
+    }
+    if (issolved) {
+      Dp_L2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { pDp[i] = p[i] + (tmp = Dp[i]); Dp_L2 += tmp * tmp; }
+      if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
+      if (Dp_L2 >= (p_L2 + eps2) / (1E-12 * 1E-12)) { stop = 4; break; }
+      f_mle_cost(S, n, e1, e2, ci1, ci2, pDp, S.wrk);
+      f_sync();
+      for (int i = lane; i < n; i += 64) S.wrk2[i] = 0.0 - S.wrk[i];
+      f_sync();
+      pDp_eL2 = 0.0;
+      for (int i = 0; i < n; ++i) { tmp = S.wrk2[i]; pDp_eL2 += tmp * tmp; }
+      if (!(lf_fabs(pDp_eL2) <= DBL_MAX)) { stop = 7; break; }
+      dF = p_eL2 - pDp_eL2;
+      if (updp || dF > 0) {                       // Broyden rank-one update, row-parallel
+        for (int i = lane; i < n; i += 64) {
+          double t2 = 0.0;
+#pragma unroll
+          for (int l = 0; l < 6; ++l) t2 += S.jac[i * m + l] * Dp[l];
+          t2 = (S.wrk[i] - S.hx[i] - t2) / Dp_L2;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) S.jac[i * m + j] += t2 * Dp[j];
+        }
+        f_sync();
+        ++updjac; newjac = 1;
+      }
+      dL = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dL += Dp[i] * (mu * Dp[i] + jacTe[i]);
+      if (dL > 0.0 && dF > 0.0) {
+        tmp = (2.0 * dF / dL - 1.0);
+        tmp = 1.0 - tmp * tmp * tmp;
+        mu = mu * ((tmp >= 0.3333333334) ? tmp : 0.3333333334);
+        nu = 2;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) p[i] = pDp[i];
+        for (int i = lane; i < n; i += 64) { S.e[i] = S.wrk2[i]; S.hx[i] = S.wrk[i]; }
+        f_sync();
+        p_eL2 = pDp_eL2;
+        updp = 1;
+        continue;
+      }
+    }
+    mu *= nu;
+    nu2 = nu << 1;
+    if (nu2 <= nu) { stop = 5; break; }
+    nu = nu2;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) jacTjac[i * m + i] = diag[i];
+  }
+  if (k >= itmax) stop = 3;
+  *stop_out = stop;
+  return (stop != 4 && stop != 7) ? k : -1;
+}
+
+__global__ void __launch_bounds__(64) k_line3d(FrontConsts c, FrontBuffers b) {
+  __shared__ L3State S;
+  const int cand = blockIdx.x, f = blockIdx.y, lane = f_lane();
+  const lf_params &P = c.P;
+  int *flag = b.cand_flag + (size_t)f * c.cand_cap + cand;
+  double *out = b.cand_out + ((size_t)f * c.cand_cap + cand) * LF_CAND_STRIDE;
+  int nseg = b.nsegs[f];
+  if (nseg > c.seg_cap) nseg = c.seg_cap;
+  if (cand >= nseg) { if (lane == 0) *flag = 0; return; }
+  const double *sg = b.segs + ((size_t)f * c.seg_cap + cand) * 5;
+  double pa = sg[0], pb = sg[1], qc = sg[2], qd = sg[3];
+  if (lane < LF_CAND_STRIDE / 2) { out[lane] = 0.0; out[lane + LF_CAND_STRIDE / 2] = 0.0; }
+  if (!(lf_sqrt((pa - qc) * (pa - qc) + (pb - qd) * (pb - qd)) > P.line_segment_len_thresh)) {   // lineslam.cpp:218
+    if (lane == 0) *flag = 0;
+    return;
+  }
+  double len = lf_sqrt((pa - qc) * (pa - qc) + (pb - qd) * (pb - qd));
+  double numSmp = len / P.line_sample_interval;
+  if (numSmp < (double)P.line_sample_min_num) numSmp = (double)P.line_sample_min_num;
+  if (numSmp > (double)P.line_sample_max_num) numSmp = (double)P.line_sample_max_num;
+  const float *depth = b.depth + (size_t)f * b.depth_frame_stride;
+  // ---- depth sampling (lineslam.cpp:252-288): sample j = lane and lane+64, order-preserving compaction
+  int np = 0;
+  for (int h = 0; h < 2; h++) {
+    int j = lane + 64 * h;
+    bool ok = false;
+    double X = 0, Y = 0, Z = 0;
+    if ((double)j <= numSmp && j < LF_MAX_SAMPLES) {
+      double ptx = pa * (1 - j / numSmp) + qc * (j / numSmp);
+      double pty = pb * (1 - j / numSmp) + qd * (j / numSmp);
+      if (!(ptx < 0 || pty < 0 || ptx >= c.W || pty >= c.H)) {
+        int row, col;
+        if ((__builtin_floor(ptx) == ptx) && (__builtin_floor(pty) == pty)) {
+          col = (int)(ptx - 1); if (col < 0) col = 0;
+          row = (int)(pty - 1); if (row < 0) row = 0;
+        } else { col = (int)ptx; row = (int)pty; }
+        float dv = depth[(size_t)row * b.depth_row_stride + col];
+        double depval = (double)dv, zval = -1;
+        if (depval < F_EPS || dv != dv) { } else zval = depval / P.depth_scaling;
+        if (zval > 0) {
+          double x = c.Kinv[0] * ptx + c.Kinv[1] * pty + c.Kinv[2] * 1.0;
+          double y = c.Kinv[3] * ptx + c.Kinv[4] * pty + c.Kinv[5] * 1.0;
+          double z = c.Kinv[6] * ptx + c.Kinv[7] * pty + c.Kinv[8] * 1.0;
+          x = x / z; y = y / z;
+          X = x * zval; Y = y * zval; Z = zval;
+          ok = true;
+        }
+      }
+    }
+    u64 mk = __ballot(ok);
+    if (ok) {
+      int pos = np + __popcll(mk & f_lt());
+      S.pos[3 * pos] = X; S.pos[3 * pos + 1] = Y; S.pos[3 * pos + 2] = Z;
+    }
+    np += __popcll(mk);
+  }
+  f_sync();
+  if (lane == 0) { out[24] = numSmp; out[25] = (double)np; }
+  {
+    double need = numSmp * P.ratio_of_collinear_pts;
+    if (need < 10.0) need = 10.0;
+    if (np < need) { if (lane == 0) *flag = 1; return; }                                     // lineslam.cpp:289
+  }
+  const int n = np;
+  for (int i = lane; i < n; i += 64) {
+    double cov[9], Wsq[3], DU[9];
+    f_pt_cov(&S.pos[3 * i], c.K[0], P, cov);
+    f_whiten(cov, DU, Wsq);
+#pragma unroll
+    for (int k = 0; k < 9; k++) S.DU[9 * i + k] = DU[k];
+    S.idx[i] = i;
+  }
+  f_sync();
+  // ---- extract3dline_mahdist (utils.cpp:343-427)
+  const double thr = P.pt2line_mahdist_extractline;
+  const uint64_t stream = LF_STREAM_LINE3D(b.frame_ids[f], cand);
+  int maxIter = P.ransac_iters_extract_line, half = (int)(n * (n - 1) * 0.5);
+  if (half < maxIter) maxIter = half;
+  u64 best0 = 0, best1 = 0, ctr = 0;
+  int nbest = 0, bestA = 0, bestB = 0;
+  for (int iter = 0; iter < maxIter; iter++) {
+    if (lane == 0) {   // random_unique(indexes, 2): partial Fisher-Yates, state carried over
+      int r = 0 + (int)(lf_rand31(P.rng_seed, stream, ctr) % (uint32_t)n);
+      int t = S.idx[0]; S.idx[0] = S.idx[r]; S.idx[r] = t;
+      r = 1 + (int)(lf_rand31(P.rng_seed, stream, ctr + 1) % (uint32_t)(n - 1));
+      t = S.idx[1]; S.idx[1] = S.idx[r]; S.idx[r] = t;
+    }
+    ctr += 2;
+    f_sync();
+    int ia = S.idx[0], ib = S.idx[1];
+    f_sync();
+    double A[3], B[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { A[k] = S.pos[3 * ia + k]; B[k] = S.pos[3 * ib + k]; }
+    double dn = lf_sqrt((B[0] - A[0]) * (B[0] - A[0]) + (B[1] - A[1]) * (B[1] - A[1]) + (B[2] - A[2]) * (B[2] - A[2]));
+    if (dn < F_EPS) continue;
+    u64 m0, m1;
+    f_inliers(S, n, A, B, thr, &m0, &m1);
+    int nc = __popcll(m0) + __popcll(m1);
+    if (nc > nbest) {
+      if (f_verify3d(S, m0, m1, A, B, P)) { best0 = m0; best1 = m1; nbest = nc; bestA = ia; bestB = ib; }
+    }
+    if (nbest > n * 0.9) break;
+  }
+  double LA[3] = {0, 0, 0}, LB[3] = {0, 0, 0};
+  if (nbest >= 2) {
+    double mm[3], dd[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { mm[k] = (S.pos[3 * bestA + k] + S.pos[3 * bestB + k]) * 0.5; dd[k] = S.pos[3 * bestB + k] - S.pos[3 * bestA + k]; }
+    for (;;) {
+      double tm[3], td[3], q2[3];
+      f_line3d_svd(S, best0, best1, nbest, tm, td);
+#pragma unroll
+      for (int k = 0; k < 3; k++) q2[k] = tm[k] + td[k];
+      u64 m0, m1;
+      f_inliers(S, n, tm, q2, thr, &m0, &m1);
+      int nc = __popcll(m0) + __popcll(m1);
+      if (nc > nbest) {
+        best0 = m0; best1 = m1; nbest = nc;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { mm[k] = tm[k]; dd[k] = td[k]; }
+      } else break;
+    }
+    bool in0 = (best0 >> lane) & 1ull, in1 = (best1 >> lane) & 1ull;
+    const double *x0 = &S.pos[3 * lane], *x1 = &S.pos[3 * (lane + 64)];
+    double d0 = in0 ? (x0[0] - mm[0]) * dd[0] + (x0[1] - mm[1]) * dd[1] + (x0[2] - mm[2]) * dd[2] : 0.0;
+    double d1 = in1 ? (x1[0] - mm[0]) * dd[0] + (x1[1] - mm[1]) * dd[1] + (x1[2] - mm[2]) * dd[2] : 0.0;
+    int first = best0 ? __builtin_ctzll(best0) : 64 + __builtin_ctzll(best1);
+    double vmin = 100.0; int imin = 1 << 30;
+    if (in0 && d0 < vmin) { vmin = d0; imin = lane; }
+    if (in1 && d1 < vmin) { vmin = d1; imin = lane + 64; }
+    f_argmin(vmin, imin);
+    if (imin == (1 << 30)) imin = first;
+    double vmax = -100.0; int imax = 1 << 30;
+    if (in0 && d0 > vmax) { vmax = d0; imax = lane; }
+    if (in1 && d1 > vmax) { vmax = d1; imax = lane + 64; }
+    f_argmax(vmax, imax);
+    if (imax == (1 << 30)) imax = first;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { LA[k] = S.pos[3 * imin + k]; LB[k] = S.pos[3 * imax + k]; }
+  }
+  if (lane == 0) { out[26] = (double)nbest; out[29] = LA[0]; out[30] = LA[1]; out[31] = LA[2]; }
+  bool have = (nbest / numSmp > P.ratio_of_collinear_pts) &&
+              (lf_sqrt((LA[0] - LB[0]) * (LA[0] - LB[0]) + (LA[1] - LB[1]) * (LA[1] - LB[1]) + (LA[2] - LB[2]) * (LA[2] - LB[2])) > P.line3d_length_thresh);
+  if (!have) { if (lane == 0) *flag = 1; return; }                                          // lineslam.cpp:302-307
+  // ---- MLEstimateLine3d (utils.cpp:980-1050) on the supporting points, in list order
+  {
+    bool in0 = (best0 >> lane) & 1ull, in1 = (best1 >> lane) & 1ull;
+    if (in0) S.sup[__popcll(best0 & f_lt())] = lane;
+    if (in1) S.sup[__popcll(best0) + __popcll(best1 & f_lt())] = lane + 64;
+  }
+  f_sync();
+  const int ns = nbest;
+  int e1, e2;
+  {
+    double AmB[3] = {LA[0] - LB[0], LA[1] - LB[1], LA[2] - LB[2]};
+    double vmin = 100.0, vmax = -100.0;
+    int imin = 1 << 30, imax = 1 << 30;
+    for (int h = 0; h < 2; h++) {
+      int i = lane + 64 * h;
+      if (i < ns) {
+        const double *x = &S.pos[3 * S.sup[i]];
+        double dp = (x[0] - LA[0]) * AmB[0] + (x[1] - LA[1]) * AmB[1] + (x[2] - LA[2]) * AmB[2];
+        if (dp < vmin) { vmin = dp; imin = i; }
+        if (dp > vmax) { vmax = dp; imax = i; }
+      }
+    }
+    f_argmin(vmin, imin);
+    f_argmax(vmax, imax);
+    e1 = (imin == (1 << 30)) ? 0 : imin;
+    e2 = (imax == (1 << 30)) ? 0 : imax;
+    if (e1 > e2) { int t = e1; e1 = e2; e2 = t; }
+  }
+  double ci1[9], ci2[9], para[6];
+  {
+    double cov[9];
+    f_pt_cov(&S.pos[3 * S.sup[e1]], c.K[0], P, cov);
+    lf_inv3(cov, ci1);
+    f_pt_cov(&S.pos[3 * S.sup[e2]], c.K[0], P, cov);
+    lf_inv3(cov, ci2);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { para[k] = S.pos[3 * S.sup[e1] + k]; para[3 + k] = S.pos[3 * S.sup[e2] + k]; }
+  }
+  int stop = 0;
+  int nit = f_levmar6(S, ns, e1, e2, ci1, ci2, para, P.line3d_mle_iter_num, &stop);
+  // ---- MleLine3dCov (utils.cpp:1138-1159): H = J^T J in point order, cov = H^-1
+  double H[36], I6[36];
+#pragma unroll
+  for (int i = 0; i < 36; i++) H[i] = 0;
+  for (int i = 0; i < ns; ++i) {
+    double J[18];
+    int pi = S.sup[i];
+#pragma unroll
+    for (int k = 0; k < 18; k++) J[k] = 0;
+    if (i == e1) {
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) J[r * 6 + k] = -S.DU[9 * pi + 3 * r + k];
+    } else if (i == e2) {
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) J[r * 6 + 3 + k] = -S.DU[9 * pi + 3 * r + k];
+    } else
+      f_jac_line(&S.pos[3 * pi], &S.DU[9 * pi], para, J);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int k = 0; k < 6; k++)
+#pragma unroll
+        for (int l = 0; l < 6; l++) H[k * 6 + l] += J[r * 6 + k] * J[r * 6 + l];
+  }
+#pragma unroll
+  for (int i = 0; i < 36; i++) I6[i] = (i % 7 == 0) ? 1.0 : 0.0;
+  if (!lf_solve6(H, I6, 6)) {
+#pragma unroll
+    for (int i = 0; i < 36; i++) I6[i] = lf_from_bits(0x7ff8000000000000ULL);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { out[k] = para[k]; out[3 + k] = para[3 + k]; }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) { out[6 + 3 * r + k] = I6[r * 6 + k]; out[15 + 3 * r + k] = I6[(r + 3) * 6 + 3 + k]; }
+    out[27] = (double)nit;
+    out[28] = (double)stop;
+    *flag = 2;
+  }
+}
+
+// ordered compaction (lineslam.cpp:332-341): one wavefront per frame
+__global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
+  const int f = blockIdx.x, lane = f_lane();
+  int nseg = b.nsegs[f];
+  if (nseg > c.seg_cap) nseg = c.seg_cap;
+  if (nseg > c.cand_cap) nseg = c.cand_cap;
+  const int *flag = b.cand_flag + (size_t)f * c.cand_cap;
+  lf_line_record *recs = b.recs + (size_t)f * c.line_cap;
+  int base = 0;
+  for (int s0 = 0; s0 < nseg; s0 += 64) {
+    int s = s0 + lane;
+    bool have = s < nseg && flag[s] == 2;
+    u64 m = __ballot(have);
+    int lid = base + __popcll(m & f_lt());
+    if (have && lid < c.line_cap) {
+      lf_line_record *R = &recs[lid];
+      const double *sg = b.segs + ((size_t)f * c.seg_cap + s) * 5;
+      const double *o = b.cand_out + ((size_t)f * c.cand_cap + s) * LF_CAND_STRIDE;
+      double p0 = sg[0], p1 = sg[1], q0 = sg[2], q1 = sg[3];
+      R->p[0] = p0; R->p[1] = p1; R->q[0] = q0; R->q[1] = q1;
+      // complineEq2d (lineslam.h:139-150)
+      double l0 = p1 * 1.0 - 1.0 * q1, l1 = 1.0 * q0 - p0 * 1.0, l2 = p0 * q1 - p1 * q0;
+      double nn = lf_sqrt(l0 * l0 + l1 * l1);
+      R->lineEq2d[0] = l0 / nn; R->lineEq2d[1] = l1 / nn; R->lineEq2d[2] = l2 / nn;
+      R->r[0] = 0; R->r[1] = 0;
+      for (int k = 0; k < 3; k++) { R->A[k] = o[k]; R->B[k] = o[3 + k]; }
+      double cov[9], DU[9], Wsq[3];
+      for (int k = 0; k < 9; k++) { cov[k] = o[6 + k]; R->covA[k] = cov[k]; }
+      f_whiten(cov, DU, Wsq);
+      for (int k = 0; k < 9; k++) R->DUa[k] = DU[k];
+      for (int k = 0; k < 3; k++) R->Wsa[k] = Wsq[k];
+      for (int k = 0; k < 9; k++) { cov[k] = o[15 + k]; R->covB[k] = cov[k]; }
+      f_whiten(cov, DU, Wsq);
+      for (int k = 0; k < 9; k++) R->DUb[k] = DU[k];
+      for (int k = 0; k < 3; k++) R->Wsb[k] = Wsq[k];
+      R->lid = lid;
+      R->seg = s;
+    }
+    base += __popcll(m);
+  }
+  if (lane == 0) b.nlines[f] = base;
+}
+
+// ------------------------------------------------------------------------------ getGradient + MSLD
+__device__ __forceinline__ int f_cvround(double v) { return (int)__builtin_rint(v); }   // cvRound: half to even
+// cv::clipLine (OpenCV 2.4 drawing.cpp)
+__device__ bool f_clipline(int w, int h, long long *px1, long long *py1, long long *px2, long long *py2) {
+  long long x1 = *px1, y1 = *py1, x2 = *px2, y2 = *py2, right = w - 1, bottom = h - 1;
+  if (w <= 0 || h <= 0) return false;
+  int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+  int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+  if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+    long long a;
+    if (c1 & 12) { a = c1 < 8 ? 0 : bottom; x1 += (a - y1) * (x2 - x1) / (y2 - y1); y1 = a; c1 = (x1 < 0) + (x1 > right) * 2; }
+    if (c2 & 12) { a = c2 < 8 ? 0 : bottom; x2 += (a - y2) * (x2 - x1) / (y2 - y1); y2 = a; c2 = (x2 < 0) + (x2 > right) * 2; }
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+      if (c1) { a = c1 == 1 ? 0 : right; y1 += (a - x1) * (y2 - y1) / (x2 - x1); x1 = a; c1 = 0; }
+      if (c2) { a = c2 == 1 ? 0 : right; y2 += (a - x2) * (y2 - y1) / (x2 - x1); x2 = a; c2 = 0; }
+    }
+    *px1 = x1; *py1 = y1; *px2 = x2; *py2 = y2;
+  }
+  return (c1 | c2) == 0;
+}
+
+#define MSLD_TILE 64
+__global__ void __launch_bounds__(64) k_describe(FrontConsts c, FrontBuffers b) {
+  __shared__ double G[MSLD_TILE * 36];
+  const int li = blockIdx.x, f = blockIdx.y, lane = f_lane();
+  int nl = b.nlines[f];
+  if (nl > c.line_cap) nl = c.line_cap;
+  if (li >= nl) return;
+  lf_line_record *R = b.recs + (size_t)f * c.line_cap + li;
+  const int16_t *gx = b.gx + (size_t)f * c.W * c.H, *gy = b.gy + (size_t)f * c.W * c.H;
+  const int W = c.W, H = c.H;
+  const double p0 = R->p[0], p1 = R->p[1], q0 = R->q[0], q1 = R->q[1];
+  // ---- FrameLine::getGradient (lineslam.cpp:527-537): cv::LineIterator(img, p, q, 8).  Pixel i of
+  // the Bresenham walk in closed form: minor-axis offset k_i = max(0, ceil((2 minor i - major)/(2 major))).
+  double r0, r1;
+  {
+    long long x1 = f_cvround(p0), y1 = f_cvround(p1), x2 = f_cvround(q0), y2 = f_cvround(q1);
+    bool ok = true;
+    if ((u64)x1 >= (u64)W || (u64)x2 >= (u64)W || (u64)y1 >= (u64)H || (u64)y2 >= (u64)H) ok = f_clipline(W, H, &x1, &y1, &x2, &y2);
+    long long sxs = 0, sys_ = 0;
+    if (ok) {
+      int dx = (int)(x2 - x1), dy = (int)(y2 - y1);
+      int sgx = dx < 0 ? -1 : 1, sgy = dy < 0 ? -1 : 1;
+      int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+      bool steep = ady > adx;
+      int major = steep ? ady : adx, minor = steep ? adx : ady;
+      int count = major + 1;
+      for (int i = lane; i < count; i += 64) {
+        long long num = 2ll * minor * i - major;
+        int k = (num > 0 && major > 0) ? (int)((num + 2ll * major - 1) / (2ll * major)) : 0;
+        int x = (int)x1 + (steep ? sgx * k : sgx * i);
+        int y = (int)y1 + (steep ? sgy * i : sgy * k);
+        sxs += gx[y * W + x];
+        sys_ += gy[y * W + x];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sxs += __shfl_xor(sxs, o, 64); sys_ += __shfl_xor(sys_, o, 64); }
+    double xs = (double)sxs, ys = (double)sys_;
+    double len = lf_sqrt(xs * xs + ys * ys);
+    r0 = xs / len;
+    r1 = ys / len;
+  }
+  // ---- computeMSLD (utils.cpp:1544-1610)
+  const int s = (int)(5 * W / 800.0);
+  const double sd = (double)s, step = c.P.msld_sample_interval;
+  const double len = lf_sqrt((p0 - q0) * (p0 - q0) + (p1 - q1) * (p1 - q1));
+  const double gauss[9] = {0.24142, 0.30046, 0.35127, 0.38579, 0.39804, 0.38579, 0.35127, 0.30046, 0.24142};
+  // number of sample indices i with i*step < len
+  int ntot = 0;
+  if (len > 0 && step > 0) {
+    ntot = (int)__builtin_ceil(len / step);
+    while ((double)ntot * step < len) ntot++;
+    while (ntot > 0 && !((double)(ntot - 1) * step < len)) ntot--;
+  }
+  double sum = 0, sum2 = 0;   // lanes 0..35: running sums of component `lane`
+  int nvalid = 0;
+  for (int i0 = 0; i0 < ntot; i0 += MSLD_TILE) {
+    int i = i0 + lane;
+    bool ok = i < ntot;
+    double col[36];
+    if (ok) {
+      double t = (i * step / len);
+      double ptx = p0 + (q0 - p0) * t, pty = p1 + (q1 - p1) * t;
+      for (int j = -4; j <= 4 && ok; ++j) {   // computeSubPSR (utils.cpp:1510-1542)
+        double px = ptx + r0 * (j * s), py = pty + r1 * (j * s);
+        double tl_x = __builtin_floor(px - sd / 2), tl_y = __builtin_floor(py - sd / 2);
+        if (tl_x < 0 || tl_y < 0 || tl_x + sd + 1 > W || tl_y + sd + 1 > H || !(tl_x == tl_x) || !(tl_y == tl_y)) { ok = false; break; }
+        double v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+        for (int y = (int)tl_y; y < tl_y + sd; ++y)
+          for (int x = (int)tl_x; x < tl_x + sd; ++x) {
+            double xg = (double)gx[y * W + x], yg = (double)gy[y * W + x];
+            double tmp1 = xg * r0 + yg * r1;
+            double tmp2 = xg * (-r1) + yg * r0;
+            if (tmp1 >= 0) v1 = v1 + tmp1; else v2 = v2 - tmp1;
+            if (tmp2 >= 0) v3 = v3 + tmp2; else v4 = v4 - tmp2;
+          }
+        col[(j + 4) * 4 + 0] = v1; col[(j + 4) * 4 + 1] = v2; col[(j + 4) * 4 + 2] = v3; col[(j + 4) * 4 + 3] = v4;
+      }
+    }
+    u64 mv = __ballot(ok);
+    if (ok) {
+      int slot = __popcll(mv & f_lt());
+#pragma unroll
+      for (int k = 0; k < 36; k++) G[slot * 36 + k] = col[k];
+    }
+    f_sync();
+    int cnt = __popcll(mv);
+    if (lane < 36) {
+      double gw = gauss[lane / 4];
+      for (int j = 0; j < cnt; j++) {
+        double v = G[j * 36 + lane] * gw;
+        sum += v;
+        sum2 += v * v;
+      }
+    }
+    nvalid += cnt;
+    f_sync();
+  }
+  double *des = R->des;
+  if (nvalid == 0) {
+    uint64_t stream = LF_STREAM_LINE3D(b.frame_ids[f], R->seg);
+    for (int i = lane; i < 72; i += 64) des[i] = (double)lf_rand31(c.P.rng_seed, stream, 1000 + (uint64_t)i);
+    if (lane == 0) { R->r[0] = r0; R->r[1] = r1; }
+    return;
+  }
+  double mean = sum / nvalid;
+  double sdev = lf_sqrt(sum2 / nvalid - mean * mean);
+  // normalisations: sequential sums of squares over the 36 / 36 / 72 entries
+  double nm = 0, ns = 0;
+  for (int i = 0; i < 36; i++) { double v = f_rl64(mean, i); nm += v * v; }
+  for (int i = 0; i < 36; i++) { double v = f_rl64(sdev, i); ns += v * v; }
+  nm = 1.0 / lf_sqrt(nm);
+  ns = 1.0 / lf_sqrt(ns);
+  double dm = mean * nm, dsd = sdev * ns;
+  if (dm > 0.4) dm = 0.4;
+  if (dsd > 0.4) dsd = 0.4;
+  double nt = 0;
+  for (int i = 0; i < 36; i++) { double v = f_rl64(dm, i); nt += v * v; }
+  for (int i = 0; i < 36; i++) { double v = f_rl64(dsd, i); nt += v * v; }
+  nt = 1.0 / lf_sqrt(nt);
+  if (lane < 36) { des[lane] = dm * nt; des[lane + 36] = dsd * nt; }
+  if (lane == 0) { R->r[0] = r0; R->r[1] = r1; }
+}
+
+// ----------------------------------------------------------------------------------------------
+void lf_front_launch(const FrontConsts &c, const FrontBuffers &b, int B, hipStream_t st) {
+  hipLaunchKernelGGL(k_sobel5, dim3((c.W + 255) / 256, c.H, B), dim3(256), 0, st, c, b);
+  hipLaunchKernelGGL(k_line3d, dim3(c.cand_cap, B), dim3(64), 0, st, c, b);
+  hipLaunchKernelGGL(k_records, dim3(B), dim3(64), 0, st, c, b);
+  hipLaunchKernelGGL(k_describe, dim3(c.line_cap, B), dim3(64), 0, st, c, b);
+}

@@ -81,22 +81,17 @@ LF_HD uint32_t lf_rand31(uint64_t seed, uint64_t stream, uint64_t counter) {
         }                                                                                      \
     }                                                                                          \
     for (i = 0; i < N; i++) w[i] = A[i * N + i];                                               \
-    for (i = 0; i < N - 1; i++) { /* selection sort, descending, stable for ties */            \
-      int best = i;                                                                            \
-      for (j = i + 1; j < N; j++)                                                              \
-        if (w[j] > w[best]) best = j;                                                          \
-      if (best != i) {                                                                         \
-        double tw = w[best];                                                                   \
-        int k;                                                                                 \
-        for (j = best; j > i; j--) w[j] = w[j - 1];                                            \
-        w[i] = tw;                                                                             \
-        for (k = 0; k < N; k++) {                                                              \
-          double tv = V[k * N + best];                                                         \
-          for (j = best; j > i; j--) V[k * N + j] = V[k * N + j - 1];                          \
-          V[k * N + i] = tv;                                                                   \
-        }                                                                                      \
-      }                                                                                        \
-    }                                                                                          \
+    for (i = 0; i < N - 1; i++)          /* stable bubble sort, descending; only constant */        \
+      for (j = 0; j < N - 1 - i; j++)    /* indices after unrolling (register friendly)   */        \
+        if (w[j] < w[j + 1]) {                                                                   \
+          double tw = w[j];                                                                      \
+          int k;                                                                                 \
+          w[j] = w[j + 1]; w[j + 1] = tw;                                                        \
+          for (k = 0; k < N; k++) {                                                              \
+            double tv = V[k * N + j];                                                            \
+            V[k * N + j] = V[k * N + j + 1]; V[k * N + j + 1] = tv;                              \
+          }                                                                                      \
+        }                                                                                        \
   }
 LF_DEFINE_JACOBI(lf_jacobi3, 3)
 LF_DEFINE_JACOBI(lf_jacobi4, 4)
@@ -115,10 +110,11 @@ LF_DEFINE_JACOBI(lf_jacobi4, 4)
         if (v > big) { big = v; piv = i; }                                                     \
       }                                                                                        \
       if (!(big > 0.0)) return 0;                                                              \
-      if (piv != k) {                                                                          \
-        for (j = 0; j < N; j++) { double t = A[k * N + j]; A[k * N + j] = A[piv * N + j]; A[piv * N + j] = t; } \
-        for (j = 0; j < m; j++) { double t = B[k * m + j]; B[k * m + j] = B[piv * m + j]; B[piv * m + j] = t; } \
-      }                                                                                        \
+      for (i = k + 1; i < N; i++)            /* row swap with constant indices */              \
+        if (i == piv) {                                                                        \
+          for (j = 0; j < N; j++) { double t = A[k * N + j]; A[k * N + j] = A[i * N + j]; A[i * N + j] = t; } \
+          for (j = 0; j < m; j++) { double t = B[k * m + j]; B[k * m + j] = B[i * m + j]; B[i * m + j] = t; } \
+        }                                                                                      \
       for (i = k + 1; i < N; i++) {                                                            \
         double f = A[i * N + k] / A[k * N + k];                                                \
         if (f != 0.0) {                                                                        \

@@ -314,6 +314,7 @@ static int o_subpsr(const double *xG, const double *yG, double px, double py, do
   double v1 = 0, v2 = 0, v3 = 0, v4 = 0;
   int x, y;
   if (tl_x < 0 || tl_y < 0 || tl_x + s + 1 > width || tl_y + s + 1 > height) return 0;
+  if (!(tl_x == tl_x) || !(tl_y == tl_y)) return 0; /* NaN direction (flat image): the reference indexes out of range */
   for (y = (int)tl_y; y < tl_y + s; ++y)
     for (x = (int)tl_x; x < tl_x + s; ++x) {
       double tmp1 = xG[y * width + x] * g[0] + yG[y * width + x] * g[1];
