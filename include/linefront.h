@@ -175,6 +175,39 @@ LF_API int lf_detect3d(lf_ctx *ctx, const uint8_t *gray, int gray_row_stride, co
                        int depth_row_stride, int width, int height, const double K[9],
                        uint64_t frame_id, lf_line_record *out, int cap, int *n_out);
 
+/* ---- a19-a25: line matching + pairwise motion ------------------------------------------------
+ * Result of  MatchingResult Node::matchNodePair(const Node* older_node)  (src/node.h:107,
+ * src/node.cpp:1494-1615) for one (newer, older) pair, flat form of MatchingResult
+ * (src/matching_result.h:23-49) + LoadedEdge3D (src/edge.h:25-33). */
+typedef struct lf_pair_result {
+  float T[16];            /* final_trafo == ransac_trafo == edge.transform: newer -> older, row-major 4x4 */
+  float rmse;             /* MatchingResult::rmse (1e9 when RANSAC could not start, motion.cpp:621-624)   */
+  int32_t valid;          /* edge.id1 >= 0  <=>  found_transformation (node.cpp:1606-1607)                */
+  int32_t n_matches;      /* all_line_matches.size()                                                      */
+  int32_t n_inliers;      /* inlier_line_matches.size()                                                   */
+  int32_t id_older;       /* edge.id1 */
+  int32_t id_newer;       /* edge.id2 */
+  int32_t ransac_best_iter;   /* diagnostics: iteration that produced the best minimal-sample model       */
+  int32_t refine_rounds;      /* diagnostics: number of re-score + g2o rounds (motion.cpp:775-839)         */
+  double information_scale;   /* edge.informationMatrix = I6 * (n_inl * weight) / rmse^2 (node.cpp:1533)   */
+} lf_pair_result;
+
+/* For each pair i: newer = frame slot query_frames[i], older = train_frames[i] of the LAST
+ * lf_detect3d_batch_device batch (node ids = the frame_ids given there).  Runs
+ * Node::lineMatching(older, |id diff| <= adjacent_linematch_window) and, with the point-match list
+ * empty, getTransform_PtsLines_ransac + getTransformFromHybridMatchesG2O.  Asynchronous.
+ * query_frames / train_frames are HOST arrays. */
+LF_API int lf_match_pairs_device(lf_ctx *ctx, const int32_t *query_frames, const int32_t *train_frames,
+                                 int n_pairs);
+LF_API int lf_pair_get_result(lf_ctx *ctx, int pair, lf_pair_result *out);
+/* all_line_matches of pair `pair`: cv::DMatch {queryIdx, trainIdx, distance} (node.cpp:1681-1687). */
+LF_API int lf_pair_get_matches(lf_ctx *ctx, int pair, int32_t *query_idx, int32_t *train_idx, double *dist,
+                               int cap, int *n_out);
+/* inlier_line_matches as indices into the match list. */
+LF_API int lf_pair_get_inliers(lf_ctx *ctx, int pair, int32_t *match_idx, int cap, int *n_out);
+/* descDiff matrix of pair `pair` (n_query x n_train doubles, 100 = gated out) for parity tests. */
+LF_API int lf_pair_get_descdiff(lf_ctx *ctx, int pair, double *D, size_t cap_doubles, int *n_query, int *n_train);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,7 +69,20 @@ SYMBOLS = {
     "lf_frame_get_lines": (_i, [_vp, _i, _vp, _i, _pi]),
     "lf_frame_get_candidates": (_i, [_vp, _i, _vp, _vp, _i, _pi]),
     "lf_detect3d": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, C.c_uint64, _vp, _i, _pi]),
+    "lf_match_pairs_device": (_i, [_vp, _vp, _vp, _i]),
+    "lf_pair_get_result": (_i, [_vp, _i, _vp]),
+    "lf_pair_get_matches": (_i, [_vp, _i, _vp, _vp, _vp, _i, _pi]),
+    "lf_pair_get_inliers": (_i, [_vp, _i, _vp, _i, _pi]),
+    "lf_pair_get_descdiff": (_i, [_vp, _i, _vp, C.c_size_t, _pi, _pi]),
 }
+
+
+class LfPairResult(C.Structure):
+    """struct lf_pair_result: flat MatchingResult of Node::matchNodePair."""
+    _fields_ = [("T", C.c_float * 16), ("rmse", C.c_float), ("valid", C.c_int32), ("n_matches", C.c_int32),
+                ("n_inliers", C.c_int32), ("id_older", C.c_int32), ("id_newer", C.c_int32),
+                ("ransac_best_iter", C.c_int32), ("refine_rounds", C.c_int32), ("information_scale", C.c_double)]
+
 
 # numpy view of struct lf_line_record (1040 bytes)
 REC_DTYPE = np.dtype([("p", "f8", 2), ("q", "f8", 2), ("lineEq2d", "f8", 3), ("r", "f8", 2),
@@ -228,3 +241,38 @@ class Context:
         self._chk(lib().lf_detect3d(self._h, g.ctypes.data, w, d.ctypes.data, w, w, h, Kc.ctypes.data,
                                     frame_id, recs.ctypes.data, cap, C.byref(n)), "lf_detect3d")
         return recs[:n.value].copy()
+
+    # ---- pair solver (Node::matchNodePair) -----------------------------------------------
+    def match_pairs_device(self, query_frames, train_frames):
+        """Line matching + relative pose for pairs of frame slots of the last detect3d batch (async)."""
+        q = np.ascontiguousarray(query_frames, np.int32)
+        t = np.ascontiguousarray(train_frames, np.int32)
+        assert q.shape == t.shape and q.ndim == 1
+        self._chk(lib().lf_match_pairs_device(self._h, q.ctypes.data, t.ctypes.data, len(q)),
+                  "lf_match_pairs_device")
+
+    def pair_result(self, pair):
+        r = LfPairResult()
+        self._chk(lib().lf_pair_get_result(self._h, pair, C.byref(r)), "lf_pair_get_result")
+        return r
+
+    def pair_matches(self, pair, cap=256):
+        q, t, d = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+        n = C.c_int()
+        self._chk(lib().lf_pair_get_matches(self._h, pair, q.ctypes.data, t.ctypes.data, d.ctypes.data, cap,
+                                            C.byref(n)), "lf_pair_get_matches")
+        return q[:n.value].copy(), t[:n.value].copy(), d[:n.value].copy()
+
+    def pair_inliers(self, pair, cap=256):
+        m = np.zeros(cap, np.int32)
+        n = C.c_int()
+        self._chk(lib().lf_pair_get_inliers(self._h, pair, m.ctypes.data, cap, C.byref(n)), "lf_pair_get_inliers")
+        return m[:n.value].copy()
+
+    def pair_descdiff(self, pair):
+        n1, n2 = C.c_int(), C.c_int()
+        self._chk(lib().lf_pair_get_descdiff(self._h, pair, None, 0, C.byref(n1), C.byref(n2)), "lf_pair_get_descdiff")
+        D = np.zeros((n1.value, n2.value), np.float64)
+        self._chk(lib().lf_pair_get_descdiff(self._h, pair, D.ctypes.data, D.size, C.byref(n1), C.byref(n2)),
+                  "lf_pair_get_descdiff")
+        return D

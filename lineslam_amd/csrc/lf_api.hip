@@ -7,6 +7,7 @@
 #include "../../include/linefront.h"
 #include "lf_lsd.h"
 #include "lf_front.h"
+#include "lf_pair.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -29,6 +30,10 @@ struct lf_ctx {
   FrontConsts fc;
   FrontBuffers fb;
   uint64_t *d_frame_ids = nullptr;
+  PairConsts pcn;
+  PairBuffers pb;
+  int *d_pair_q = nullptr, *d_pair_t = nullptr;
+  int last_pairs = 0;
   uint8_t *d_gray_stage = nullptr;   // staging for the host-pointer convenience entry points
   float *d_depth_stage = nullptr;
   int last_batch = 0;
@@ -290,6 +295,23 @@ static int alloc_lsd(lf_ctx *c) {
   ALLOC(c, fb.nlines, B);
   fb.frame_ids = c->d_frame_ids;
   fb.segs = b.segs; fb.nsegs = b.nsegs;
+  // ---- pair solver (at most one pair per frame slot)
+  PairConsts &pcn = c->pcn;
+  PairBuffers &pb = c->pb;
+  memset(&pcn, 0, sizeof pcn);
+  memset(&pb, 0, sizeof pb);
+  pcn.line_cap = fc.line_cap; pcn.match_cap = LF_MAX_MATCHES;
+  pcn.cos_angle_thresh = cos(30 * 3.14159265 / 180);   // node.cpp:1624 with lineslam.h:38 PI
+  ALLOC(c, c->d_pair_q, B); ALLOC(c, c->d_pair_t, B);
+  ALLOC(c, pb.D, B * (size_t)fc.line_cap * fc.line_cap);
+  ALLOC(c, pb.match_q, B * (size_t)pcn.match_cap); ALLOC(c, pb.match_t, B * (size_t)pcn.match_cap);
+  ALLOC(c, pb.match_d, B * (size_t)pcn.match_cap);
+  ALLOC(c, pb.nmatches, B);
+  ALLOC(c, pb.results, B);
+  ALLOC(c, pb.inliers, B * (size_t)LF_MAX_MATCHES);
+  ALLOC(c, pb.ws, B * (size_t)LF_PAIR_WS_DOUBLES);
+  pb.recs = fb.recs; pb.nlines = fb.nlines; pb.frame_ids = c->d_frame_ids;
+  pb.pair_q = c->d_pair_q; pb.pair_t = c->d_pair_t;
   return LF_OK;
 }
 
@@ -522,6 +544,87 @@ int lf_detect3d(lf_ctx *c, const uint8_t *gray, int gray_row_stride, const float
                                    (size_t)width * height, width, 1, K, &frame_id);
   if (r != LF_OK) return r;
   return lf_frame_get_lines(c, 0, out, cap, n_out);
+}
+
+// ---- a19-a25 -----------------------------------------------------------------------------------
+int lf_match_pairs_device(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs) {
+  if (!c || !query_frames || !train_frames || n_pairs < 1) return LF_ERR_INVALID;
+  if (n_pairs > c->maxB) return LF_ERR_CAPACITY;
+  for (int i = 0; i < n_pairs; i++)
+    if (query_frames[i] < 0 || query_frames[i] >= c->last_batch || train_frames[i] < 0 || train_frames[i] >= c->last_batch)
+      return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(c->d_pair_q, query_frames, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_pair_t, train_frames, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // caller's arrays may be temporaries
+  c->pcn.P = c->params;
+  lf_pair_launch(c->pcn, c->pb, n_pairs, c->stream);
+  HIPCHK(c, hipGetLastError());
+  c->last_pairs = n_pairs;
+  return LF_OK;
+}
+
+int lf_pair_get_result(lf_ctx *c, int pair, lf_pair_result *out) {
+  if (!c || !out || pair < 0 || pair >= c->last_pairs) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(out, c->pb.results + pair, sizeof(lf_pair_result), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LF_OK;
+}
+
+int lf_pair_get_matches(lf_ctx *c, int pair, int32_t *qi, int32_t *ti, double *dist, int cap, int *n_out) {
+  if (!c || !n_out || pair < 0 || pair >= c->last_pairs || cap < 0) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int n = 0;
+  HIPCHK(c, hipMemcpyAsync(&n, c->pb.nmatches + pair, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_out = n;
+  int m = n < cap ? n : cap;
+  if (m > c->pcn.match_cap) m = c->pcn.match_cap;
+  size_t off = (size_t)pair * c->pcn.match_cap;
+  if (m > 0 && qi) HIPCHK(c, hipMemcpyAsync(qi, c->pb.match_q + off, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+  if (m > 0 && ti) HIPCHK(c, hipMemcpyAsync(ti, c->pb.match_t + off, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+  if (m > 0 && dist) HIPCHK(c, hipMemcpyAsync(dist, c->pb.match_d + off, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return (n > cap || n > c->pcn.match_cap) ? LF_ERR_CAPACITY : LF_OK;
+}
+
+int lf_pair_get_inliers(lf_ctx *c, int pair, int32_t *match_idx, int cap, int *n_out) {
+  if (!c || !n_out || pair < 0 || pair >= c->last_pairs || cap < 0) return LF_ERR_INVALID;
+  lf_pair_result r;
+  int rc = lf_pair_get_result(c, pair, &r);
+  if (rc != LF_OK) return rc;
+  *n_out = r.n_inliers;
+  int m = r.n_inliers < cap ? r.n_inliers : cap;
+  if (m > 0 && match_idx) {
+    HIPCHK(c, hipMemcpyAsync(match_idx, c->pb.inliers + (size_t)pair * LF_MAX_MATCHES, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return r.n_inliers > cap ? LF_ERR_CAPACITY : LF_OK;
+}
+
+int lf_pair_get_descdiff(lf_ctx *c, int pair, double *D, size_t cap_doubles, int *n_query, int *n_train) {
+  if (!c || pair < 0 || pair >= c->last_pairs) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int pq = 0, pt = 0, n1 = 0, n2 = 0;
+  HIPCHK(c, hipMemcpyAsync(&pq, c->d_pair_q + pair, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&pt, c->d_pair_t + pair, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(&n1, c->fb.nlines + pq, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&n2, c->fb.nlines + pt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n1 > c->fc.line_cap) n1 = c->fc.line_cap;
+  if (n2 > c->fc.line_cap) n2 = c->fc.line_cap;
+  if (n_query) *n_query = n1;
+  if (n_train) *n_train = n2;
+  size_t need = (size_t)n1 * n2;
+  if (!D) return LF_OK;
+  if (cap_doubles < need) return LF_ERR_CAPACITY;
+  if (need) {
+    HIPCHK(c, hipMemcpyAsync(D, c->pb.D + (size_t)pair * c->fc.line_cap * c->fc.line_cap, need * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return LF_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,35 @@
+// lf_pair.h -- internal interface of the pair solver (a19-a25 of SURVEY.md section 8):
+// Node::lineMatching (src/node.cpp:1619-1694), getTransform_PtsLines_ransac (src/line/motion.cpp:605-849,
+// line matches), getTransformFromHybridMatchesG2O (src/transformation_estimation.cpp:218-461) and the
+// matchNodePair bookkeeping (src/node.cpp:1494-1615).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/linefront.h"
+
+#define LF_MAX_MATCHES 256        // line matches per pair handled by the pose kernel (4 per lane)
+#define LF_RANSAC_MAX_ITERS 1024  // sample table capacity
+#define LF_PAIR_WS_DOUBLES (LF_MAX_MATCHES * (120 + 36 + 42 + 6 + 6))   // per-pair LM workspace
+
+struct PairConsts {
+  lf_params P;
+  double cos_angle_thresh;   // cos(30 * 3.14159265 / 180), host libm (node.cpp:1624,1647)
+  int line_cap;              // records per frame
+  int match_cap;             // rows of the match list per pair
+};
+
+struct PairBuffers {
+  const lf_line_record *recs;   // [B][line_cap]
+  const int *nlines;            // [B]
+  const uint64_t *frame_ids;    // [B]  node ids (adjacency window, loop-closure threshold, RNG stream)
+  const int *pair_q, *pair_t;   // [n_pairs] frame slots of the newer (query) and older (train) node
+  double *D;                    // [n_pairs][line_cap*line_cap] descDiff scratch
+  int *match_q, *match_t;       // [n_pairs][match_cap]
+  double *match_d;              // [n_pairs][match_cap]
+  int *nmatches;                // [n_pairs] (may exceed match_cap)
+  lf_pair_result *results;      // [n_pairs]
+  int *inliers;                 // [n_pairs][LF_MAX_MATCHES] indices into the match list
+  double *ws;                   // [n_pairs][LF_PAIR_WS_DOUBLES]
+};
+
+void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t stream);

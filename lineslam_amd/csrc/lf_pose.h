@@ -1,0 +1,363 @@
+/* lf_pose.h -- geometric primitives of the pairwise motion solver, host + device, IEEE-only
+ * (+,-,*,/,sqrt; no fma, no libm) so that gcc and hipcc (-ffp-contract=off) agree bit for bit.
+ *
+ * Reference code restated here:
+ *   computeRelativeMotion_svd   src/line/motion.cpp:315-365   (3-line minimal solver, Zhang)
+ *   q2r                         src/line/utils.cpp:1677-1694
+ *   line inlier test            src/line/motion.cpp:688-699   (float transform, then mah-dist)
+ *   EdgeSE3LineEndpts::computeError   src/line/edge_se3_lineendpts.cpp:146-189
+ *   getTransformFromHybridMatchesG2O  src/transformation_estimation.cpp:218-461 (line edges only)
+ * Third-party arithmetic that is not in the reference tree and is restated from its published
+ * algorithm ("parity unpinned"): g2o's VertexSE3 update (translation + compact
+ * quaternion, right-multiplied), numeric central-difference Jacobians (delta 1e-9), Huber kernel,
+ * OptimizationAlgorithmLevenberg (tau 1e-5, Nielsen-style lambda update, <= 10 retries).  The
+ * normal equations have an arrow structure (one 6-dof pose + one 6-dof landmark per line match);
+ * they are solved exactly by eliminating the landmark blocks (Schur complement), which is what the
+ * sparse Cholesky of g2o does implicitly.
+ *
+ * The sequential oracle (oracle/pair_oracle.c) and the HIP kernels (lf_pair.hip) both compose these
+ * functions; what differs is the driver (sequential loops vs. lanes + ordered accumulation).
+ */
+#ifndef LF_POSE_H
+#define LF_POSE_H
+
+#include "lf_linalg.h"
+
+typedef struct { double R[9]; double t[3]; } lf_se3;   /* x_out = R x_in + t */
+
+LF_HD void lf_cross3(const double *a, const double *b, double *c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+LF_HD double lf_norm3(const double *a) { return lf_sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+
+/* q2r(cv::Mat q), utils.cpp:1677-1694: q = (a,b,c,d), normalised first */
+LF_HD void lf_q2r(const double *q, double *R) {
+  double a = q[0], b = q[1], c = q[2], d = q[3];
+  double nm = lf_sqrt(a * a + b * b + c * c + d * d);
+  a = a / nm; b = b / nm; c = c / nm; d = d / nm;
+  R[0] = a * a + b * b - c * c - d * d; R[1] = 2 * b * c - 2 * a * d;         R[2] = 2 * b * d + 2 * a * c;
+  R[3] = 2 * b * c + 2 * a * d;         R[4] = a * a - b * b + c * c - d * d; R[5] = 2 * c * d - 2 * a * b;
+  R[6] = 2 * b * d - 2 * a * c;         R[7] = 2 * c * d + 2 * a * b;         R[8] = a * a - b * b - c * c + d * d;
+}
+
+/* computeRelativeMotion_svd (motion.cpp:315-365) for n line pairs (n <= 3 used by RANSAC).
+ * la / lb: n x 6 doubles (A,B) of the lines in frame a (query) and frame b (train);  x_b = R x_a + t. */
+LF_HD int lf_rel_motion_lines(const double *la, const double *lb, int n, double *R, double *t) {
+  double ua[9], ub[9], da[9], db[9], A4[16], V[16], w[4], q[4];
+  double uu[9], udr[3], uui[9];
+  int i, r, c, k;
+  if (n < 2 || n > 3) return 0;
+  for (i = 0; i < n; i++) {
+    double l[3], m[3], s;
+    for (k = 0; k < 3; k++) { l[k] = la[6 * i + 3 + k] - la[6 * i + k]; m[k] = (la[6 * i + k] + la[6 * i + 3 + k]) * 0.5; }
+    s = 1 / lf_norm3(l);
+    for (k = 0; k < 3; k++) ua[3 * i + k] = l[k] * s;
+    lf_cross3(&ua[3 * i], m, &da[3 * i]);
+    for (k = 0; k < 3; k++) { l[k] = lb[6 * i + 3 + k] - lb[6 * i + k]; m[k] = (lb[6 * i + k] + lb[6 * i + 3 + k]) * 0.5; }
+    s = 1 / lf_norm3(l);
+    for (k = 0; k < 3; k++) ub[3 * i + k] = l[k] * s;
+    lf_cross3(&ub[3 * i], m, &db[3 * i]);
+  }
+  for (k = 0; k < 16; k++) A4[k] = 0;
+  for (i = 0; i < n; i++) {
+    double Ai[16], dm[3], sp[3];
+    for (k = 0; k < 16; k++) Ai[k] = 0;
+    for (k = 0; k < 3; k++) { dm[k] = ua[3 * i + k] - ub[3 * i + k]; sp[k] = ua[3 * i + k] + ub[3 * i + k]; }
+    Ai[1] = dm[0]; Ai[2] = dm[1]; Ai[3] = dm[2];
+    Ai[4] = ub[3 * i + 0] - ua[3 * i + 0]; Ai[8] = ub[3 * i + 1] - ua[3 * i + 1]; Ai[12] = ub[3 * i + 2] - ua[3 * i + 2];
+    /* vec2SkewMat(sp) into rows 1..3, cols 1..3 */
+    Ai[5] = 0;      Ai[6] = -sp[2]; Ai[7] = sp[1];
+    Ai[9] = sp[2];  Ai[10] = 0;     Ai[11] = -sp[0];
+    Ai[13] = -sp[1]; Ai[14] = sp[0]; Ai[15] = 0;
+    for (r = 0; r < 4; r++)
+      for (c = 0; c < 4; c++) {
+        double s = 0;
+        for (k = 0; k < 4; k++) s += Ai[4 * k + r] * Ai[4 * k + c];   /* (Ai^T Ai)[r][c] */
+        A4[4 * r + c] = A4[4 * r + c] + s;
+      }
+  }
+  lf_jacobi4(A4, V, w);
+  for (k = 0; k < 4; k++) q[k] = V[4 * k + 3];      /* svd.u.col(3): smallest singular value */
+  lf_q2r(q, R);
+  for (k = 0; k < 9; k++) uu[k] = 0;
+  for (k = 0; k < 3; k++) udr[k] = 0;
+  for (i = 0; i < n; i++) {
+    const double *u = &ub[3 * i];
+    double S[9], Rd[3], v[3];
+    S[0] = 0; S[1] = -u[2]; S[2] = u[1]; S[3] = u[2]; S[4] = 0; S[5] = -u[0]; S[6] = -u[1]; S[7] = u[0]; S[8] = 0;
+    for (r = 0; r < 3; r++)
+      for (c = 0; c < 3; c++) {
+        double s = 0;
+        for (k = 0; k < 3; k++) s += S[3 * r + k] * S[3 * c + k];     /* S S^T */
+        uu[3 * r + c] = uu[3 * r + c] + s;
+      }
+    for (r = 0; r < 3; r++) Rd[r] = R[3 * r] * da[3 * i] + R[3 * r + 1] * da[3 * i + 1] + R[3 * r + 2] * da[3 * i + 2];
+    for (r = 0; r < 3; r++) v[r] = db[3 * i + r] - Rd[r];
+    for (r = 0; r < 3; r++) {
+      double s = 0;
+      for (k = 0; k < 3; k++) s += S[3 * k + r] * v[k];               /* S^T v */
+      udr[r] = udr[r] + s;
+    }
+  }
+  if (!lf_inv3(uu, uui)) { t[0] = t[1] = t[2] = lf_from_bits(0x7ff8000000000000ULL); return 1; }
+  for (r = 0; r < 3; r++) t[r] = uui[3 * r] * udr[0] + uui[3 * r + 1] * udr[1] + uui[3 * r + 2] * udr[2];
+  return 1;
+}
+
+/* mah_dist3d_pt_line (utils.cpp:761-822) */
+LF_HD double lf_mah_dist(const double *pos, const double *c, const double *q1, const double *q2) {
+  double x1 = pos[0], x2 = pos[1], x3 = pos[2];
+  double xa = q1[0], ya = q1[1], za = q1[2], xb = q2[0], yb = q2[1], zb = q2[2];
+  double a0 = c[0] * (x1 - xa) + c[1] * (x2 - ya) + c[2] * (x3 - za);
+  double a1 = c[3] * (x1 - xa) + c[4] * (x2 - ya) + c[5] * (x3 - za);
+  double a2 = c[6] * (x1 - xa) + c[7] * (x2 - ya) + c[8] * (x3 - za);
+  double b0 = c[0] * (x1 - xb) + c[1] * (x2 - yb) + c[2] * (x3 - zb);
+  double b1 = c[3] * (x1 - xb) + c[4] * (x2 - yb) + c[5] * (x3 - zb);
+  double b2 = c[6] * (x1 - xb) + c[7] * (x2 - yb) + c[8] * (x3 - zb);
+  double t1 = a0 * b1 - a1 * b0, t2 = a0 * b2 - a2 * b0, t3 = a1 * b2 - a2 * b1;
+  double t4 = c[0] * (x1 - xa) - c[0] * (x1 - xb) + c[1] * (x2 - ya) - c[1] * (x2 - yb) + c[2] * (x3 - za) - c[2] * (x3 - zb);
+  double t5 = c[3] * (x1 - xa) - c[3] * (x1 - xb) + c[4] * (x2 - ya) - c[4] * (x2 - yb) + c[5] * (x3 - za) - c[5] * (x3 - zb);
+  double t6 = c[6] * (x1 - xa) - c[6] * (x1 - xb) + c[7] * (x2 - ya) - c[7] * (x2 - yb) + c[8] * (x3 - za) - c[8] * (x3 - zb);
+  return lf_sqrt((t1 * t1 + t2 * t2 + t3 * t3) / (t4 * t4 + t5 * t5 + t6 * t6));
+}
+
+/* Line inlier test of getTransform_PtsLines_ransac (motion.cpp:688-699): the query end points are
+ * transformed with the FLOAT matrix tf (Eigen::Matrix4f * Vector4f; evaluated left to right), then
+ * the Mahalanobis distances to the train line's rndA / rndB are taken in double.                  */
+LF_HD void lf_tf_point_f(const float *tf, const double *p, double *out) {
+  float x = (float)p[0], y = (float)p[1], z = (float)p[2];
+  int r;
+  for (r = 0; r < 3; r++) out[r] = (double)(((tf[4 * r] * x + tf[4 * r + 1] * y) + tf[4 * r + 2] * z) + tf[4 * r + 3] * 1.0f);
+}
+LF_HD int lf_line_inlier(const float *tf, const double *qA, const double *qB, const double *tA, const double *tB,
+                         const double *tDUa, const double *tDUb, double thr, double *sse_add) {
+  double a[3], b[3], da, db;
+  lf_tf_point_f(tf, qA, a);
+  lf_tf_point_f(tf, qB, b);
+  da = lf_mah_dist(tA, tDUa, a, b);
+  db = lf_mah_dist(tB, tDUb, a, b);
+  if (da < thr && db < thr) { *sse_add = da * da + db * db; return 1; }
+  *sse_add = 0.0;
+  return 0;
+}
+
+/* ---------------------------------------------------------------- LM refinement primitives */
+/* EdgeSE3LineEndpts::computeError (edge_se3_lineendpts.cpp:146-189): PA,PB = landmark end points in
+ * the camera frame; (Am,Bm) measured end points with whitening matrices Ma, Mb (= D^-1/2 U^T).   */
+LF_HD void lf_line_edge_error(const double *Ma, const double *Mb, const double *Am, const double *Bm,
+                              const double *PA, const double *PB, double *e) {
+  int h, r;
+  for (h = 0; h < 2; h++) {
+    const double *M = h ? Mb : Ma, *m = h ? Bm : Am;
+    double Ap[3], Bp[3], d[3], t;
+    for (r = 0; r < 3; r++) {
+      Ap[r] = M[3 * r] * (PA[0] - m[0]) + M[3 * r + 1] * (PA[1] - m[1]) + M[3 * r + 2] * (PA[2] - m[2]);
+      Bp[r] = M[3 * r] * (PB[0] - m[0]) + M[3 * r + 1] * (PB[1] - m[1]) + M[3 * r + 2] * (PB[2] - m[2]);
+      d[r] = Bp[r] - Ap[r];
+    }
+    t = -(Ap[0] * d[0] + Ap[1] * d[1] + Ap[2] * d[2]) / (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    for (r = 0; r < 3; r++) e[3 * h + r] = Ap[r] + t * d[r];
+  }
+}
+/* world -> camera (cache->w2n() with identity sensor offset): R^T (p - t) */
+LF_HD void lf_se3_inv_apply(const lf_se3 *X, const double *p, double *out) {
+  double d0 = p[0] - X->t[0], d1 = p[1] - X->t[1], d2 = p[2] - X->t[2];
+  int r;
+  for (r = 0; r < 3; r++) out[r] = X->R[r] * d0 + X->R[3 + r] * d1 + X->R[6 + r] * d2;
+}
+/* g2o VertexSE3::oplusImpl: X <- X * fromVectorMQT(v): translation v[0:3], rotation = compact
+ * quaternion v[3:6] (w = sqrt(1 - |q|^2), identity if negative)                                  */
+LF_HD void lf_se3_oplus(const lf_se3 *X, const double *v, lf_se3 *out) {
+  double w = 1.0 - (v[3] * v[3] + v[4] * v[4] + v[5] * v[5]);
+  double dR[9], q[4];
+  int r, c, k;
+  if (w < 0) { for (k = 0; k < 9; k++) dR[k] = (k % 4 == 0) ? 1.0 : 0.0; }
+  else {
+    /* Eigen::Quaterniond(w,x,y,z).toRotationMatrix() */
+    double tx, ty, tz, twx, twy, twz, txx, txy, txz, tyy, tyz, tzz;
+    q[0] = lf_sqrt(w); q[1] = v[3]; q[2] = v[4]; q[3] = v[5];
+    tx = 2.0 * q[1]; ty = 2.0 * q[2]; tz = 2.0 * q[3];
+    twx = tx * q[0]; twy = ty * q[0]; twz = tz * q[0];
+    txx = tx * q[1]; txy = ty * q[1]; txz = tz * q[1];
+    tyy = ty * q[2]; tyz = tz * q[2]; tzz = tz * q[3];
+    dR[0] = 1.0 - (tyy + tzz); dR[1] = txy - twz; dR[2] = txz + twy;
+    dR[3] = txy + twz; dR[4] = 1.0 - (txx + tzz); dR[5] = tyz - twx;
+    dR[6] = txz - twy; dR[7] = tyz + twx; dR[8] = 1.0 - (txx + tyy);
+  }
+  for (r = 0; r < 3; r++) {
+    out->t[r] = X->R[3 * r] * v[0] + X->R[3 * r + 1] * v[1] + X->R[3 * r + 2] * v[2] + X->t[r];
+    for (c = 0; c < 3; c++) {
+      double s = 0;
+      for (k = 0; k < 3; k++) s += X->R[3 * r + k] * dR[3 * k + c];
+      out->R[3 * r + c] = s;
+    }
+  }
+}
+/* Eigen::Quaterniond(Matrix3d) followed by normalisation (g2o::SE3Quat ctor) and back to a matrix:
+ * the initial estimate of the older camera (transformation_estimation.cpp:114-118)               */
+LF_HD void lf_rot_normalise(double *R) {
+  double q[4], t = R[0] + R[4] + R[8];
+  if (t > 0) {
+    double s = lf_sqrt(t + 1.0);
+    q[0] = 0.5 * s; s = 0.5 / s;
+    q[1] = (R[7] - R[5]) * s; q[2] = (R[2] - R[6]) * s; q[3] = (R[3] - R[1]) * s;
+  } else {
+    int i = 0, j, k;
+    double s;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[4 * i]) i = 2;
+    j = (i + 1) % 3; k = (j + 1) % 3;
+    s = lf_sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+    q[1 + i] = 0.5 * s; s = 0.5 / s;
+    q[0] = (R[3 * k + j] - R[3 * j + k]) * s;
+    q[1 + j] = (R[3 * j + i] + R[3 * i + j]) * s;
+    q[1 + k] = (R[3 * k + i] + R[3 * i + k]) * s;
+  }
+  lf_q2r(q, R);
+}
+
+/* Huber robust kernel (g2o RobustKernelHuber): rho[0] = rho(e2), rho[1] = rho'(e2) */
+LF_HD void lf_huber(double e2, double delta, int use, double *rho0, double *rho1) {
+  double dsqr = delta * delta;
+  if (!use || e2 <= dsqr) { *rho0 = e2; *rho1 = 1.0; }
+  else { double sq = lf_sqrt(e2); *rho0 = 2 * sq * delta - dsqr; *rho1 = delta / sq; }
+}
+
+/* One line match k of the refinement graph: landmark L (6), newer-camera measurement (world ==
+ * newer camera, fixed at identity) and older-camera measurement (pose X).  Outputs the robustified
+ * chi2 of its two edges and, if Hout != 0, its blocks of the normal equations built from numeric
+ * central-difference Jacobians (delta 1e-9, as g2o's BaseBinaryEdge::linearizeOplus):
+ *   V (6x6) landmark block, W (6x6) pose-landmark block (rows pose), bl (6), Hpp (6x6), bp (6).
+ * b = -J^T (rho' Omega) e  as in g2o (the system solved is H dx = b).                            */
+typedef struct {
+  const double *nA, *nB, *nMa, *nMb;   /* newer (query) line: end points, whitening matrices */
+  const double *oA, *oB, *oMa, *oMb;   /* older (train) line */
+} lf_line_meas;
+typedef struct { double V[36], W[36], bl[6], Hpp[36], bp[6]; } lf_line_blocks;
+
+LF_HD void lf_match_errors(const lf_se3 *X, const double *L, const lf_line_meas *m, double *en, double *eo) {
+  double PA[3], PB[3];
+  lf_line_edge_error(m->nMa, m->nMb, m->nA, m->nB, L, L + 3, en);
+  lf_se3_inv_apply(X, L, PA);
+  lf_se3_inv_apply(X, L + 3, PB);
+  lf_line_edge_error(m->oMa, m->oMb, m->oA, m->oB, PA, PB, eo);
+}
+LF_HD double lf_match_chi2(const lf_se3 *X, const double *L, const lf_line_meas *m, double wgt, double hdelta, int huber) {
+  double en[6], eo[6], c, r0, r1, s;
+  int i;
+  lf_match_errors(X, L, m, en, eo);
+  c = 0; for (i = 0; i < 6; i++) c += en[i] * (wgt * en[i]);
+  lf_huber(c, hdelta, huber, &r0, &r1);
+  s = r0;
+  c = 0; for (i = 0; i < 6; i++) c += eo[i] * (wgt * eo[i]);
+  lf_huber(c, hdelta, huber, &r0, &r1);
+  return s + r0;
+}
+LF_HD void lf_match_blocks(const lf_se3 *X, const double *L, const lf_line_meas *m, double wgt, double hdelta,
+                           int huber, lf_line_blocks *B) {
+  const double delta = 1e-9, scalar = 1.0 / (2 * 1e-9);
+  double en[6], eo[6], Jn[36], Jo[36], Jp[36];   /* d e_n/dL, d e_o/dL, d e_o/dX  (row-major 6x6) */
+  double c, r0, wn, wo;
+  int d, i, j, k;
+  lf_match_errors(X, L, m, en, eo);
+  for (d = 0; d < 6; d++) {
+    double Lp[6], ep[6], em[6], ep2[6], em2[6];
+    for (i = 0; i < 6; i++) Lp[i] = L[i];
+    Lp[d] = L[d] + delta;
+    lf_match_errors(X, Lp, m, ep, ep2);
+    Lp[d] = L[d] - delta;
+    lf_match_errors(X, Lp, m, em, em2);
+    for (i = 0; i < 6; i++) { Jn[6 * i + d] = scalar * (ep[i] - em[i]); Jo[6 * i + d] = scalar * (ep2[i] - em2[i]); }
+  }
+  for (d = 0; d < 6; d++) {
+    double v[6], PA[3], PB[3], ep[6], em[6];
+    lf_se3 Xp;
+    for (i = 0; i < 6; i++) v[i] = 0;
+    v[d] = delta;
+    lf_se3_oplus(X, v, &Xp);
+    lf_se3_inv_apply(&Xp, L, PA); lf_se3_inv_apply(&Xp, L + 3, PB);
+    lf_line_edge_error(m->oMa, m->oMb, m->oA, m->oB, PA, PB, ep);
+    v[d] = -delta;
+    lf_se3_oplus(X, v, &Xp);
+    lf_se3_inv_apply(&Xp, L, PA); lf_se3_inv_apply(&Xp, L + 3, PB);
+    lf_line_edge_error(m->oMa, m->oMb, m->oA, m->oB, PA, PB, em);
+    for (i = 0; i < 6; i++) Jp[6 * i + d] = scalar * (ep[i] - em[i]);
+  }
+  c = 0; for (i = 0; i < 6; i++) c += en[i] * (wgt * en[i]);
+  lf_huber(c, hdelta, huber, &r0, &wn);
+  c = 0; for (i = 0; i < 6; i++) c += eo[i] * (wgt * eo[i]);
+  lf_huber(c, hdelta, huber, &r0, &wo);
+  wn = wn * wgt; wo = wo * wgt;
+  for (i = 0; i < 6; i++) {
+    double sbl_n = 0, sbl_o = 0, sbp = 0;
+    for (k = 0; k < 6; k++) { sbl_n += Jn[6 * k + i] * (wn * en[k]); sbl_o += Jo[6 * k + i] * (wo * eo[k]); sbp += Jp[6 * k + i] * (wo * eo[k]); }
+    B->bl[i] = -(sbl_n + sbl_o);
+    B->bp[i] = -sbp;
+    for (j = 0; j < 6; j++) {
+      double vn = 0, vo = 0, hw = 0, hp = 0;
+      for (k = 0; k < 6; k++) {
+        vn += Jn[6 * k + i] * (wn * Jn[6 * k + j]);
+        vo += Jo[6 * k + i] * (wo * Jo[6 * k + j]);
+        hw += Jp[6 * k + i] * (wo * Jo[6 * k + j]);
+        hp += Jp[6 * k + i] * (wo * Jp[6 * k + j]);
+      }
+      B->V[6 * i + j] = vn + vo;
+      B->W[6 * i + j] = hw;
+      B->Hpp[6 * i + j] = hp;
+    }
+  }
+}
+/* Elimination of one landmark at damping lambda: Vi = (V + lambda I)^-1;  T = W Vi W^T (6x6),
+ * u = W Vi bl (6).  Vi is kept for the back-substitution dl = Vi (bl - W^T dp).                  */
+LF_HD int lf_match_eliminate(const lf_line_blocks *B, double lambda, double *Vi, double *T, double *u) {
+  double A[36], I6[36], WV[36];
+  int i, j, k;
+  for (i = 0; i < 36; i++) { A[i] = B->V[i]; I6[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+  for (i = 0; i < 6; i++) A[7 * i] += lambda;
+  if (!lf_solve6(A, I6, 6)) return 0;
+  for (i = 0; i < 36; i++) Vi[i] = I6[i];
+  for (i = 0; i < 6; i++)
+    for (j = 0; j < 6; j++) { double s = 0; for (k = 0; k < 6; k++) s += B->W[6 * i + k] * Vi[6 * k + j]; WV[6 * i + j] = s; }
+  for (i = 0; i < 6; i++) {
+    double s = 0;
+    for (k = 0; k < 6; k++) s += WV[6 * i + k] * B->bl[k];
+    u[i] = s;
+    for (j = 0; j < 6; j++) { double s2 = 0; for (k = 0; k < 6; k++) s2 += WV[6 * i + k] * B->W[6 * j + k]; T[6 * i + j] = s2; }
+  }
+  return 1;
+}
+LF_HD void lf_match_backsub(const lf_line_blocks *B, const double *Vi, const double *dp, double *dl) {
+  double r[6];
+  int i, k;
+  for (i = 0; i < 6; i++) { double s = 0; for (k = 0; k < 6; k++) s += B->W[6 * k + i] * dp[k]; r[i] = B->bl[i] - s; }
+  for (i = 0; i < 6; i++) { double s = 0; for (k = 0; k < 6; k++) s += Vi[6 * i + k] * r[k]; dl[i] = s; }
+}
+
+/* float Matrix4f (row-major 16) <-> the pose of the OLDER camera in the newer frame
+ * (transformation_estimation.cpp:226-232: vertex 0 is initialised with T^-1; :459 returns
+ * estimate().cast<float>().inverse()).                                                          */
+LF_HD void lf_tf_to_older_pose(const float *tf, lf_se3 *X) {
+  double R[9], t[3];
+  int r, c;
+  for (r = 0; r < 3; r++) { for (c = 0; c < 3; c++) R[3 * r + c] = (double)tf[4 * r + c]; t[r] = (double)tf[4 * r + 3]; }
+  for (r = 0; r < 3; r++) {
+    for (c = 0; c < 3; c++) X->R[3 * r + c] = R[3 * c + r];
+    X->t[r] = -(R[r] * t[0] + R[3 + r] * t[1] + R[6 + r] * t[2]);
+  }
+  lf_rot_normalise(X->R);
+}
+LF_HD void lf_older_pose_to_tf(const lf_se3 *X, float *tf) {
+  float R[9], t[3];
+  int r, c;
+  for (r = 0; r < 9; r++) R[r] = (float)X->R[r];
+  for (r = 0; r < 3; r++) t[r] = (float)X->t[r];
+  for (r = 0; r < 3; r++) {
+    for (c = 0; c < 3; c++) tf[4 * r + c] = R[3 * c + r];
+    tf[4 * r + 3] = -((R[r] * t[0] + R[3 + r] * t[1]) + R[6 + r] * t[2]);
+  }
+  tf[12] = 0.0f; tf[13] = 0.0f; tf[14] = 0.0f; tf[15] = 1.0f;
+}
+
+#endif /* LF_POSE_H */

@@ -173,3 +173,36 @@ def sobel_oracle(gray_u8, flavour="lf"):
     lib.oracle_sobel5(C.c_void_p(g.ctypes.data), C.c_int(w), C.c_int(w), C.c_int(h),
                       C.c_void_p(gx.ctypes.data), C.c_void_p(gy.ctypes.data))
     return gx, gy
+
+
+# ------------------------------------------------------------------ pair solver
+def match_oracle(f1, f2, adjacent=True, flavour="lf", cap=1024):
+    """oracle_line_matching: Node::lineMatching(this=f1 (query), other=f2 (train))."""
+    lib = oracle_lib(flavour)
+    a, b = np.ascontiguousarray(f1), np.ascontiguousarray(f2)
+    mq, mt, md = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+    D = np.zeros((max(len(a), 1), max(len(b), 1)), np.float64)
+    lib.oracle_line_matching.restype = C.c_int
+    n = lib.oracle_line_matching(C.c_void_p(a.ctypes.data), C.c_int(len(a)), C.c_void_p(b.ctypes.data),
+                                 C.c_int(len(b)), C.c_int(1 if adjacent else 0), C.c_void_p(mq.ctypes.data),
+                                 C.c_void_p(mt.ctypes.data), C.c_void_p(md.ctypes.data), C.c_int(cap),
+                                 C.c_void_p(D.ctypes.data))
+    return mq[:n].copy(), mt[:n].copy(), md[:n].copy(), D
+
+
+def pose_oracle(train, query, mq, mt, id_train, id_query, params, stream, flavour="lf"):
+    """oracle_pose_lines_ransac: getTransform_PtsLines_ransac with line matches only."""
+    lib = oracle_lib(flavour)
+    tr, qu = np.ascontiguousarray(train), np.ascontiguousarray(query)
+    q, t = np.ascontiguousarray(mq, np.int32), np.ascontiguousarray(mt, np.int32)
+    tf = np.zeros(16, np.float32)
+    rmse = C.c_float()
+    inl = np.zeros(max(len(q), 1), np.int32)
+    ninl = C.c_int()
+    dbg = np.zeros(4, np.int32)
+    lib.oracle_pose_lines_ransac.restype = C.c_int
+    ok = lib.oracle_pose_lines_ransac(C.c_void_p(tr.ctypes.data), C.c_void_p(qu.ctypes.data), C.c_void_p(q.ctypes.data),
+                                      C.c_void_p(t.ctypes.data), C.c_int(len(q)), C.c_int(id_train), C.c_int(id_query),
+                                      C.byref(params), C.c_uint64(stream), C.c_void_p(tf.ctypes.data), C.byref(rmse),
+                                      C.c_void_p(inl.ctypes.data), C.byref(ninl), C.c_void_p(dbg.ctypes.data))
+    return bool(ok), tf.reshape(4, 4).copy(), float(rmse.value), inl[:ninl.value].copy(), dbg
