@@ -300,7 +300,8 @@ __device__ void p_refine(const PoseCtx &pc, const int *set, int n, float *tf, in
 
 // inlier scan of all matches with tf; returns count, fills set[] (ascending) and the float sse the
 // reference accumulates (motion.cpp:688-699 / 795-812)
-__device__ int p_score(const PoseCtx &pc, int nLn, const float *tf, double thr, int *set, float *sse_out) {
+__device__ int p_score(const PoseCtx &pc, int nLn, const float *tf, double thr, int *set, float *sse_out,
+                       double *sse_d_out) {
   const int lane = p_lane();
   double add[NSLOT];
   u64 msk[NSLOT];
@@ -318,13 +319,15 @@ __device__ int p_score(const PoseCtx &pc, int nLn, const float *tf, double thr, 
     if (in) set[cnt + __popcll(msk[h] & p_lt())] = i;
     cnt += __popcll(msk[h]);
   }
-  float sse = 0;
+  float sse = 0;      // `float sse` of the RANSAC loop (motion.cpp:666)
+  double sse_d = 0;   // `double tmp_sse` of the re-scoring loop (motion.cpp:778)
 #pragma unroll
   for (int h = 0; h < NSLOT; h++) {
     u64 m = msk[h];
-    while (m) { int l = __builtin_ctzll(m); m &= m - 1; sse += p_rl64(add[h], l); }
+    while (m) { int l = __builtin_ctzll(m); m &= m - 1; double a = p_rl64(add[h], l); sse += a; sse_d += a; }
   }
   *sse_out = sse;
+  *sse_d_out = sse_d;
   __syncthreads();
   return cnt;
 }
@@ -419,7 +422,8 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
       lf_rel_motion_lines(la, lb, 3, R, t);
       for (int i = 0; i < 3; i++) { for (int cc = 0; cc < 3; cc++) tf_best[4 * i + cc] = (float)R[3 * i + cc]; tf_best[4 * i + 3] = (float)t[i]; }
       tf_best[12] = tf_best[13] = tf_best[14] = 0.0f; tf_best[15] = 1.0f;
-      int nb = p_score(pc, nLn, tf_best, thr, S.set, &sse_best);
+      double sse_unused;
+      int nb = p_score(pc, nLn, tf_best, thr, S.set, &sse_best, &sse_unused);
       float refined_tf[16];
 #pragma unroll
       for (int i = 0; i < 16; i++) refined_tf[i] = tf_best[i];
@@ -427,11 +431,12 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
       double refined_rmse = lf_sqrt(sse_best / (0 + nb));                                    // :731
       int nref = 0;
       for (int iter = 0; iter < 20; ++iter) {                                                // :775-839
-        float tmp_sse;
+        float tmp_sse_f;
+        double tmp_sse;
         int *inl = b.inliers + (size_t)pr * LF_MAX_MATCHES;
         // score into a scratch list first (kept only if it improves)
         __syncthreads();
-        int ncur = p_score(pc, nLn, refined_tf, thr, S.idx, &tmp_sse);
+        int ncur = p_score(pc, nLn, refined_tf, thr, S.idx, &tmp_sse_f, &tmp_sse);
         if (0 + ncur * lw > 0 + nref * lw) {
           for (int i = lane; i < ncur; i += 64) { S.set[i] = S.idx[i]; inl[i] = S.idx[i]; }
           __syncthreads();

@@ -56,8 +56,9 @@ def test_pairs_bit_exact_vs_oracle(built_lib, seq):
             assert r.id_older == int(ids[ft]) and r.id_newer == int(ids[fq])
             assert r.information_scale == pytest.approx(len(inl) / rmse ** 2, rel=1e-6)
             # BASELINE.json tolerance vs the CPU path, and sanity vs ground truth
-            dR = T[:3, :3].astype(float) @ tf[:3, :3].astype(float).T
-            assert np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)) <= 1e-4
+            # (rotation angle between two nearly equal rotations ~ |R1 - R2|_F / sqrt(2); float32 matrices
+            #  are not orthonormal to better than 1e-7, so acos(trace) would be meaningless here)
+            assert np.linalg.norm(T[:3, :3].astype(float) - tf[:3, :3].astype(float)) / np.sqrt(2) <= 1e-4
             assert np.linalg.norm(T[:3, 3] - tf[:3, 3]) <= 1e-3
             Tgt = np.linalg.inv(poses[ft]) @ poses[fq]
             dG = T[:3, :3].astype(float) @ Tgt[:3, :3].T
