@@ -208,6 +208,26 @@ LF_API int lf_pair_get_inliers(lf_ctx *ctx, int pair, int32_t *match_idx, int ca
 /* descDiff matrix of pair `pair` (n_query x n_train doubles, 100 = gated out) for parity tests. */
 LF_API int lf_pair_get_descdiff(lf_ctx *ctx, int pair, double *D, size_t cap_doubles, int *n_query, int *n_train);
 
+/* Stage durations (ms) of the last launches, measured with HIP events recorded on the context
+ * stream: which = 0 LSD data-parallel kernels, 1 the LSD sweep kernel (k_lsd_sweep), 2 the 3D-line
+ * stage, 3 the pair solver.  Synchronises. */
+LF_API int lf_get_stage_ms(lf_ctx *ctx, int which, float *ms);
+
+/* ---- multi-GPU: keyframe line maps ----------------------------------------------------------
+ * Device pointers of the per-frame line maps of the last batch -- [max_batch][line_cap] records,
+ * [max_batch] counts, [max_batch] node ids -- the fixed-stride payload of the RCCL all-gather that
+ * gives every rank all keyframe line maps.  The pointers stay owned by the
+ * context. */
+LF_API int lf_get_device_records(lf_ctx *ctx, lf_line_record **d_recs, int32_t **d_nlines, uint64_t **d_ids,
+                                 int *line_cap);
+/* As lf_match_pairs_device, but the older (train) node of pair i is slot train_slots[i] of an
+ * EXTERNAL device-resident map (ext_frames x ext_line_cap records + counts + node ids), e.g. the
+ * all-gathered keyframes of all ranks: loop-closure matching, BASELINE.json configs 4 and 5. */
+LF_API int lf_match_external_device(lf_ctx *ctx, const int32_t *query_frames, const int32_t *train_slots,
+                                    int n_pairs, const lf_line_record *d_ext_recs,
+                                    const int32_t *d_ext_nlines, const uint64_t *d_ext_ids, int ext_frames,
+                                    int ext_line_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,7 +74,18 @@ SYMBOLS = {
     "lf_pair_get_matches": (_i, [_vp, _i, _vp, _vp, _vp, _i, _pi]),
     "lf_pair_get_inliers": (_i, [_vp, _i, _vp, _i, _pi]),
     "lf_pair_get_descdiff": (_i, [_vp, _i, _vp, C.c_size_t, _pi, _pi]),
+    "lf_get_stage_ms": (_i, [_vp, _i, C.POINTER(C.c_float)]),
+    "lf_get_device_records": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _pi]),
+    "lf_match_external_device": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i]),
 }
+
+
+class _DevArray:
+    """Zero-copy view of library-owned device memory for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2}
 
 
 class LfPairResult(C.Structure):
@@ -276,3 +287,32 @@ class Context:
         self._chk(lib().lf_pair_get_descdiff(self._h, pair, D.ctypes.data, D.size, C.byref(n1), C.byref(n2)),
                   "lf_pair_get_descdiff")
         return D
+
+    def stage_ms(self, which):
+        """HIP-event duration (ms) of a stage of the last launches: 0 LSD data-parallel, 1 k_lsd_sweep,
+        2 3D-line stage, 3 pair solver."""
+        v = C.c_float()
+        self._chk(lib().lf_get_stage_ms(self._h, which, C.byref(v)), "lf_get_stage_ms")
+        return float(v.value)
+
+    # ---- multi-GPU plumbing ---------------------------------------------------------------
+    def device_records(self, torch):
+        """torch uint8/int32/int64 views (no copy) of the record, count and node-id arrays of the last batch:
+        ([max_batch, line_cap*1040] u8, [max_batch] i32, [max_batch] i64).  Payload of the RCCL all-gather."""
+        r, n, i = _vp(), _vp(), _vp()
+        cap = C.c_int()
+        self._chk(lib().lf_get_device_records(self._h, C.byref(r), C.byref(n), C.byref(i), C.byref(cap)),
+                  "lf_get_device_records")
+        self.line_cap = cap.value
+        recs = torch.as_tensor(_DevArray(r.value, (self.max_batch, cap.value * REC_DTYPE.itemsize), "|u1"), device="cuda")
+        nl = torch.as_tensor(_DevArray(n.value, (self.max_batch,), "<i4"), device="cuda")
+        ids = torch.as_tensor(_DevArray(i.value, (self.max_batch,), "<i8"), device="cuda")
+        return recs, nl, ids
+
+    def match_external_device(self, query_frames, train_slots, ext_recs_ptr, ext_nlines_ptr, ext_ids_ptr,
+                              ext_frames, ext_line_cap):
+        q = np.ascontiguousarray(query_frames, np.int32)
+        t = np.ascontiguousarray(train_slots, np.int32)
+        self._chk(lib().lf_match_external_device(self._h, q.ctypes.data, t.ctypes.data, len(q), _vp(ext_recs_ptr),
+                                                 _vp(ext_nlines_ptr), _vp(ext_ids_ptr), ext_frames, ext_line_cap),
+                  "lf_match_external_device")

@@ -34,6 +34,7 @@ struct lf_ctx {
   PairBuffers pb;
   int *d_pair_q = nullptr, *d_pair_t = nullptr;
   int last_pairs = 0;
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint8_t *d_gray_stage = nullptr;   // staging for the host-pointer convenience entry points
   float *d_depth_stage = nullptr;
   int last_batch = 0;
@@ -311,6 +312,7 @@ static int alloc_lsd(lf_ctx *c) {
   ALLOC(c, pb.inliers, B * (size_t)LF_MAX_MATCHES);
   ALLOC(c, pb.ws, B * (size_t)LF_PAIR_WS_DOUBLES);
   pb.recs = fb.recs; pb.nlines = fb.nlines; pb.frame_ids = c->d_frame_ids;
+  pb.recs_t = fb.recs; pb.nlines_t = fb.nlines; pb.frame_ids_t = c->d_frame_ids; pb.line_cap_t = fc.line_cap;
   pb.pair_q = c->d_pair_q; pb.pair_t = c->d_pair_t;
   return LF_OK;
 }
@@ -336,6 +338,8 @@ int lf_ctx_create(lf_ctx **out, int device, void *hip_stream, int width, int hei
       if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { r = fail_hip(c, e, "hipStreamCreate"); break; }
       c->own_stream = true;
     }
+    for (int i = 0; i < 8; i++) if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) { r = fail_hip(c, e, "hipEventCreate"); break; }
+    if (r != LF_OK) break;
     if ((r = build_lsd_consts(c)) != LF_OK) break;
     if ((r = alloc_lsd(c)) != LF_OK) break;
     if ((r = upload_lsd_tables(c)) != LF_OK) break;
@@ -350,6 +354,7 @@ void lf_ctx_destroy(lf_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (void *p : c->allocs) (void)hipFree(p);
+  for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -380,6 +385,7 @@ int lf_lsd_batch_device(lf_ctx *c, const uint8_t *d_gray, size_t frame_stride, i
   c->lb.gray = d_gray;
   c->lb.gray_frame_stride = frame_stride;
   c->lb.gray_row_stride = row_stride;
+  c->lb.ev_pre = c->ev[0]; c->lb.ev_sweep0 = c->ev[1]; c->lb.ev_sweep1 = c->ev[2];
   lf_lsd_launch(c->lc, c->lb, n_frames, c->stream);
   HIPCHK(c, hipGetLastError());
   c->last_batch = n_frames;
@@ -494,6 +500,7 @@ int lf_detect3d_batch_device(lf_ctx *c, const uint8_t *d_gray, size_t gray_frame
   c->fb.gray = d_gray; c->fb.gray_frame_stride = gray_frame_stride; c->fb.gray_row_stride = gray_row_stride;
   c->fb.depth = d_depth; c->fb.depth_frame_stride = depth_frame_stride; c->fb.depth_row_stride = depth_row_stride;
   lf_front_launch(c->fc, c->fb, n_frames, c->stream);
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   HIPCHK(c, hipGetLastError());
   return LF_OK;
 }
@@ -547,20 +554,47 @@ int lf_detect3d(lf_ctx *c, const uint8_t *gray, int gray_row_stride, const float
 }
 
 // ---- a19-a25 -----------------------------------------------------------------------------------
-int lf_match_pairs_device(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs) {
+static int match_pairs_impl(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
+                            const lf_line_record *d_ext_recs, const int32_t *d_ext_nlines,
+                            const uint64_t *d_ext_ids, int ext_frames, int ext_line_cap) {
   if (!c || !query_frames || !train_frames || n_pairs < 1) return LF_ERR_INVALID;
   if (n_pairs > c->maxB) return LF_ERR_CAPACITY;
+  const int ntrain = d_ext_recs ? ext_frames : c->last_batch;
   for (int i = 0; i < n_pairs; i++)
-    if (query_frames[i] < 0 || query_frames[i] >= c->last_batch || train_frames[i] < 0 || train_frames[i] >= c->last_batch)
+    if (query_frames[i] < 0 || query_frames[i] >= c->last_batch || train_frames[i] < 0 || train_frames[i] >= ntrain)
       return LF_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(c->d_pair_q, query_frames, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_pair_t, train_frames, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // caller's arrays may be temporaries
   c->pcn.P = c->params;
-  lf_pair_launch(c->pcn, c->pb, n_pairs, c->stream);
+  PairBuffers pb = c->pb;
+  if (d_ext_recs) { pb.recs_t = d_ext_recs; pb.nlines_t = d_ext_nlines; pb.frame_ids_t = d_ext_ids; pb.line_cap_t = ext_line_cap; }
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  lf_pair_launch(c->pcn, pb, n_pairs, c->stream);
+  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   HIPCHK(c, hipGetLastError());
   c->last_pairs = n_pairs;
+  return LF_OK;
+}
+
+int lf_match_pairs_device(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs) {
+  return match_pairs_impl(c, query_frames, train_frames, n_pairs, nullptr, nullptr, nullptr, 0, 0);
+}
+
+int lf_match_external_device(lf_ctx *c, const int32_t *query_frames, const int32_t *train_slots, int n_pairs,
+                             const lf_line_record *d_ext_recs, const int32_t *d_ext_nlines,
+                             const uint64_t *d_ext_ids, int ext_frames, int ext_line_cap) {
+  if (!d_ext_recs || !d_ext_nlines || !d_ext_ids || ext_frames < 1 || ext_line_cap < 1) return LF_ERR_INVALID;
+  return match_pairs_impl(c, query_frames, train_slots, n_pairs, d_ext_recs, d_ext_nlines, d_ext_ids, ext_frames, ext_line_cap);
+}
+
+int lf_get_device_records(lf_ctx *c, lf_line_record **d_recs, int32_t **d_nlines, uint64_t **d_ids, int *line_cap) {
+  if (!c) return LF_ERR_INVALID;
+  if (d_recs) *d_recs = c->fb.recs;
+  if (d_nlines) *d_nlines = c->fb.nlines;
+  if (d_ids) *d_ids = c->d_frame_ids;
+  if (line_cap) *line_cap = c->fc.line_cap;
   return LF_OK;
 }
 
@@ -624,6 +658,25 @@ int lf_pair_get_descdiff(lf_ctx *c, int pair, double *D, size_t cap_doubles, int
     HIPCHK(c, hipMemcpyAsync(D, c->pb.D + (size_t)pair * c->fc.line_cap * c->fc.line_cap, need * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  return LF_OK;
+}
+
+// Stage durations of the last launches, from HIP events recorded on the context stream:
+// which = 0 LSD data-parallel kernels (sampler, gradient, seed sort), 1 k_lsd_sweep, 2 3D-line stage,
+// 3 pair solver.  Synchronises the stream.
+int lf_get_stage_ms(lf_ctx *c, int which, float *ms) {
+  if (!c || !ms || which < 0 || which > 3) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipEvent_t a, b;
+  switch (which) {
+    case 0: a = c->ev[0]; b = c->ev[1]; break;
+    case 1: a = c->ev[1]; b = c->ev[2]; break;
+    case 2: a = c->ev[2]; b = c->ev[3]; break;
+    default: a = c->ev[4]; b = c->ev[5]; break;
+  }
+  hipError_t e = hipEventElapsedTime(ms, a, b);
+  if (e != hipSuccess) { *ms = -1.0f; return fail_hip(c, e, "hipEventElapsedTime"); }
   return LF_OK;
 }
 

@@ -57,6 +57,7 @@ struct LsdBuffers {
   double *segs;          // [B][seg_cap][5]
   int *nsegs;            // [B]  (may exceed seg_cap: overflow)
   unsigned long long *stats; // [B][8] optional work counters, may be null
+  hipEvent_t ev_pre, ev_sweep0, ev_sweep1;   // optional: recorded before the first kernel / around k_lsd_sweep
 };
 
 void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int n_frames, hipStream_t stream);

@@ -759,6 +759,7 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
 void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int B, hipStream_t st) {
   const size_t NM = (size_t)c.N * c.M;
   dim3 blk(256);
+  if (b.ev_pre) (void)hipEventRecord(b.ev_pre, st);
   hipLaunchKernelGGL(k_gauss_x, dim3((c.N + 255) / 256, c.H, B), blk, 0, st, c, b);
   hipLaunchKernelGGL(k_gauss_y, dim3((c.N + 255) / 256, c.M, B), blk, 0, st, c, b);
   hipLaunchKernelGGL(k_ll_angle, dim3((c.N + 255) / 256, c.M, B), blk, 0, st, c, b);
@@ -769,5 +770,7 @@ void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int B, hipStream_t s
   hipLaunchKernelGGL(k_seed_scatter, dim3(nch, B), dim3(64), lds, st, c, b);
   (void)hipMemsetAsync(b.used, 0, NM * (size_t)B, st);
   (void)hipMemsetAsync(b.labels, 0, NM * (size_t)B * sizeof(uint16_t), st);
+  if (b.ev_sweep0) (void)hipEventRecord(b.ev_sweep0, st);
   hipLaunchKernelGGL(k_lsd_sweep, dim3(B), dim3(64), 0, st, c, b.dconsts, b);
+  if (b.ev_sweep1) (void)hipEventRecord(b.ev_sweep1, st);
 }

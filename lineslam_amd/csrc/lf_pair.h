@@ -19,9 +19,13 @@ struct PairConsts {
 };
 
 struct PairBuffers {
-  const lf_line_record *recs;   // [B][line_cap]
+  const lf_line_record *recs;   // [B][line_cap]   query (newer) side: this context's last batch
   const int *nlines;            // [B]
   const uint64_t *frame_ids;    // [B]  node ids (adjacency window, loop-closure threshold, RNG stream)
+  const lf_line_record *recs_t; // train (older) side: the same arrays, or an external keyframe map
+  const int *nlines_t;          //   (e.g. the result of the RCCL all-gather of other ranks' line maps)
+  const uint64_t *frame_ids_t;
+  int line_cap_t;
   const int *pair_q, *pair_t;   // [n_pairs] frame slots of the newer (query) and older (train) node
   double *D;                    // [n_pairs][line_cap*line_cap] descDiff scratch
   int *match_q, *match_t;       // [n_pairs][match_cap]

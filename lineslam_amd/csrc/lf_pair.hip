@@ -58,12 +58,13 @@ __global__ void __launch_bounds__(256) k_match(PairConsts c, PairBuffers b) {
   __shared__ int s_wbase[4];
   const int pr = blockIdx.x, tid = threadIdx.x;
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];
-  int n1 = b.nlines[fq], n2 = b.nlines[ft];
+  int n1 = b.nlines[fq], n2 = b.nlines_t[ft];
   if (n1 > c.line_cap) n1 = c.line_cap;
+  if (n2 > b.line_cap_t) n2 = b.line_cap_t;
   if (n2 > c.line_cap) n2 = c.line_cap;
-  const lf_line_record *f1 = b.recs + (size_t)fq * c.line_cap, *f2 = b.recs + (size_t)ft * c.line_cap;
+  const lf_line_record *f1 = b.recs + (size_t)fq * c.line_cap, *f2 = b.recs_t + (size_t)ft * b.line_cap_t;
   double *D = b.D + (size_t)pr * c.line_cap * c.line_cap;
-  long long idd = (long long)b.frame_ids[fq] - (long long)b.frame_ids[ft];
+  long long idd = (long long)b.frame_ids[fq] - (long long)b.frame_ids_t[ft];
   if (idd < 0) idd = -idd;
   const bool adjacent = !(idd > c.P.adjacent_linematch_window);                       // node.cpp:1505-1507
   const double lineDistThresh = adjacent ? 45 : 80, descDiffThresh = adjacent ? 0.85 : 0.7;
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];
   lf_pair_result *res = b.results + pr;
   PoseCtx pc;
-  pc.train = b.recs + (size_t)ft * c.line_cap;
+  pc.train = b.recs_t + (size_t)ft * b.line_cap_t;
   pc.query = b.recs + (size_t)fq * c.line_cap;
   pc.mq = b.match_q + (size_t)pr * c.match_cap;
   pc.mt = b.match_t + (size_t)pr * c.match_cap;
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
   const int n_all = nLn;
   if (nLn > c.match_cap) nLn = c.match_cap;
   if (nLn > LF_MAX_MATCHES) nLn = LF_MAX_MATCHES;
-  const long long id_t = (long long)b.frame_ids[ft], id_q = (long long)b.frame_ids[fq];
+  const long long id_t = (long long)b.frame_ids_t[ft], id_q = (long long)b.frame_ids[fq];
   float tf_out[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) tf_out[i] = (i % 5 == 0) ? 1.0f : 0.0f;

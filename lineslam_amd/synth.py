@@ -14,7 +14,27 @@ K_TUM = np.array([[525.0, 0.0, 319.5], [0.0, 525.0, 239.5], [0.0, 0.0, 1.0]])
 
 def _quad(o, u, v, grey, stripes=0, axis=0):
     return dict(o=np.asarray(o, float), u=np.asarray(u, float), v=np.asarray(v, float), grey=float(grey),
-                stripes=int(stripes), axis=int(axis))
+                stripes=int(stripes), axis=int(axis), tex=None)
+
+
+def _texture(qd, qi, seed, cell=0.035, amp=14.0):
+    """Fine surface texture (value noise, `cell` metres per knot): real images are full of weak
+    gradients that seed thousands of small LSD regions; flat synthetic surfaces are not."""
+    if qd["tex"] is None:
+        rng = np.random.default_rng(seed * 1009 + qi)
+        nu_, nv_ = int(np.linalg.norm(qd["u"]) / cell) + 2, int(np.linalg.norm(qd["v"]) / cell) + 2
+        qd["tex"] = rng.uniform(-amp, amp, (min(nv_, 400), min(nu_, 400)))
+    return qd["tex"]
+
+
+def _sample_tex(tex, s, r):
+    h, w = tex.shape
+    x = np.clip(s, 0, 1) * (w - 1.001)
+    y = np.clip(r, 0, 1) * (h - 1.001)
+    x0, y0 = np.floor(x).astype(np.int64), np.floor(y).astype(np.int64)
+    fx, fy = x - x0, y - y0
+    return (tex[y0, x0] * (1 - fx) * (1 - fy) + tex[y0, x0 + 1] * fx * (1 - fy) +
+            tex[y0 + 1, x0] * (1 - fx) * fy + tex[y0 + 1, x0 + 1] * fx * fy)
 
 
 def _box(c, size, rng):
@@ -27,7 +47,7 @@ def _box(c, size, rng):
             _quad(o + ey, ex, ez, g[3]), _quad(o, ey, ez, g[4]), _quad(o + ex, ey, ez, g[5])]
 
 
-def make_scene(seed=0, n_boxes=10, n_posters=14):
+def make_scene(seed=0, n_boxes=24, n_posters=40):
     """World frame: x right, y down, z forward (camera looks along +z from near the origin)."""
     rng = np.random.default_rng(seed)
     q = []
@@ -73,7 +93,7 @@ def camera_pose(t, seed=0):
     return T
 
 
-def render(scene, T_wc, K=K_TUM, w=640, h=480, noise_seed=0, noise_sigma=2.0, hole_frac=0.05):
+def render(scene, T_wc, K=K_TUM, w=640, h=480, noise_seed=0, noise_sigma=2.0, hole_frac=0.05, texture_seed=0):
     """Ray-cast the scene.  Returns (gray uint8 [h,w], depth float32 [h,w] in metres, NaN = no data)."""
     rng = np.random.default_rng(noise_seed)
     xs, ys = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
@@ -85,21 +105,39 @@ def render(scene, T_wc, K=K_TUM, w=640, h=480, noise_seed=0, noise_sigma=2.0, ho
     for qi, qd in enumerate(scene):
         o, u, v = qd["o"], qd["u"], qd["v"]
         n = np.cross(u, v)
-        den = dw @ n
+        # screen-space bounding box of the quad (whole image if it crosses the camera plane)
+        corners = np.stack([o, o + u, o + v, o + u + v])
+        cc = (corners - c) @ R
+        x0, x1, y0, y1 = 0, w, 0, h
+        if np.all(cc[:, 2] > 0.05):
+            px = cc[:, 0] / cc[:, 2] * K[0, 0] + K[0, 2]
+            py = cc[:, 1] / cc[:, 2] * K[1, 1] + K[1, 2]
+            x0, x1 = int(max(0, np.floor(px.min()) - 1)), int(min(w, np.ceil(px.max()) + 2))
+            y0, y1 = int(max(0, np.floor(py.min()) - 1)), int(min(h, np.ceil(py.max()) + 2))
+            if x0 >= x1 or y0 >= y1:
+                continue
+        d_ = dw[y0:y1, x0:x1]
+        den = d_ @ n
         with np.errstate(divide="ignore", invalid="ignore"):
             t = ((o - c) @ n) / den
-        hit = c + t[..., None] * dw - o
-        s = (hit @ u) / (u @ u)
-        r = (hit @ v) / (v @ v)
-        ok = (t > 0.05) & (s >= 0) & (s <= 1) & (r >= 0) & (r <= 1) & (t < best_t)
-        g = np.full((h, w), qd["grey"])
+            hit = c + t[..., None] * d_ - o
+            s = (hit @ u) / (u @ u)
+            r = (hit @ v) / (v @ v)
+            ok = (t > 0.05) & (s >= 0) & (s <= 1) & (r >= 0) & (r <= 1) & (t < best_t[y0:y1, x0:x1])
+        if not ok.any():
+            continue
+        so, ro = s[ok], r[ok]
+        g = np.full(so.shape, qd["grey"])
         if qd["stripes"]:
-            coord = s if qd["axis"] == 0 else r
+            coord = so if qd["axis"] == 0 else ro
             g = g + 45.0 * (((np.floor(coord * qd["stripes"] * 2)).astype(np.int64) % 2) * 2 - 1)
+        if texture_seed is not None:
+            g = g + _sample_tex(_texture(qd, qi, texture_seed), so, ro)
         # mild Lambertian shading so that faces of one box differ
         shade = 0.75 + 0.25 * abs(n[2]) / np.linalg.norm(n)
-        grey = np.where(ok, g * shade, grey)
-        best_t = np.where(ok, t, best_t)
+        sub_g, sub_t = grey[y0:y1, x0:x1], best_t[y0:y1, x0:x1]
+        sub_g[ok] = g * shade
+        sub_t[ok] = t[ok]
     depth = np.where(np.isfinite(best_t), best_t, 0.0)           # z along the optical axis == t
     depth = np.round(depth * 5000.0) / 5000.0                     # TUM quantisation
     depth[depth > 8.0] = 0.0
@@ -115,7 +153,7 @@ def sequence(n_frames, seed=0, fps=30.0, w=640, h=480, n_unique=None):
     """Frames of a synthetic sequence: returns (gray [n,h,w] u8, depth [n,h,w] f32, poses [n,4,4]).
     With n_unique < n_frames only n_unique camera poses are ray-cast; the remaining frames reuse the
     geometry of frame (i mod n_unique) with fresh sensor noise and holes (cheap to generate, still
-    distinct inputs)."""
+    distinct inputs).  The pose index ping-pongs (0..nu-1..0..) so frame i and i+1 are always adjacent."""
     scene = make_scene(seed)
     nu = n_frames if n_unique is None else min(n_unique, n_frames)
     gray = np.zeros((n_frames, h, w), np.uint8)
@@ -127,7 +165,11 @@ def sequence(n_frames, seed=0, fps=30.0, w=640, h=480, n_unique=None):
         g, d = render(scene, T, w=w, h=h, noise_seed=seed * 100003 + i, noise_sigma=0.0, hole_frac=0.0)
         clean.append((g, d, T))
     for i in range(n_frames):
-        g, d, T = clean[i % nu]
+        # ping-pong over the ray-cast poses so that consecutive frames are always neighbours in time
+        j = i % (2 * nu - 2) if nu > 1 else 0
+        if j >= nu:
+            j = 2 * nu - 2 - j
+        g, d, T = clean[j]
         rng = np.random.default_rng(seed * 7919 + i)
         gi = np.clip(np.rint(g.astype(np.float64) + rng.normal(0.0, 2.0, g.shape)), 0, 255).astype(np.uint8)
         di = d.copy()
