@@ -292,6 +292,7 @@ static int alloc_lsd(lf_ctx *c) {
   ALLOC(c, c->d_frame_ids, B);
   ALLOC(c, fb.cand_flag, B * fc.cand_cap);
   ALLOC(c, fb.cand_out, B * (size_t)fc.cand_cap * LF_CAND_STRIDE);
+  ALLOC(c, fb.pts, B * (size_t)fc.cand_cap * LF_MAX_SAMPLES * 3);
   ALLOC(c, fb.recs, B * (size_t)fc.line_cap);
   ALLOC(c, fb.nlines, B);
   fb.frame_ids = c->d_frame_ids;

@@ -29,6 +29,7 @@ struct FrontBuffers {
   const uint64_t *frame_ids; // [B]  keys of the counter-based generator
   int *cand_flag;            // [B][cand_cap]: 0 short, 1 no depth, 2 3D line
   double *cand_out;          // [B][cand_cap][LF_CAND_STRIDE]
+  double *pts;               // [B][cand_cap][LF_MAX_SAMPLES*3] supporting points of each RANSAC line
   lf_line_record *recs;      // [B][line_cap]
   int *nlines;               // [B]  (may exceed line_cap: overflow)
 };

@@ -8,8 +8,9 @@
 //                  compPt3dCov + RandomPoint3d ctor           utils.cpp:671-722, lineslam.h:59-81
 //                  extract3dline_mahdist (RANSAC)             utils.cpp:343-427 (+570-624, 471-493)
 //                  acceptance                                 lineslam.cpp:302-307
-//                  MLEstimateLine3d (dlevmar_dif) + covariance utils.cpp:954-1050, 1086-1159
-//   k_records    ordered compaction into `lines` (+lid, complineEq2d, rndA/rndB)  lineslam.cpp:332-341
+//   k_records    ordered compaction into `lines` (+lid, complineEq2d)              lineslam.cpp:332-341
+//   k_mle        ONE WAVEFRONT PER 3D LINE: MLEstimateLine3d (dlevmar_dif) + covariance + rndA/rndB
+//                utils.cpp:954-1050, 1086-1159, external/levmar-2.6/lm_core.c:438-846
 //   k_describe   ONE WAVEFRONT PER 3D LINE: getGradient (lineslam.cpp:527-537) and computeMSLD
 //                (utils.cpp:1510-1610)
 //
@@ -137,10 +138,7 @@ __device__ __forceinline__ u64 f_or64(u64 v) {
 struct L3State {          // LDS of one wavefront
   double pos[LF_MAX_SAMPLES * 3];
   double DU[LF_MAX_SAMPLES * 9];
-  double jac[LF_MAX_SAMPLES * 6];
-  double hx[LF_MAX_SAMPLES], e[LF_MAX_SAMPLES], wrk[LF_MAX_SAMPLES], wrk2[LF_MAX_SAMPLES];
   int idx[LF_MAX_SAMPLES];
-  int sup[LF_MAX_SAMPLES];
 };
 
 // inlier masks of all points against the line (q1,q2); points lane and lane+64
@@ -247,31 +245,6 @@ __device__ void f_line3d_svd(const L3State &S, u64 m0, u64 m1, int n, double *me
   for (int k = 0; k < 3; k++) drct[k] = V[3 * k + 0];
 }
 
-// costFun_MLEstimateLine3d (utils.cpp:954-978): residuals of support points lane and lane+64
-__device__ __forceinline__ void f_mle_cost(const L3State &S, int n, int e1, int e2, const double *ci1,
-                                           const double *ci2, const double *p, double *out) {
-  int lane = f_lane();
-  for (int h = 0; h < 2; h++) {
-    int i = lane + 64 * h;
-    if (i < n) {
-      int pi = S.sup[i];
-      double r;
-      if (i == e1 || i == e2) {
-        const double *ci = (i == e1) ? ci1 : ci2;
-        const double *e = (i == e1) ? p : p + 3;
-        double v[3], t[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) v[k] = e[k] - S.pos[3 * pi + k];
-#pragma unroll
-        for (int k = 0; k < 3; k++) t[k] = v[0] * ci[0 * 3 + k] + v[1] * ci[1 * 3 + k] + v[2] * ci[2 * 3 + k];
-        r = t[0] * v[0] + t[1] * v[1] + t[2] * v[2];
-      } else
-        r = f_mah(&S.pos[3 * pi], &S.DU[9 * pi], p, p + 3);
-      out[i] = r;
-    }
-  }
-}
-
 // jac_rpt2ln_mahvec_wrt_ln (utils.cpp:1086-1116), closed form (see oracle/front_oracle.c o_jac_line)
 __device__ __forceinline__ void f_jac_line(const double *pos, const double *M, const double *l, double *J) {
   double a[3], b[3], d[3];
@@ -294,142 +267,6 @@ __device__ __forceinline__ void f_jac_line(const double *pos, const double *M, c
       J[r * 6 + 3 + j] = ma * d[r] / D + Mrj * Sd / D - 2.0 * Sd * md * d[r] / (D * D);
     }
   }
-}
-
-// dlevmar_dif (external/levmar-2.6/lm_core.c:438-846) for m = 6, x = 0, restated for one wavefront.
-// Residuals/Jacobian rows live in LDS; J^T J and J^T e use one accumulator per lane that walks
-// l = n-1 .. 0 exactly as lm_core.c:581-591.
-__device__ int f_levmar6(L3State &S, int n, int e1, int e2, const double *ci1, const double *ci2, double *p,
-                         int itmax, int *stop_out) {
-  const int m = 6, lane = f_lane();
-  const double tau = 1E-03, eps1 = 1E-10, eps2 = 1E-20, eps2_sq = 1E-20 * 1E-20, eps3 = 1E-20, delta = 1E-06;
-  double jacTe[6], jacTjac[36], Dp[6], diag[6], pDp[6];
-  double mu = 0, tmp, p_eL2, jacTe_inf = 0, pDp_eL2, p_L2 = 0, Dp_L2 = DBL_MAX, dF, dL;
-  int nu, nu2, stop = 0, K = 10, updjac = 0, updp = 1, newjac = 0, k;
-  // accumulator ownership: lanes 0..20 lower triangle (i,j), lanes 21..26 J^T e
-  int ai = 0, aj = 0;
-  if (lane < 21) { int a = lane; while ((ai + 1) * (ai + 2) / 2 <= a) ai++; aj = a - ai * (ai + 1) / 2; }
-  else if (lane < 27) { ai = lane - 21; aj = -1; }
-  f_mle_cost(S, n, e1, e2, ci1, ci2, p, S.hx);
-  f_sync();
-  p_eL2 = 0.0;
-  for (int i = lane; i < n; i += 64) S.e[i] = 0.0 - S.hx[i];
-  f_sync();
-  for (int i = 0; i < n; ++i) { tmp = S.e[i]; p_eL2 += tmp * tmp; }
-  if (!(lf_fabs(p_eL2) <= DBL_MAX)) stop = 7;
-  nu = 20;
-  for (k = 0; k < itmax && !stop; ++k) {
-    if (p_eL2 <= eps3) { stop = 6; break; }
-    if ((updp && nu > 16) || updjac == K) {
-      for (int j = 0; j < m; ++j) {           // forward differences (misc_core.c:137-171)
-        double d = 1E-04 * p[j], t;
-        d = lf_fabs(d);
-        if (d < delta) d = delta;
-        t = p[j]; p[j] += d;
-        f_mle_cost(S, n, e1, e2, ci1, ci2, p, S.wrk);
-        p[j] = t;
-        d = 1.0 / d;
-        f_sync();
-        for (int i = lane; i < n; i += 64) S.jac[i * m + j] = (S.wrk[i] - S.hx[i]) * d;
-      }
-      f_sync();
-      nu = 2; updjac = 0; updp = 0; newjac = 1;
-    }
-    if (newjac) {
-      newjac = 0;
-      double acc = 0.0;
-      if (lane < 27)
-        for (int l = n; l-- > 0;) {
-          double alpha = S.jac[l * m + ai];
-          acc += (aj >= 0) ? S.jac[l * m + aj] * alpha : alpha * S.e[l];
-        }
-#pragma unroll
-      for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = 0; j <= i; j++) { double v = f_rl64(acc, i * (i + 1) / 2 + j); jacTjac[i * m + j] = v; jacTjac[j * m + i] = v; }
-#pragma unroll
-      for (int i = 0; i < 6; i++) jacTe[i] = f_rl64(acc, 21 + i);
-      p_L2 = jacTe_inf = 0.0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        if (jacTe_inf < (tmp = lf_fabs(jacTe[i]))) jacTe_inf = tmp;
-        diag[i] = jacTjac[i * m + i];
-        p_L2 += p[i] * p[i];
-      }
-    }
-    if (jacTe_inf <= eps1) { Dp_L2 = 0.0; stop = 1; break; }
-    if (k == 0) {
-      tmp = DBL_MIN;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) if (diag[i] > tmp) tmp = diag[i];
-      mu = tau * tmp;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) jacTjac[i * m + i] += mu;
-    int issolved;
-    {
-      double A[36], Bv[6];
-#pragma unroll
-      for (int i = 0; i < 36; i++) A[i] = jacTjac[i];
-#pragma unroll
-      for (int i = 0; i < 6; i++) Bv[i] = jacTe[i];
-      issolved = lf_solve6(A, Bv, 1);
-#pragma unroll
-      for (int i = 0; i < 6; i++) Dp[i] = Bv[i];
-    }
-    if (issolved) {
-      Dp_L2 = 0.0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { pDp[i] = p[i] + (tmp = Dp[i]); Dp_L2 += tmp * tmp; }
-      if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
-      if (Dp_L2 >= (p_L2 + eps2) / (1E-12 * 1E-12)) { stop = 4; break; }
-      f_mle_cost(S, n, e1, e2, ci1, ci2, pDp, S.wrk);
-      f_sync();
-      for (int i = lane; i < n; i += 64) S.wrk2[i] = 0.0 - S.wrk[i];
-      f_sync();
-      pDp_eL2 = 0.0;
-      for (int i = 0; i < n; ++i) { tmp = S.wrk2[i]; pDp_eL2 += tmp * tmp; }
-      if (!(lf_fabs(pDp_eL2) <= DBL_MAX)) { stop = 7; break; }
-      dF = p_eL2 - pDp_eL2;
-      if (updp || dF > 0) {                       // Broyden rank-one update, row-parallel
-        for (int i = lane; i < n; i += 64) {
-          double t2 = 0.0;
-#pragma unroll
-          for (int l = 0; l < 6; ++l) t2 += S.jac[i * m + l] * Dp[l];
-          t2 = (S.wrk[i] - S.hx[i] - t2) / Dp_L2;
-#pragma unroll
-          for (int j = 0; j < 6; ++j) S.jac[i * m + j] += t2 * Dp[j];
-        }
-        f_sync();
-        ++updjac; newjac = 1;
-      }
-      dL = 0.0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) dL += Dp[i] * (mu * Dp[i] + jacTe[i]);
-      if (dL > 0.0 && dF > 0.0) {
-        tmp = (2.0 * dF / dL - 1.0);
-        tmp = 1.0 - tmp * tmp * tmp;
-        mu = mu * ((tmp >= 0.3333333334) ? tmp : 0.3333333334);
-        nu = 2;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) p[i] = pDp[i];
-        for (int i = lane; i < n; i += 64) { S.e[i] = S.wrk2[i]; S.hx[i] = S.wrk[i]; }
-        f_sync();
-        p_eL2 = pDp_eL2;
-        updp = 1;
-        continue;
-      }
-    }
-    mu *= nu;
-    nu2 = nu << 1;
-    if (nu2 <= nu) { stop = 5; break; }
-    nu = nu2;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) jacTjac[i * m + i] = diag[i];
-  }
-  if (k >= itmax) stop = 3;
-  *stop_out = stop;
-  return (stop != 4 && stop != 7) ? k : -1;
 }
 
 __global__ void __launch_bounds__(64) k_line3d(FrontConsts c, FrontBuffers b) {
@@ -577,89 +414,16 @@ __global__ void __launch_bounds__(64) k_line3d(FrontConsts c, FrontBuffers b) {
   bool have = (nbest / numSmp > P.ratio_of_collinear_pts) &&
               (lf_sqrt((LA[0] - LB[0]) * (LA[0] - LB[0]) + (LA[1] - LB[1]) * (LA[1] - LB[1]) + (LA[2] - LB[2]) * (LA[2] - LB[2])) > P.line3d_length_thresh);
   if (!have) { if (lane == 0) *flag = 1; return; }                                          // lineslam.cpp:302-307
-  // ---- MLEstimateLine3d (utils.cpp:980-1050) on the supporting points, in list order
+  // ---- hand the supporting points (line.pts, in list order) to the MLE kernel
   {
+    double *pts = b.pts + ((size_t)f * c.cand_cap + cand) * (LF_MAX_SAMPLES * 3);
     bool in0 = (best0 >> lane) & 1ull, in1 = (best1 >> lane) & 1ull;
-    if (in0) S.sup[__popcll(best0 & f_lt())] = lane;
-    if (in1) S.sup[__popcll(best0) + __popcll(best1 & f_lt())] = lane + 64;
-  }
-  f_sync();
-  const int ns = nbest;
-  int e1, e2;
-  {
-    double AmB[3] = {LA[0] - LB[0], LA[1] - LB[1], LA[2] - LB[2]};
-    double vmin = 100.0, vmax = -100.0;
-    int imin = 1 << 30, imax = 1 << 30;
-    for (int h = 0; h < 2; h++) {
-      int i = lane + 64 * h;
-      if (i < ns) {
-        const double *x = &S.pos[3 * S.sup[i]];
-        double dp = (x[0] - LA[0]) * AmB[0] + (x[1] - LA[1]) * AmB[1] + (x[2] - LA[2]) * AmB[2];
-        if (dp < vmin) { vmin = dp; imin = i; }
-        if (dp > vmax) { vmax = dp; imax = i; }
-      }
-    }
-    f_argmin(vmin, imin);
-    f_argmax(vmax, imax);
-    e1 = (imin == (1 << 30)) ? 0 : imin;
-    e2 = (imax == (1 << 30)) ? 0 : imax;
-    if (e1 > e2) { int t = e1; e1 = e2; e2 = t; }
-  }
-  double ci1[9], ci2[9], para[6];
-  {
-    double cov[9];
-    f_pt_cov(&S.pos[3 * S.sup[e1]], c.K[0], P, cov);
-    lf_inv3(cov, ci1);
-    f_pt_cov(&S.pos[3 * S.sup[e2]], c.K[0], P, cov);
-    lf_inv3(cov, ci2);
-#pragma unroll
-    for (int k = 0; k < 3; k++) { para[k] = S.pos[3 * S.sup[e1] + k]; para[3 + k] = S.pos[3 * S.sup[e2] + k]; }
-  }
-  int stop = 0;
-  int nit = f_levmar6(S, ns, e1, e2, ci1, ci2, para, P.line3d_mle_iter_num, &stop);
-  // ---- MleLine3dCov (utils.cpp:1138-1159): H = J^T J in point order, cov = H^-1
-  double H[36], I6[36];
-#pragma unroll
-  for (int i = 0; i < 36; i++) H[i] = 0;
-  for (int i = 0; i < ns; ++i) {
-    double J[18];
-    int pi = S.sup[i];
-#pragma unroll
-    for (int k = 0; k < 18; k++) J[k] = 0;
-    if (i == e1) {
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) J[r * 6 + k] = -S.DU[9 * pi + 3 * r + k];
-    } else if (i == e2) {
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) J[r * 6 + 3 + k] = -S.DU[9 * pi + 3 * r + k];
-    } else
-      f_jac_line(&S.pos[3 * pi], &S.DU[9 * pi], para, J);
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int k = 0; k < 6; k++)
-#pragma unroll
-        for (int l = 0; l < 6; l++) H[k * 6 + l] += J[r * 6 + k] * J[r * 6 + l];
-  }
-#pragma unroll
-  for (int i = 0; i < 36; i++) I6[i] = (i % 7 == 0) ? 1.0 : 0.0;
-  if (!lf_solve6(H, I6, 6)) {
-#pragma unroll
-    for (int i = 0; i < 36; i++) I6[i] = lf_from_bits(0x7ff8000000000000ULL);
+    if (in0) { int r = __popcll(best0 & f_lt()); for (int k = 0; k < 3; k++) pts[3 * r + k] = S.pos[3 * lane + k]; }
+    if (in1) { int r = __popcll(best0) + __popcll(best1 & f_lt()); for (int k = 0; k < 3; k++) pts[3 * r + k] = S.pos[3 * (lane + 64) + k]; }
   }
   if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) { out[k] = para[k]; out[3 + k] = para[3 + k]; }
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) { out[6 + 3 * r + k] = I6[r * 6 + k]; out[15 + 3 * r + k] = I6[(r + 3) * 6 + 3 + k]; }
-    out[27] = (double)nit;
-    out[28] = (double)stop;
+    for (int k = 0; k < 3; k++) { out[k] = LA[k]; out[3 + k] = LB[k]; }
     *flag = 2;
   }
 }
@@ -681,7 +445,6 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
     if (have && lid < c.line_cap) {
       lf_line_record *R = &recs[lid];
       const double *sg = b.segs + ((size_t)f * c.seg_cap + s) * 5;
-      const double *o = b.cand_out + ((size_t)f * c.cand_cap + s) * LF_CAND_STRIDE;
       double p0 = sg[0], p1 = sg[1], q0 = sg[2], q1 = sg[3];
       R->p[0] = p0; R->p[1] = p1; R->q[0] = q0; R->q[1] = q1;
       // complineEq2d (lineslam.h:139-150)
@@ -689,22 +452,293 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
       double nn = lf_sqrt(l0 * l0 + l1 * l1);
       R->lineEq2d[0] = l0 / nn; R->lineEq2d[1] = l1 / nn; R->lineEq2d[2] = l2 / nn;
       R->r[0] = 0; R->r[1] = 0;
-      for (int k = 0; k < 3; k++) { R->A[k] = o[k]; R->B[k] = o[3 + k]; }
-      double cov[9], DU[9], Wsq[3];
-      for (int k = 0; k < 9; k++) { cov[k] = o[6 + k]; R->covA[k] = cov[k]; }
-      f_whiten(cov, DU, Wsq);
-      for (int k = 0; k < 9; k++) R->DUa[k] = DU[k];
-      for (int k = 0; k < 3; k++) R->Wsa[k] = Wsq[k];
-      for (int k = 0; k < 9; k++) { cov[k] = o[15 + k]; R->covB[k] = cov[k]; }
-      f_whiten(cov, DU, Wsq);
-      for (int k = 0; k < 9; k++) R->DUb[k] = DU[k];
-      for (int k = 0; k < 3; k++) R->Wsb[k] = Wsq[k];
       R->lid = lid;
       R->seg = s;
     }
     base += __popcll(m);
   }
   if (lane == 0) b.nlines[f] = base;
+}
+
+// ----------------------------------------------------------------------------------------------
+// MLEstimateLine3d + MleLine3dCov (utils.cpp:954-1050, 1086-1159): ONE WAVEFRONT PER 3D LINE.
+// Supporting points live in LDS (one or two per lane); residuals and Jacobian rows are evaluated
+// lane-parallel; J^T J / J^T e use one accumulator per lane walking the rows in levmar's order.
+#define MLE_N 104
+struct MState {
+  double pos[MLE_N * 3];
+  double DU[MLE_N * 9];
+  double jac[MLE_N * 6];
+  double hx[MLE_N], e[MLE_N], wrk[MLE_N], wrk2[MLE_N];
+};
+
+// costFun_MLEstimateLine3d (utils.cpp:954-978): residuals of support points lane and lane+64
+__device__ __forceinline__ void f_mle_cost(const MState &S, int n, int e1, int e2, const double *ci1,
+                                           const double *ci2, const double *p, double *out) {
+  int lane = f_lane();
+  for (int h = 0; h < 2; h++) {
+    int i = lane + 64 * h;
+    if (i < n) {
+      int pi = i;
+      double r;
+      if (i == e1 || i == e2) {
+        const double *ci = (i == e1) ? ci1 : ci2;
+        const double *e = (i == e1) ? p : p + 3;
+        double v[3], t[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] = e[k] - S.pos[3 * pi + k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) t[k] = v[0] * ci[0 * 3 + k] + v[1] * ci[1 * 3 + k] + v[2] * ci[2 * 3 + k];
+        r = t[0] * v[0] + t[1] * v[1] + t[2] * v[2];
+      } else
+        r = f_mah(&S.pos[3 * pi], &S.DU[9 * pi], p, p + 3);
+      out[i] = r;
+    }
+  }
+}
+
+// dlevmar_dif (external/levmar-2.6/lm_core.c:438-846) for m = 6, x = 0, restated for one wavefront.
+// Residuals/Jacobian rows live in LDS; J^T J and J^T e use one accumulator per lane that walks
+// l = n-1 .. 0 exactly as lm_core.c:581-591.
+__device__ int f_levmar6(MState &S, int n, int e1, int e2, const double *ci1, const double *ci2, double *p,
+                         int itmax, int *stop_out) {
+  const int m = 6, lane = f_lane();
+  const double tau = 1E-03, eps1 = 1E-10, eps2 = 1E-20, eps2_sq = 1E-20 * 1E-20, eps3 = 1E-20, delta = 1E-06;
+  double jacTe[6], jacTjac[36], Dp[6], diag[6], pDp[6];
+  double mu = 0, tmp, p_eL2, jacTe_inf = 0, pDp_eL2, p_L2 = 0, Dp_L2 = DBL_MAX, dF, dL;
+  int nu, nu2, stop = 0, K = 10, updjac = 0, updp = 1, newjac = 0, k;
+  // accumulator ownership: lanes 0..20 lower triangle (i,j), lanes 21..26 J^T e
+  int ai = 0, aj = 0;
+  if (lane < 21) { int a = lane; while ((ai + 1) * (ai + 2) / 2 <= a) ai++; aj = a - ai * (ai + 1) / 2; }
+  else if (lane < 27) { ai = lane - 21; aj = -1; }
+  f_mle_cost(S, n, e1, e2, ci1, ci2, p, S.hx);
+  f_sync();
+  p_eL2 = 0.0;
+  for (int i = lane; i < n; i += 64) S.e[i] = 0.0 - S.hx[i];
+  f_sync();
+  for (int i = 0; i < n; ++i) { tmp = S.e[i]; p_eL2 += tmp * tmp; }
+  if (!(lf_fabs(p_eL2) <= DBL_MAX)) stop = 7;
+  nu = 20;
+  for (k = 0; k < itmax && !stop; ++k) {
+    if (p_eL2 <= eps3) { stop = 6; break; }
+    if ((updp && nu > 16) || updjac == K) {
+      for (int j = 0; j < m; ++j) {           // forward differences (misc_core.c:137-171)
+        double d = 1E-04 * p[j], t;
+        d = lf_fabs(d);
+        if (d < delta) d = delta;
+        t = p[j]; p[j] += d;
+        f_mle_cost(S, n, e1, e2, ci1, ci2, p, S.wrk);
+        p[j] = t;
+        d = 1.0 / d;
+        f_sync();
+        for (int i = lane; i < n; i += 64) S.jac[i * m + j] = (S.wrk[i] - S.hx[i]) * d;
+      }
+      f_sync();
+      nu = 2; updjac = 0; updp = 0; newjac = 1;
+    }
+    if (newjac) {
+      newjac = 0;
+      double acc = 0.0;
+      if (lane < 27)
+        for (int l = n; l-- > 0;) {
+          double alpha = S.jac[l * m + ai];
+          acc += (aj >= 0) ? S.jac[l * m + aj] * alpha : alpha * S.e[l];
+        }
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) { double v = f_rl64(acc, i * (i + 1) / 2 + j); jacTjac[i * m + j] = v; jacTjac[j * m + i] = v; }
+#pragma unroll
+      for (int i = 0; i < 6; i++) jacTe[i] = f_rl64(acc, 21 + i);
+      p_L2 = jacTe_inf = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        if (jacTe_inf < (tmp = lf_fabs(jacTe[i]))) jacTe_inf = tmp;
+        diag[i] = jacTjac[i * m + i];
+        p_L2 += p[i] * p[i];
+      }
+    }
+    if (jacTe_inf <= eps1) { Dp_L2 = 0.0; stop = 1; break; }
+    if (k == 0) {
+      tmp = DBL_MIN;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) if (diag[i] > tmp) tmp = diag[i];
+      mu = tau * tmp;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) jacTjac[i * m + i] += mu;
+    int issolved;
+    {
+      double A[36], Bv[6];
+#pragma unroll
+      for (int i = 0; i < 36; i++) A[i] = jacTjac[i];
+#pragma unroll
+      for (int i = 0; i < 6; i++) Bv[i] = jacTe[i];
+      issolved = lf_solve6(A, Bv, 1);
+#pragma unroll
+      for (int i = 0; i < 6; i++) Dp[i] = Bv[i];
+    }
+    if (issolved) {
+      Dp_L2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { pDp[i] = p[i] + (tmp = Dp[i]); Dp_L2 += tmp * tmp; }
+      if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
+      if (Dp_L2 >= (p_L2 + eps2) / (1E-12 * 1E-12)) { stop = 4; break; }
+      f_mle_cost(S, n, e1, e2, ci1, ci2, pDp, S.wrk);
+      f_sync();
+      for (int i = lane; i < n; i += 64) S.wrk2[i] = 0.0 - S.wrk[i];
+      f_sync();
+      pDp_eL2 = 0.0;
+      for (int i = 0; i < n; ++i) { tmp = S.wrk2[i]; pDp_eL2 += tmp * tmp; }
+      if (!(lf_fabs(pDp_eL2) <= DBL_MAX)) { stop = 7; break; }
+      dF = p_eL2 - pDp_eL2;
+      if (updp || dF > 0) {                       // Broyden rank-one update, row-parallel
+        for (int i = lane; i < n; i += 64) {
+          double t2 = 0.0;
+#pragma unroll
+          for (int l = 0; l < 6; ++l) t2 += S.jac[i * m + l] * Dp[l];
+          t2 = (S.wrk[i] - S.hx[i] - t2) / Dp_L2;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) S.jac[i * m + j] += t2 * Dp[j];
+        }
+        f_sync();
+        ++updjac; newjac = 1;
+      }
+      dL = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dL += Dp[i] * (mu * Dp[i] + jacTe[i]);
+      if (dL > 0.0 && dF > 0.0) {
+        tmp = (2.0 * dF / dL - 1.0);
+        tmp = 1.0 - tmp * tmp * tmp;
+        mu = mu * ((tmp >= 0.3333333334) ? tmp : 0.3333333334);
+        nu = 2;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) p[i] = pDp[i];
+        for (int i = lane; i < n; i += 64) { S.e[i] = S.wrk2[i]; S.hx[i] = S.wrk[i]; }
+        f_sync();
+        p_eL2 = pDp_eL2;
+        updp = 1;
+        continue;
+      }
+    }
+    mu *= nu;
+    nu2 = nu << 1;
+    if (nu2 <= nu) { stop = 5; break; }
+    nu = nu2;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) jacTjac[i * m + i] = diag[i];
+  }
+  if (k >= itmax) stop = 3;
+  *stop_out = stop;
+  return (stop != 4 && stop != 7) ? k : -1;
+}
+
+__global__ void __launch_bounds__(64) k_mle(FrontConsts c, FrontBuffers b) {
+  __shared__ MState S;
+  const int f = blockIdx.y, lane = f_lane(), lid = blockIdx.x;
+  int nl = b.nlines[f];
+  if (nl > c.line_cap) nl = c.line_cap;
+  if (lid >= nl) return;
+  const lf_params &P = c.P;
+  lf_line_record *R = b.recs + (size_t)f * c.line_cap + lid;
+  const int seg = R->seg;
+  double *out = b.cand_out + ((size_t)f * c.cand_cap + seg) * LF_CAND_STRIDE;
+  const double *pts = b.pts + ((size_t)f * c.cand_cap + seg) * (LF_MAX_SAMPLES * 3);
+  int ns = (int)out[26];
+  if (ns > MLE_N) ns = MLE_N;
+  double LA[3] = {out[0], out[1], out[2]}, LB[3] = {out[3], out[4], out[5]};
+  for (int i = lane; i < ns; i += 64) {
+    double pos[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, cov[9], DU[9], Wsq[3];
+    f_pt_cov(pos, c.K[0], P, cov);
+    f_whiten(cov, DU, Wsq);
+#pragma unroll
+    for (int k = 0; k < 3; k++) S.pos[3 * i + k] = pos[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) S.DU[9 * i + k] = DU[k];
+  }
+  f_sync();
+  int e1, e2;
+  {   // extremities along the line (utils.cpp:985-999), first occurrence on ties
+    double AmB[3] = {LA[0] - LB[0], LA[1] - LB[1], LA[2] - LB[2]};
+    double vmin = 100.0, vmax = -100.0;
+    int imin = 1 << 30, imax = 1 << 30;
+    for (int h = 0; h < 2; h++) {
+      int i = lane + 64 * h;
+      if (i < ns) {
+        const double *x = &S.pos[3 * i];
+        double dp = (x[0] - LA[0]) * AmB[0] + (x[1] - LA[1]) * AmB[1] + (x[2] - LA[2]) * AmB[2];
+        if (dp < vmin) { vmin = dp; imin = i; }
+        if (dp > vmax) { vmax = dp; imax = i; }
+      }
+    }
+    f_argmin(vmin, imin);
+    f_argmax(vmax, imax);
+    e1 = (imin == (1 << 30)) ? 0 : imin;
+    e2 = (imax == (1 << 30)) ? 0 : imax;
+    if (e1 > e2) { int t = e1; e1 = e2; e2 = t; }
+  }
+  double ci1[9], ci2[9], para[6];
+  {
+    double cov[9];
+    f_pt_cov(&S.pos[3 * e1], c.K[0], P, cov);
+    lf_inv3(cov, ci1);
+    f_pt_cov(&S.pos[3 * e2], c.K[0], P, cov);
+    lf_inv3(cov, ci2);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { para[k] = S.pos[3 * e1 + k]; para[3 + k] = S.pos[3 * e2 + k]; }
+  }
+  int stop = 0;
+  int nit = f_levmar6(S, ns, e1, e2, ci1, ci2, para, P.line3d_mle_iter_num, &stop);
+  // ---- MleLine3dCov (utils.cpp:1138-1159): H = J^T J in point order, cov = H^-1
+  double H[36], I6[36];
+#pragma unroll
+  for (int i = 0; i < 36; i++) H[i] = 0;
+  for (int i = 0; i < ns; ++i) {
+    double J[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) J[k] = 0;
+    if (i == e1) {
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) J[r * 6 + k] = -S.DU[9 * i + 3 * r + k];
+    } else if (i == e2) {
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) J[r * 6 + 3 + k] = -S.DU[9 * i + 3 * r + k];
+    } else
+      f_jac_line(&S.pos[3 * i], &S.DU[9 * i], para, J);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int k = 0; k < 6; k++)
+#pragma unroll
+        for (int l = 0; l < 6; l++) H[k * 6 + l] += J[r * 6 + k] * J[r * 6 + l];
+  }
+#pragma unroll
+  for (int i = 0; i < 36; i++) I6[i] = (i % 7 == 0) ? 1.0 : 0.0;
+  if (!lf_solve6(H, I6, 6)) {
+#pragma unroll
+    for (int i = 0; i < 36; i++) I6[i] = lf_from_bits(0x7ff8000000000000ULL);
+  }
+  // ---- results: line3d.A/B, covA/covB, rndA/rndB (RandomPoint3d ctor) into the record
+  if (lane == 0) {
+    double cov[9], DU[9], Wsq[3];
+    for (int q = 0; q < 3; q++) { R->A[q] = para[q]; R->B[q] = para[3 + q]; out[29 + q] = LA[q]; out[q] = para[q]; out[3 + q] = para[3 + q]; }
+    for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) cov[3 * r + q] = I6[r * 6 + q];
+    for (int q = 0; q < 9; q++) { R->covA[q] = cov[q]; out[6 + q] = cov[q]; }
+    f_whiten(cov, DU, Wsq);
+    for (int q = 0; q < 9; q++) R->DUa[q] = DU[q];
+    for (int q = 0; q < 3; q++) R->Wsa[q] = Wsq[q];
+    for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) cov[3 * r + q] = I6[(r + 3) * 6 + 3 + q];
+    for (int q = 0; q < 9; q++) { R->covB[q] = cov[q]; out[15 + q] = cov[q]; }
+    f_whiten(cov, DU, Wsq);
+    for (int q = 0; q < 9; q++) R->DUb[q] = DU[q];
+    for (int q = 0; q < 3; q++) R->Wsb[q] = Wsq[q];
+    out[27] = (double)nit;
+    out[28] = (double)stop;
+  }
 }
 
 // ------------------------------------------------------------------------------ getGradient + MSLD
@@ -857,5 +891,6 @@ void lf_front_launch(const FrontConsts &c, const FrontBuffers &b, int B, hipStre
   hipLaunchKernelGGL(k_sobel5, dim3((c.W + 255) / 256, c.H, B), dim3(256), 0, st, c, b);
   hipLaunchKernelGGL(k_line3d, dim3(c.cand_cap, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_records, dim3(B), dim3(64), 0, st, c, b);
+  hipLaunchKernelGGL(k_mle, dim3(c.line_cap, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_describe, dim3(c.line_cap, B), dim3(64), 0, st, c, b);
 }

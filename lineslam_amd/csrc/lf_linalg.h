@@ -102,6 +102,7 @@ LF_DEFINE_JACOBI(lf_jacobi4, 4)
 #define LF_DEFINE_SOLVE(NAME, N)                                                               \
   LF_HD int NAME(double *A, double *B, int m) {                                                \
     int i, j, k;                                                                               \
+    double rp[N];                         /* reciprocals of the pivots (one division each) */  \
     for (k = 0; k < N; k++) {                                                                  \
       int piv = k;                                                                             \
       double big = lf_fabs(A[k * N + k]);                                                      \
@@ -110,13 +111,15 @@ LF_DEFINE_JACOBI(lf_jacobi4, 4)
         if (v > big) { big = v; piv = i; }                                                     \
       }                                                                                        \
       if (!(big > 0.0)) return 0;                                                              \
-      for (i = k + 1; i < N; i++)            /* row swap with constant indices */              \
-        if (i == piv) {                                                                        \
-          for (j = 0; j < N; j++) { double t = A[k * N + j]; A[k * N + j] = A[i * N + j]; A[i * N + j] = t; } \
-          for (j = 0; j < m; j++) { double t = B[k * m + j]; B[k * m + j] = B[i * m + j]; B[i * m + j] = t; } \
-        }                                                                                      \
+      if (piv != k)                                                                            \
+        for (i = k + 1; i < N; i++)          /* row swap with constant indices */              \
+          if (i == piv) {                                                                      \
+            for (j = 0; j < N; j++) { double t = A[k * N + j]; A[k * N + j] = A[i * N + j]; A[i * N + j] = t; } \
+            for (j = 0; j < m; j++) { double t = B[k * m + j]; B[k * m + j] = B[i * m + j]; B[i * m + j] = t; } \
+          }                                                                                    \
+      rp[k] = 1.0 / A[k * N + k];                                                              \
       for (i = k + 1; i < N; i++) {                                                            \
-        double f = A[i * N + k] / A[k * N + k];                                                \
+        double f = A[i * N + k] * rp[k];                                                       \
         if (f != 0.0) {                                                                        \
           for (j = k + 1; j < N; j++) A[i * N + j] -= f * A[k * N + j];                        \
           for (j = 0; j < m; j++) B[i * m + j] -= f * B[k * m + j];                            \
@@ -128,7 +131,7 @@ LF_DEFINE_JACOBI(lf_jacobi4, 4)
       for (i = N - 1; i >= 0; i--) {                                                           \
         double s = B[i * m + j];                                                               \
         for (k = i + 1; k < N; k++) s -= A[i * N + k] * B[k * m + j];                          \
-        B[i * m + j] = s / A[i * N + i];                                                       \
+        B[i * m + j] = s * rp[i];                                                              \
       }                                                                                        \
     return 1;                                                                                  \
   }
