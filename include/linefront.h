@@ -228,6 +228,14 @@ LF_API int lf_match_external_device(lf_ctx *ctx, const int32_t *query_frames, co
                                     const int32_t *d_ext_nlines, const uint64_t *d_ext_ids, int ext_frames,
                                     int ext_line_cap);
 
+/* MatchingResult Node::matchNodePair(const Node* older_node) (src/node.h:107) for two nodes whose
+ * `lines` live in host memory: uploads both line maps into slots 0/1 of the context, runs
+ * lineMatching + RANSAC + LM, returns the flat MatchingResult.  Matches / inliers of the pair are
+ * then available as pair 0 (lf_pair_get_matches / lf_pair_get_inliers).  Needs max_batch >= 2. */
+LF_API int lf_match_node_pair(lf_ctx *ctx, const lf_line_record *newer, int n_newer, uint64_t id_newer,
+                              const lf_line_record *older, int n_older, uint64_t id_older,
+                              lf_pair_result *out);
+
 #ifdef __cplusplus
 }
 #endif

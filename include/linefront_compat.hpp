@@ -1,0 +1,120 @@
+// linefront_compat.hpp -- C++ host-side mirror of the reference's Node surface for the hot path, header
+// only, on top of the C ABI (linefront.h).  Same method names and argument meaning as
+//   src/node.h:107        MatchingResult matchNodePair(const Node* older_node);
+//   src/node.h:124-128    bool getRelativeTransformationTo(const Node*, std::vector<cv::DMatch>*, Eigen::Matrix4f&, float&, std::vector<cv::DMatch>&) const;
+//   src/node.h:286-288    void detect3DLines(...);  unsigned lineMatching(const Node*, bool, std::vector<cv::DMatch>*) const;
+// OpenCV / Eigen types are replaced by plain structs (cv::Mat -> pointer + stride, cv::DMatch -> lf::DMatch,
+// Eigen::Matrix4f -> float[16] row-major) so that this header has no dependency beyond the C ABI.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "linefront.h"
+
+namespace lf {
+
+struct DMatch { int queryIdx, trainIdx; float distance; };            // cv::DMatch
+typedef lf_line_record FrameLine;                                       // src/line/lineslam.h:113-151 (flat)
+
+struct LoadedEdge3D { int id1 = -1, id2 = -1; double transform[16]; double informationMatrix[36]; };   // src/edge.h:25-33
+struct MatchingResult {                                                 // src/matching_result.h:23-49 (line part)
+  std::vector<DMatch> all_line_matches, inlier_line_matches;
+  float rmse = 0.f;
+  float ransac_trafo[16], final_trafo[16];
+  LoadedEdge3D edge;
+};
+
+class Error : public std::runtime_error {
+ public:
+  int status;
+  Error(int s, const char* what) : std::runtime_error(std::string(what) + ": " + lf_status_str(s)), status(s) {}
+};
+inline void check(int s, const char* what) { if (s != LF_OK) throw Error(s, what); }
+
+// One context per image size / thread; replaces the globals `sysPara` and `K`.
+class Context {
+ public:
+  lf_ctx* h = nullptr;
+  lf_params params;
+  Context(int width, int height, int max_batch = 2, const lf_params* p = nullptr, int device = 0, void* stream = nullptr) {
+    if (p) params = *p; else lf_params_init(&params);
+    check(lf_ctx_create(&h, device, stream, width, height, max_batch, &params), "lf_ctx_create");
+  }
+  ~Context() { lf_ctx_destroy(h); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+};
+
+class Node {
+ public:
+  int id_ = 0;
+  std::vector<FrameLine> lines;     // src/node.h:280
+  Context* ctx = nullptr;
+
+  Node(Context* c, int id) : id_(id), ctx(c) {}
+
+  // Node::detect3DLines (src/line/lineslam.cpp:200-357)
+  void detect3DLines(const uint8_t* gray_uchar, int gray_stride, const float* depth_float, int depth_stride,
+                     int width, int height, double line2d_len_thres, const double K[9],
+                     double ratio_of_collinear_pts, double line_3d_len_thres_m, double depth_scaling,
+                     const std::string& algorithm) {
+    if (algorithm != "LSD") throw Error(LF_ERR_UNSUPPORTED, "detect3DLines: only \"LSD\" (EDLines is binary-only in the reference)");
+    lf_params p = ctx->params;
+    p.line_segment_len_thresh = line2d_len_thres; p.ratio_of_collinear_pts = ratio_of_collinear_pts;
+    p.line3d_length_thresh = line_3d_len_thres_m; p.depth_scaling = depth_scaling;
+    check(lf_ctx_set_params(ctx->h, &p), "lf_ctx_set_params");
+    lines.resize(512);
+    int n = 0;
+    int r = lf_detect3d(ctx->h, gray_uchar, gray_stride, depth_float, depth_stride, width, height, K,
+                        (uint64_t)id_, lines.data(), (int)lines.size(), &n);
+    if (r != LF_OK && r != LF_ERR_CAPACITY) throw Error(r, "lf_detect3d");
+    lines.resize(n < 512 ? n : 512);
+  }
+
+  // Node::matchNodePair (src/node.cpp:1494-1615): valid edge <=> mr.edge.id1 >= 0
+  MatchingResult matchNodePair(const Node* older_node) const {
+    MatchingResult mr;
+    lf_pair_result r;
+    check(lf_match_node_pair(ctx->h, lines.data(), (int)lines.size(), (uint64_t)id_, older_node->lines.data(),
+                             (int)older_node->lines.size(), (uint64_t)older_node->id_, &r), "lf_match_node_pair");
+    std::vector<int32_t> q(256), t(256), inl(256);
+    std::vector<double> d(256);
+    int n = 0, ni = 0;
+    int s = lf_pair_get_matches(ctx->h, 0, q.data(), t.data(), d.data(), 256, &n);
+    if (s != LF_OK && s != LF_ERR_CAPACITY) throw Error(s, "lf_pair_get_matches");
+    if (n > 256) n = 256;
+    for (int i = 0; i < n; i++) mr.all_line_matches.push_back({q[i], t[i], (float)d[i]});
+    check(lf_pair_get_inliers(ctx->h, 0, inl.data(), 256, &ni), "lf_pair_get_inliers");
+    for (int i = 0; i < ni; i++) mr.inlier_line_matches.push_back(mr.all_line_matches[inl[i]]);
+    mr.rmse = r.rmse;
+    for (int i = 0; i < 16; i++) { mr.ransac_trafo[i] = mr.final_trafo[i] = r.T[i]; mr.edge.transform[i] = r.T[i]; }
+    for (int i = 0; i < 36; i++) mr.edge.informationMatrix[i] = (i % 7 == 0 && r.valid) ? r.information_scale : 0.0;
+    mr.edge.id1 = r.valid ? r.id_older : -1;
+    mr.edge.id2 = r.valid ? r.id_newer : -1;
+    return mr;
+  }
+
+  // Node::lineMatching (src/node.cpp:1619-1694): appends to *matches, returns matches->size()
+  unsigned lineMatching(const Node* other, bool /*adjacentFrame: derived from the node ids as matchNodePair does*/,
+                        std::vector<DMatch>* matches) const {
+    MatchingResult mr = matchNodePair(other);
+    matches->insert(matches->end(), mr.all_line_matches.begin(), mr.all_line_matches.end());
+    return (unsigned)matches->size();
+  }
+
+  // Node::getRelativeTransformationTo (src/node.h:124-128): legacy point-RANSAC entry, routed to the same
+  // solver with the point-match list empty
+  bool getRelativeTransformationTo(const Node* target_node, std::vector<DMatch>* /*initial_matches*/,
+                                   float resulting_transformation[16], float& rmse, std::vector<DMatch>& matches) const {
+    MatchingResult mr = matchNodePair(target_node);
+    for (int i = 0; i < 16; i++) resulting_transformation[i] = mr.final_trafo[i];
+    rmse = mr.rmse;
+    matches = mr.inlier_line_matches;
+    return mr.edge.id1 >= 0;
+  }
+};
+
+}  // namespace lf

@@ -77,6 +77,7 @@ SYMBOLS = {
     "lf_get_stage_ms": (_i, [_vp, _i, C.POINTER(C.c_float)]),
     "lf_get_device_records": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _pi]),
     "lf_match_external_device": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i]),
+    "lf_match_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, C.c_uint64, _vp]),
 }
 
 
@@ -316,3 +317,11 @@ class Context:
         self._chk(lib().lf_match_external_device(self._h, q.ctypes.data, t.ctypes.data, len(q), _vp(ext_recs_ptr),
                                                  _vp(ext_nlines_ptr), _vp(ext_ids_ptr), ext_frames, ext_line_cap),
                   "lf_match_external_device")
+
+    def match_node_pair(self, newer_recs, id_newer, older_recs, id_older):
+        """Node::matchNodePair for two host-resident line maps; returns LfPairResult (pair slot 0)."""
+        a, b = np.ascontiguousarray(newer_recs), np.ascontiguousarray(older_recs)
+        r = LfPairResult()
+        self._chk(lib().lf_match_node_pair(self._h, a.ctypes.data, len(a), int(id_newer), b.ctypes.data, len(b),
+                                           int(id_older), C.byref(r)), "lf_match_node_pair")
+        return r

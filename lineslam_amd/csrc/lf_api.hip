@@ -681,4 +681,25 @@ int lf_get_stage_ms(lf_ctx *c, int which, float *ms) {
   return LF_OK;
 }
 
+// Node-level convenience: two frames whose line maps live in HOST memory (e.g. two lf::Node objects).
+int lf_match_node_pair(lf_ctx *c, const lf_line_record *newer, int n_newer, uint64_t id_newer,
+                       const lf_line_record *older, int n_older, uint64_t id_older, lf_pair_result *out) {
+  if (!c || !out || n_newer < 0 || n_older < 0 || (n_newer && !newer) || (n_older && !older)) return LF_ERR_INVALID;
+  if (c->maxB < 2) return LF_ERR_CAPACITY;
+  if (n_newer > c->fc.line_cap || n_older > c->fc.line_cap) return LF_ERR_CAPACITY;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t ids[2] = {id_newer, id_older};
+  const int nl[2] = {n_newer, n_older};
+  if (n_newer) HIPCHK(c, hipMemcpyAsync(c->fb.recs, newer, sizeof(lf_line_record) * (size_t)n_newer, hipMemcpyHostToDevice, c->stream));
+  if (n_older) HIPCHK(c, hipMemcpyAsync(c->fb.recs + c->fc.line_cap, older, sizeof(lf_line_record) * (size_t)n_older, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->fb.nlines, nl, sizeof nl, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_frame_ids, ids, sizeof ids, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->last_batch < 2) c->last_batch = 2;
+  const int32_t q = 0, t = 1;
+  int r = lf_match_pairs_device(c, &q, &t, 1);
+  if (r != LF_OK) return r;
+  return lf_pair_get_result(c, 0, out);
+}
+
 }  // extern "C"

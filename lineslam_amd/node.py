@@ -1,0 +1,93 @@
+"""Host-side mirror of the reference's `Node` surface for the hot path (src/node.h:107,124-128,280-288),
+implemented entirely on the C ABI (liblinefront.so -> HIP kernels).  Same method names and argument
+meaning as the reference so that the parity tests read like the reference's call sites:
+
+    Node(gray, depth, K, id)                 <-> Node::Node(...)  (runs detect3DLines, node.cpp:198-217)
+    node.detect3DLines(...)                  <-> Node::detect3DLines          (lineslam.cpp:200-357)
+    node.lineMatching(other, adjacent)       <-> Node::lineMatching           (node.cpp:1619-1694)
+    node.matchNodePair(older)                <-> Node::matchNodePair          (node.cpp:1494-1615)
+    node.getRelativeTransformationTo(older)  <-> Node::getRelativeTransformationTo (node.h:124-128): the
+        legacy point-RANSAC entry, routed to the same solver with the point-match list empty.
+"""
+import numpy as np
+
+from . import capi
+
+
+class MatchingResult:
+    """src/matching_result.h:23-49 (+ LoadedEdge3D, src/edge.h:25-33), line part."""
+
+    def __init__(self):
+        self.all_line_matches = []        # (queryIdx, trainIdx, distance)
+        self.inlier_line_matches = []
+        self.rmse = 0.0
+        self.ransac_trafo = np.eye(4, dtype=np.float32)
+        self.final_trafo = np.eye(4, dtype=np.float32)
+        self.edge_id1 = -1                # valid edge <=> id1 >= 0 (node.cpp:1606-1607)
+        self.edge_id2 = -1
+        self.edge_transform = np.eye(4)
+        self.edge_information = np.zeros((6, 6))
+
+
+class Node:
+    _shared_ctx = {}
+
+    def __init__(self, gray_uchar, depth_float, K, node_id, params=None, ctx=None):
+        self.id_ = int(node_id)
+        self.K = np.asarray(K, np.float64).reshape(3, 3)
+        self.params = params if params is not None else capi.default_params()
+        h, w = np.asarray(gray_uchar).shape
+        key = (w, h)
+        if ctx is None:
+            if key not in Node._shared_ctx:
+                Node._shared_ctx[key] = capi.Context(w, h, max_batch=2, params=self.params)
+            ctx = Node._shared_ctx[key]
+        self._ctx = ctx
+        self.lines = np.zeros(0, capi.REC_DTYPE)
+        self.detect3DLines(gray_uchar, depth_float, self.params.line_segment_len_thresh, self.K,
+                           self.params.ratio_of_collinear_pts, self.params.line3d_length_thresh,
+                           self.params.depth_scaling, "LSD")
+
+    def detect3DLines(self, gray_uchar, depth_float, line2d_len_thres, K, ratio_of_collinear_pts,
+                      line_3d_len_thres_m, depth_scaling, algorithm="LSD"):
+        if algorithm != "LSD":
+            raise capi.LinefrontError(capi.LF_ERR_UNSUPPORTED, "detect3DLines(algorithm=%r)" % algorithm)
+        p = self.params
+        p.line_segment_len_thresh, p.ratio_of_collinear_pts = line2d_len_thres, ratio_of_collinear_pts
+        p.line3d_length_thresh, p.depth_scaling = line_3d_len_thres_m, depth_scaling
+        self._ctx.set_params(p)
+        self.lines = self._ctx.detect3d(gray_uchar, depth_float, K, frame_id=self.id_)
+
+    def _pair(self, older):
+        p = self.params
+        self._ctx.set_params(p)
+        r = self._ctx.match_node_pair(self.lines, self.id_, older.lines, older.id_)
+        mq, mt, md = self._ctx.pair_matches(0)
+        inl = self._ctx.pair_inliers(0) if r.n_inliers else np.zeros(0, np.int32)
+        return r, mq, mt, md, inl
+
+    def lineMatching(self, other, adjacentFrame=None, matches=None):
+        """Appends (queryIdx, trainIdx, distance) to `matches`; returns the count (node.cpp:1619)."""
+        r, mq, mt, md, _ = self._pair(other)
+        out = matches if matches is not None else []
+        out.extend(zip(mq.tolist(), mt.tolist(), md.tolist()))
+        return len(out)
+
+    def matchNodePair(self, older_node):
+        r, mq, mt, md, inl = self._pair(older_node)
+        mr = MatchingResult()
+        mr.all_line_matches = list(zip(mq.tolist(), mt.tolist(), md.tolist()))
+        mr.inlier_line_matches = [mr.all_line_matches[i] for i in inl.tolist()]
+        mr.rmse = float(r.rmse)
+        if r.valid:
+            T = np.array(list(r.T), np.float32).reshape(4, 4)
+            mr.ransac_trafo = mr.final_trafo = T
+            mr.edge_id1, mr.edge_id2 = r.id_older, r.id_newer
+            mr.edge_transform = T.astype(np.float64)
+            mr.edge_information = np.eye(6) * r.information_scale
+        return mr
+
+    def getRelativeTransformationTo(self, target_node, initial_matches=None):
+        """(found, transformation, rmse, inlier matches) -- node.h:124-128."""
+        mr = self.matchNodePair(target_node)
+        return mr.edge_id1 >= 0, mr.final_trafo, mr.rmse, mr.inlier_line_matches
