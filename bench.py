@@ -31,7 +31,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_FRAME = 25_128_960 + 253 * 1040     # SURVEY.md section 8(d) + ~253 output records
+ALGO_BYTES_PER_FRAME = 25_128_960 + 200 * 1040     # compulsory traffic + ~0.2 MB of output records
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--keyframes", type=int, default=32, help="keyframes per rank exchanged by the all-gather")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--launch-params", action="store_true", help="launch/lineslam.launch overrides (ang_th 40)")
+    ap.add_argument("--default-params", action="store_true",
+                    help="ParameterServer defaults (lsd_angle_thres 22.5, min_matches 20) instead of the shipped "
+                         "launch/lineslam.launch values (40, 10), which are what the reference actually runs with")
     return ap.parse_args()
 
 
@@ -96,7 +98,7 @@ def main():
         build.build()
     if world > 1:
         dist.barrier()
-    P = capi.default_params(launch=a.launch_params)
+    P = capi.default_params(launch=not a.default_params)
     F = a.frames
     gray, depth, poses = synth.sequence(F, seed=2 + rank, n_unique=a.unique)
     stream = torch.cuda.current_stream()
@@ -186,7 +188,7 @@ def main():
             "config": {"workload": "TUM fr3/cabinet-length sequence (%d frames, 640x480), lines-only odometry: "
                                    "LSD + 3D line fit + MSLD + MLE per frame, line matching + 3-line RANSAC + LM "
                                    "pose vs predecessor; synthetic seeded RGB-D (lineslam_amd/synth.py)" % F,
-                       "frames_per_gpu": F, "params": "launch/lineslam.launch" if a.launch_params else "ParameterServer defaults",
+                       "frames_per_gpu": F, "params": "ParameterServer defaults" if a.default_params else "launch/lineslam.launch (lsd_angle_thres 40, min_matches 10)",
                        "lines_per_frame": nlines, "parallelism": "frames in flight: one wavefront per frame (LSD sweep), "
                        "per segment (3D fit), per pair (pose)" + ("; %d ranks, 1 sequence each, 1 all-gather/step" % world if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_lsd_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -187,6 +187,7 @@ static int build_lsd_consts(lf_ctx *c) {
   lc.prec = M_PI * p.lsd_angle_th / 180.0;                  // lsd.cpp:1963
   lc.p = p.lsd_angle_th / 180.0;                            // lsd.cpp:1964
   lc.rho = p.lsd_quant / sin(lc.prec);                      // lsd.cpp:1965
+  lc.cos_prec = cos(lc.prec);
   lc.logNT = 5.0 * (log10((double)lc.N) + log10((double)lc.M)) / 2.0;   // lsd.cpp:1983
   lc.min_reg_size = (int)(-lc.logNT / log10(lc.p));         // lsd.cpp:1984
   lc.density_th = p.lsd_density_th;
@@ -266,6 +267,8 @@ static int alloc_lsd(lf_ctx *c) {
   ALLOC(c, b.scaled, B * NM);
   ALLOC(c, b.angles, B * NM);
   ALLOC(c, b.modgrad, B * NM);
+  ALLOC(c, b.cosang, B * NM);
+  ALLOC(c, b.sinang, B * NM);
   ALLOC(c, b.bins, B * NM);
   int nch = (lc.N - 1 + LF_SORT_CHUNK_COLS - 1) / LF_SORT_CHUNK_COLS;
   ALLOC(c, b.cnt, B * nch * 1024);

@@ -24,6 +24,7 @@ struct LsdConsts {
   double rho;          // quant / sin(prec)              (lsd.cpp:1965)
   double prec;         // pi * ang_th / 180              (lsd.cpp:1963)
   double p;            // ang_th / 180                   (lsd.cpp:1964)
+  double cos_prec;     // cos(prec), host libm: alignment pre-filter of region_grow
   double logNT;        // 5 (log10 N + log10 M) / 2      (lsd.cpp:1983)
   int min_reg_size;    // (int)(-logNT / log10 p)        (lsd.cpp:1984)
   double density_th;   // sysPara.lsd_density_th
@@ -46,6 +47,7 @@ struct LsdBuffers {
   double *scaled;        // [B][M][N]
   double *angles;        // [B][M][N]
   double *modgrad;       // [B][M][N]
+  double *cosang, *sinang; // [B][M][N] cos / sin of the level-line angle (cos = 2 marks NOTDEF)
   uint16_t *bins;        // [B][M][N]
   uint32_t *cnt;         // [B][nchunks][n_bins]
   uint32_t *seeds;       // [B][M*N]   pixel address y*N+x in reference list order

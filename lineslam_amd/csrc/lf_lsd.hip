@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) k_ll_angle(LsdConsts c, LsdBuffers b) {
   const size_t NM = (size_t)c.N * c.M;
   const double *in = b.scaled + f * NM;
   size_t adr = (size_t)y * c.N + x;
-  double ang = LF_NOTDEF, norm = 0.0;
+  double ang = LF_NOTDEF, norm = 0.0, ca = 2.0, sa = 0.0;
   uint16_t bin = LF_BIN_NONE;
   if (x < c.N - 1 && y < c.M - 1) {
     double com1 = in[adr + c.N + 1] - in[adr];
@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(256) k_ll_angle(LsdConsts c, LsdBuffers b) {
     norm = lf_sqrt(norm2 / 4.0);
     if (!(norm <= c.rho)) {
       ang = lf_atan2(gx, -gy);
+      lf_sincos(ang, &sa, &ca);      // cos/sin of the stored angle, as region_grow evaluates them (lsd.cpp:1652-1653)
       unsigned int i = (unsigned int)(norm * (double)c.n_bins / c.max_grad);
       if (i >= (unsigned int)c.n_bins) i = (unsigned int)c.n_bins - 1;
       bin = (uint16_t)i;
@@ -114,6 +115,8 @@ __global__ void __launch_bounds__(256) k_ll_angle(LsdConsts c, LsdBuffers b) {
   }
   b.angles[f * NM + adr] = ang;
   b.modgrad[f * NM + adr] = norm;
+  b.cosang[f * NM + adr] = ca;
+  b.sinang[f * NM + adr] = sa;
   b.bins[f * NM + adr] = bin;
 }
 
@@ -228,7 +231,7 @@ struct Rect {   // lsd.cpp:1075-1084, plus the precision level (p = p0 / 2^plev)
 };
 struct FrameView {
   int N, M, lane;
-  const double *angles, *modgrad, *lgam;
+  const double *angles, *modgrad, *lgam, *cosang, *sinang;
   const LsdConsts *dc;
   uint8_t *used;
   uint32_t *reg, *tmp;
@@ -273,15 +276,29 @@ __device__ __forceinline__ double d_angle_diff(double a, double b) {          //
 // next 64 slots against the CURRENT reg_angle; every slot before the first hit is a final "no";
 // the first hit is committed (used, reg[], sums, reg_angle = atan2) and the step restarts right
 // after it -- exactly the sequential semantics.
-__device__ int d_region_grow(const FrameView &f, int sx, int sy, double prec, double *reg_angle_io,
+#define LF_RING 1024   // most recent region pixels kept in LDS (the growth front reads them back)
+// Alignment test of region_grow without atan2 on the critical path.  The reference decides
+//   | atan2(sumdy, sumdx) - a | (wrapped, lsd.cpp:799-832) < prec.
+// For 0 < prec < pi/2 that is  cos(angle between (sumdx,sumdy) and (cos a, sin a)) > cos(prec), i.e.
+//   dot > 0  and  dot^2 > cos^2(prec) |S|^2     with dot = sumdx cos a + sumdy sin a.
+// Both sides are evaluated in fp64 with relative error ~1e-15; whenever they are closer than 1e-12
+// (relative) the lane is AMBIGUOUS and the step falls back to the exact reference arithmetic (atan2 +
+// isaligned), so every decision equals the reference's.  cos a / sin a come from k_ll_angle (the same
+// lf_sincos values the reference's sums use, lsd.cpp:1652-1653).  prec outside (1e-6, 1.5) -- possible for
+// the tolerance tau of refine() -- always takes the exact path (the wrap quirk of isaligned for angle
+// differences in (pi, 3pi/2] matters once prec > pi/2).
+__device__ int d_region_grow(const FrameView &f, int sx, int sy, double prec, double cos_prec, double *reg_angle_io,
                              u64 *n_steps) {
+  __shared__ uint32_t ring[LF_RING];
   const int N = f.N, M = f.M, lane = f.lane;
   const int seed = sy * N + sx;
+  const bool fast = (prec > 1e-6 && prec < 1.5);
+  const double cp2 = cos_prec * cos_prec;
   double reg_angle = f.angles[seed];
-  double sn, cs;
-  lf_sincos(reg_angle, &sn, &cs);
-  double sumdx = cs, sumdy = sn;
-  if (lane == 0) { f.reg[0] = (uint32_t)sx | ((uint32_t)sy << 16); f.used[seed] = 1; }
+  double sumdx = f.cosang[seed], sumdy = f.sinang[seed];
+  double S2 = sumdx * sumdx + sumdy * sumdy;
+  bool angle_valid = true;     // reg_angle == atan2(sumdy, sumdx) of the current sums
+  if (lane == 0) { uint32_t pk = (uint32_t)sx | ((uint32_t)sy << 16); f.reg[0] = pk; ring[0] = pk; f.used[seed] = 1; }
   wave_mem_order();
   int size = 1, cur = 0;
   for (;;) {
@@ -291,28 +308,51 @@ __device__ int d_region_grow(const FrameView &f, int sx, int sy, double prec, do
     int slot = cur + lane;
     bool act = slot < total;
     int pi = slot / 9, nb = slot - pi * 9;
-    uint32_t pk = act ? f.reg[pi] : 0u;
+    uint32_t pk = 0u;
+    if (act) pk = (pi + LF_RING >= size) ? ring[pi & (LF_RING - 1)] : f.reg[pi];
     int ox = nb / 3;
     int cx = (int)(pk & 0xffffu) + ox - 1, cy = (int)(pk >> 16) + (nb - ox * 3) - 1;
     bool inb = act && cx >= 0 && cy >= 0 && cx < N && cy < M;
     int ca = inb ? cy * N + cx : 0;
-    bool cand = inb && (f.used[ca] == 0);
-    double a = cand ? f.angles[ca] : LF_NOTDEF;
-    bool ok = cand && d_isaligned(a, reg_angle, prec);
+    unsigned char u = f.used[ca];          // the three gathers are issued together
+    double cc = f.cosang[ca], ss = f.sinang[ca];
+    bool cand = inb && (u == 0) && (cc <= 1.5);   // cos == 2 marks NOTDEF
+    bool ok;
+    if (fast) {
+      double dot = sumdx * cc + sumdy * ss;
+      double lhs = dot * dot, rhs = cp2 * S2, band = 1e-12 * S2;
+      bool yes = cand && dot > 0.0 && lhs > rhs + band;
+      bool no = !cand || !(dot > 0.0) || lhs < rhs - band;
+      u64 amb = __ballot(!yes && !no);
+      if (amb == 0) ok = yes;
+      else {   // exact reference arithmetic for this step
+        if (!angle_valid) { reg_angle = lf_atan2(sumdy, sumdx); angle_valid = true; }
+        double a = cand ? f.angles[ca] : LF_NOTDEF;
+        ok = cand && d_isaligned(a, reg_angle, prec);
+      }
+    } else {
+      if (!angle_valid) { reg_angle = lf_atan2(sumdy, sumdx); angle_valid = true; }
+      double a = cand ? f.angles[ca] : LF_NOTDEF;
+      ok = cand && d_isaligned(a, reg_angle, prec);
+    }
     u64 mask = __ballot(ok);
     if (mask == 0) { cur += min(64, total - cur); continue; }
     int L = __builtin_ctzll(mask);
-    double aL = rl64(a, L);
+    double cL = rl64(cc, L), sL = rl64(ss, L);
     int caL = rl32(ca, L), cxL = rl32(cx, L), cyL = rl32(cy, L);
-    if (lane == 0) { f.used[caL] = 1; f.reg[size] = (uint32_t)cxL | ((uint32_t)cyL << 16); }
+    if (lane == 0) {
+      uint32_t npk = (uint32_t)cxL | ((uint32_t)cyL << 16);
+      f.used[caL] = 1; f.reg[size] = npk; ring[size & (LF_RING - 1)] = npk;
+    }
     wave_mem_order();
     size++;
-    lf_sincos(aL, &sn, &cs);
-    sumdx += cs;
-    sumdy += sn;
-    reg_angle = lf_atan2(sumdy, sumdx);
+    sumdx += cL;
+    sumdy += sL;
+    S2 = sumdx * sumdx + sumdy * sumdy;
+    angle_valid = false;
     cur += L + 1;
   }
+  if (!angle_valid) reg_angle = lf_atan2(sumdy, sumdx);   // value after the last accepted pixel (lsd.cpp:1654)
   *reg_angle_io = reg_angle;
   return size;
 }
@@ -675,7 +715,7 @@ __device__ bool d_refine(const FrameView &f, int *reg_size, double reg_angle, do
   wave_mem_order();
   double mean_angle = sum / (double)n;
   double tau = 2.0 * lf_sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
-  size = d_region_grow(f, sx, sy, tau, &reg_angle, n_steps);
+  size = d_region_grow(f, sx, sy, tau, lf_cos(tau), &reg_angle, n_steps);
   *reg_size = size;
   if (size < 2) return false;
   d_region2rect(f, size, reg_angle, prec, p, 0, rec);
@@ -692,6 +732,8 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
   f.N = c.N; f.M = c.M; f.lane = lane;
   f.angles = b.angles + fidx * NM;
   f.modgrad = b.modgrad + fidx * NM;
+  f.cosang = b.cosang + fidx * NM;
+  f.sinang = b.sinang + fidx * NM;
   f.lgam = b.lgam;
   f.dc = dc;
   f.used = b.used + fidx * NM;
@@ -701,7 +743,8 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
   const uint32_t *seeds = b.seeds + fidx * NM;
   double *segs = b.segs + (size_t)fidx * c.seg_cap * LF_SEG_STRIDE;
   const int nseeds = b.nseeds[fidx];
-  u64 n_grow = 0, n_steps = 0, n_nfa = 0, n_px = 0, n_regpx = 0;
+  u64 n_grow = 0, n_steps = 0, n_nfa = 0, n_px = 0, n_regpx = 0, cyc_grow = 0, cyc_imp = 0, cyc_r2r = 0;
+  const u64 cyc0 = __builtin_readcyclecounter();
   int ls_count = 0;
   int s = 0;
   while (s < nseeds) {
@@ -717,13 +760,23 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
     int sx = sa % c.N, sy = sa / c.N;
     double reg_angle;
     ++n_grow;
-    int reg_size = d_region_grow(f, sx, sy, c.prec, &reg_angle, &n_steps);
+    u64 t0 = __builtin_readcyclecounter();
+    int reg_size = d_region_grow(f, sx, sy, c.prec, c.cos_prec, &reg_angle, &n_steps);
+    cyc_grow += __builtin_readcyclecounter() - t0;
     n_regpx += (u64)reg_size;
     if (reg_size < c.min_reg_size) continue;
     Rect rec;
+    t0 = __builtin_readcyclecounter();
     d_region2rect(f, reg_size, reg_angle, c.prec, c.p, 0, &rec);
-    if (!d_refine(f, &reg_size, reg_angle, c.prec, c.p, &rec, c.density_th, &n_steps)) continue;
+    cyc_r2r += __builtin_readcyclecounter() - t0;
+    t0 = __builtin_readcyclecounter();
+    bool refined_ok = d_refine(f, &reg_size, reg_angle, c.prec, c.p, &rec, c.density_th, &n_steps);
+    cyc_r2r += __builtin_readcyclecounter() - t0;
+    if (!refined_ok) continue;
+    if (false && !d_refine(f, &reg_size, reg_angle, c.prec, c.p, &rec, c.density_th, &n_steps)) continue;
+    t0 = __builtin_readcyclecounter();
     double log_nfa = d_rect_improve(f, &rec, c.logNT, c.eps, &n_nfa, &n_px);
+    cyc_imp += __builtin_readcyclecounter() - t0;
     if (log_nfa <= c.eps) continue;
     ++ls_count;
     rec.x1 += 0.5; rec.y1 += 0.5;
@@ -750,7 +803,8 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
     if (b.stats) {
       unsigned long long *st = b.stats + (size_t)fidx * 8;
       st[0] = n_grow; st[1] = n_steps; st[2] = n_nfa; st[3] = n_px; st[4] = n_regpx;
-      st[5] = (u64)nseeds; st[6] = 0; st[7] = 0;
+      st[5] = __builtin_readcyclecounter() - cyc0; st[6] = cyc_grow; st[7] = cyc_imp; (void)cyc_r2r;
+      st[3] = cyc_r2r;   /* slot 3 repurposed: cycles in region2rect + refine */
     }
   }
 }
