@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -200,6 +201,12 @@ static int build_lsd_consts(lf_ctx *c) {
     pk /= 2.0;
   }
   lc.seg_cap = 4096;
+  {
+    const char *e = getenv("LF_SWEEP_WAVES");   // 1 = sequential one-wavefront sweep; 2/4/8 = speculative multi-wave sweep
+    lc.sweep_waves = e ? atoi(e) : LF_MW_MAXW;
+    if (lc.sweep_waves < 1) lc.sweep_waves = 1;
+    if (lc.sweep_waves > LF_MW_MAXW) lc.sweep_waves = LF_MW_MAXW;
+  }
   return LF_OK;
 }
 
@@ -277,6 +284,9 @@ static int alloc_lsd(lf_ctx *c) {
   ALLOC(c, b.used, B * NM);
   ALLOC(c, b.reg, B * NM);
   ALLOC(c, b.tmp, B * NM);
+  ALLOC(c, b.mw_tag, B * LF_MW_MAXW * NM);
+  ALLOC(c, b.mw_lists, B * LF_MW_MAXW * 4 * (size_t)LF_MW_CAP);
+  HIPCHK(c, hipMemsetAsync(b.mw_tag, 0, B * LF_MW_MAXW * NM, c->stream));
   ALLOC(c, b.labels, B * NM);
   ALLOC(c, b.segs, B * (size_t)lc.seg_cap * LF_SEG_STRIDE);
   ALLOC(c, b.nsegs, B);

@@ -13,6 +13,8 @@
 #define LF_SEG_STRIDE 5              // x1,y1,x2,y2,width
 #define LF_BIN_NONE 0xFFFFu
 #define LF_SORT_CHUNK_COLS 8         // seed counting sort: columns per chunk
+#define LF_MW_CAP 8192               // multi-wave sweep: speculative region list capacity (larger regions re-run at the frontier)
+#define LF_MW_MAXW 8                 // wavefronts per frame
 
 // Host-computed constants (host libm, exactly as the reference evaluates them on the CPU).
 struct LsdConsts {
@@ -34,6 +36,7 @@ struct LsdConsts {
   double log1mp[LF_MAX_PLEVEL];  // log(1 - p / 2^k)
   double log10p[LF_MAX_PLEVEL];  // log10(p / 2^k)
   int seg_cap;         // rows available per frame in the segment output
+  int sweep_waves;     // wavefronts per frame in the seed sweep (1 = sequential kernel)
 };
 
 // Per-batch device pointers (frame f uses offset f * per-frame size).
@@ -55,6 +58,8 @@ struct LsdBuffers {
   uint8_t *used;         // [B][M*N]
   uint32_t *reg;         // [B][M*N]   region pixel list, x | y<<16
   uint32_t *tmp;         // [B][M*N]   scratch for reduce_region_radius
+  uint8_t *mw_tag;       // [B][W][M*N] private tentative marks of each sweep wavefront
+  uint32_t *mw_lists;    // [B][W][4][LF_MW_CAP] private region list, scratch, accepted-ever list (2x)
   uint16_t *labels;      // [B][M*N]   0 = none, k = k-th segment  (the integer pixel support)
   double *segs;          // [B][seg_cap][5]
   int *nsegs;            // [B]  (may exceed seg_cap: overflow)

@@ -233,9 +233,23 @@ struct FrameView {
   int N, M, lane;
   const double *angles, *modgrad, *lgam, *cosang, *sinang;
   const LsdConsts *dc;
-  uint8_t *used;
-  uint32_t *reg, *tmp;
+  uint8_t *used;          // committed `used` mask of the frame
+  uint8_t *tag;           // multi-wave sweep: this wavefront's PRIVATE marks (null: mark `used` directly)
+  uint32_t *reg, *tmp;    // region list / scratch, `cap` entries each
+  int cap;
+  uint32_t *ring;         // LDS ring of the most recent region pixels (per wavefront)
+  uint32_t *ever;         // multi-wave sweep: every pixel this region ever accepted (for validation)
+  int ever_cap;
+  int *n_ever, *overflow; // (wave-uniform values kept in memory visible to the helpers)
 };
+// `used` as the growing region sees it: committed marks plus its own tentative marks
+__device__ __forceinline__ bool fv_is_used(const FrameView &f, int p) {
+  unsigned char u = f.used[p];
+  if (f.tag) u |= f.tag[p];
+  return u != 0;
+}
+__device__ __forceinline__ void fv_mark(const FrameView &f, int p) { if (f.tag) f.tag[p] = 1; else f.used[p] = 1; }
+__device__ __forceinline__ void fv_unmark(const FrameView &f, int p) { if (f.tag) f.tag[p] = 0; else f.used[p] = 0; }
 
 // lsd.cpp:147-165
 __device__ __forceinline__ bool d_double_equal(double a, double b) {
@@ -289,7 +303,7 @@ __device__ __forceinline__ double d_angle_diff(double a, double b) {          //
 // differences in (pi, 3pi/2] matters once prec > pi/2).
 __device__ int d_region_grow(const FrameView &f, int sx, int sy, double prec, double cos_prec, double *reg_angle_io,
                              u64 *n_steps) {
-  __shared__ uint32_t ring[LF_RING];
+  uint32_t *ring = f.ring;
   const int N = f.N, M = f.M, lane = f.lane;
   const int seed = sy * N + sx;
   const bool fast = (prec > 1e-6 && prec < 1.5);
@@ -298,7 +312,7 @@ __device__ int d_region_grow(const FrameView &f, int sx, int sy, double prec, do
   double sumdx = f.cosang[seed], sumdy = f.sinang[seed];
   double S2 = sumdx * sumdx + sumdy * sumdy;
   bool angle_valid = true;     // reg_angle == atan2(sumdy, sumdx) of the current sums
-  if (lane == 0) { uint32_t pk = (uint32_t)sx | ((uint32_t)sy << 16); f.reg[0] = pk; ring[0] = pk; f.used[seed] = 1; }
+  if (lane == 0) { uint32_t pk = (uint32_t)sx | ((uint32_t)sy << 16); f.reg[0] = pk; ring[0] = pk; fv_mark(f, seed); }
   wave_mem_order();
   int size = 1, cur = 0;
   for (;;) {
@@ -314,9 +328,9 @@ __device__ int d_region_grow(const FrameView &f, int sx, int sy, double prec, do
     int cx = (int)(pk & 0xffffu) + ox - 1, cy = (int)(pk >> 16) + (nb - ox * 3) - 1;
     bool inb = act && cx >= 0 && cy >= 0 && cx < N && cy < M;
     int ca = inb ? cy * N + cx : 0;
-    unsigned char u = f.used[ca];          // the three gathers are issued together
+    bool u = fv_is_used(f, ca);            // the gathers are issued together
     double cc = f.cosang[ca], ss = f.sinang[ca];
-    bool cand = inb && (u == 0) && (cc <= 1.5);   // cos == 2 marks NOTDEF
+    bool cand = inb && !u && (cc <= 1.5);   // cos == 2 marks NOTDEF
     bool ok;
     if (fast) {
       double dot = sumdx * cc + sumdy * ss;
@@ -337,12 +351,13 @@ __device__ int d_region_grow(const FrameView &f, int sx, int sy, double prec, do
     }
     u64 mask = __ballot(ok);
     if (mask == 0) { cur += min(64, total - cur); continue; }
+    if (size >= f.cap) { if (f.overflow) *f.overflow = 1; break; }   // speculative list full: caller re-runs at the frontier
     int L = __builtin_ctzll(mask);
     double cL = rl64(cc, L), sL = rl64(ss, L);
     int caL = rl32(ca, L), cxL = rl32(cx, L), cyL = rl32(cy, L);
     if (lane == 0) {
       uint32_t npk = (uint32_t)cxL | ((uint32_t)cyL << 16);
-      f.used[caL] = 1; f.reg[size] = npk; ring[size & (LF_RING - 1)] = npk;
+      fv_mark(f, caL); f.reg[size] = npk; ring[size & (LF_RING - 1)] = npk;
     }
     wave_mem_order();
     size++;
@@ -630,7 +645,7 @@ __device__ double d_rect_improve(const FrameView &f, Rect *rec, double logNT, do
 __device__ bool d_reduce_region_radius(const FrameView &f, int *reg_size, double reg_angle, double prec,
                                        double p, Rect *rec, double density_th) {
   const int N = f.N, lane = f.lane;
-  const int NM = f.N * f.M;
+  const int NM = f.cap;   // scratch capacity: holes grow from the bottom, fillers from the top
   int size = *reg_size;
   double density = (double)size / (d_dist(rec->x1, rec->y1, rec->x2, rec->y2) * rec->width);
   if (density >= density_th) return true;
@@ -656,7 +671,7 @@ __device__ bool d_reduce_region_radius(const FrameView &f, int *reg_size, double
       uint32_t pk = v ? f.reg[i] : 0u;
       int rx = (int)(pk & 0xffffu), ry = (int)(pk >> 16);
       bool far = v && (d_dist(xc, yc, (double)rx, (double)ry) > rad);
-      if (far) f.used[ry * N + rx] = 0;
+      if (far) fv_unmark(f, ry * N + rx);
       bool hole = far && i < nkeep;
       bool fill = v && !far && i >= nkeep;
       u64 mh = __ballot(hole), mf = __ballot(fill);
@@ -699,7 +714,8 @@ __device__ bool d_refine(const FrameView &f, int *reg_size, double reg_angle, do
     bool v = i < size;
     uint32_t pk = v ? f.reg[i] : 0u;
     int rx = (int)(pk & 0xffffu), ry = (int)(pk >> 16);
-    if (v) f.used[ry * N + rx] = 0;
+    if (v) fv_unmark(f, ry * N + rx);
+    if (v && f.ever) { if (i < f.ever_cap) f.ever[i] = pk; }   // first growth, kept for validation
     bool q = v && d_dist(xc, yc, (double)rx, (double)ry) < rec->width;
     double ang_d = q ? d_angle_diff_signed(f.angles[ry * N + rx], ang_c) : 0.0;
     u64 m = __ballot(q);
@@ -715,8 +731,17 @@ __device__ bool d_refine(const FrameView &f, int *reg_size, double reg_angle, do
   wave_mem_order();
   double mean_angle = sum / (double)n;
   double tau = 2.0 * lf_sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
+  if (f.ever) { if (size > f.ever_cap) { *f.overflow = 1; } *f.n_ever = size < f.ever_cap ? size : f.ever_cap; }
   size = d_region_grow(f, sx, sy, tau, lf_cos(tau), &reg_angle, n_steps);
   *reg_size = size;
+  if (f.overflow && *f.overflow) return false;
+  if (f.ever) {   // second growth: append
+    int n0 = *f.n_ever;
+    if (n0 + size > f.ever_cap) *f.overflow = 1;
+    else { for (int i = lane; i < size; i += 64) f.ever[n0 + i] = f.reg[i]; *f.n_ever = n0 + size; }
+    wave_mem_order();
+    if (*f.overflow) return false;
+  }
   if (size < 2) return false;
   d_region2rect(f, size, reg_angle, prec, p, 0, rec);
   density = (double)size / (d_dist(rec->x1, rec->y1, rec->x2, rec->y2) * rec->width);
@@ -736,9 +761,14 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
   f.sinang = b.sinang + fidx * NM;
   f.lgam = b.lgam;
   f.dc = dc;
+  __shared__ uint32_t ring1[LF_RING];
   f.used = b.used + fidx * NM;
+  f.tag = nullptr;
   f.reg = b.reg + fidx * NM;
   f.tmp = b.tmp + fidx * NM;
+  f.cap = (int)NM;
+  f.ring = ring1;
+  f.ever = nullptr; f.ever_cap = 0; f.n_ever = nullptr; f.overflow = nullptr;
   uint16_t *labels = b.labels + fidx * NM;
   const uint32_t *seeds = b.seeds + fidx * NM;
   double *segs = b.segs + (size_t)fidx * c.seg_cap * LF_SEG_STRIDE;
@@ -809,6 +839,186 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
   }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Multi-wavefront sweep: W wavefronts per frame, SPECULATIVE regions with IN-ORDER commit.
+//
+// The reference visits the seeds in list order and every region sees the `used` marks of all
+// earlier regions.  Here each wavefront takes the next unresolved seed (a TICKET, handed out in list
+// order under an LDS lock), grows / refines / validates its region against the COMMITTED `used` mask
+// plus its own private marks (f.tag), and then waits until all earlier tickets have committed.  At
+// that point the committed mask is exactly the state the sequential algorithm would see, so the
+// speculation is valid iff (a) the seed is still unused and (b) no pixel the region ever accepted has
+// been marked meanwhile (pixels it saw as used stay used: commits are permanent; pixels it rejected
+// as not aligned stay rejected).  A valid region is committed as is; an invalid one is re-run right
+// there -- at the frontier nothing can interfere -- unless its seed got covered (then the sequential
+// algorithm would have skipped it).  Segment numbers are assigned at commit, i.e. in list order.  The
+// result is bit-identical to the one-wavefront sweep; what changes is that W regions are in flight.
+struct SweepCtl {
+  int lock, scan, next_ticket, frontier, ls_count, done;
+};
+struct RegionResult { int reg_size; int accepted; Rect rec; };
+
+__device__ void mw_process(const FrameView &f, const LsdConsts &c, int sx, int sy, RegionResult *out,
+                           u64 *n_steps, u64 *n_nfa, u64 *n_px) {
+  double reg_angle;
+  out->accepted = 0;
+  int reg_size = d_region_grow(f, sx, sy, c.prec, c.cos_prec, &reg_angle, n_steps);
+  out->reg_size = reg_size;
+  if (f.overflow && *f.overflow) return;
+  if (reg_size < c.min_reg_size) return;
+  Rect rec;
+  d_region2rect(f, reg_size, reg_angle, c.prec, c.p, 0, &rec);
+  bool okr = d_refine(f, &reg_size, reg_angle, c.prec, c.p, &rec, c.density_th, n_steps);
+  out->reg_size = reg_size;
+  if (f.overflow && *f.overflow) return;
+  if (!okr) return;
+  double log_nfa = d_rect_improve(f, &rec, c.logNT, c.eps, n_nfa, n_px);
+  if (log_nfa <= c.eps) return;
+  out->accepted = 1;
+  out->rec = rec;
+}
+
+template <int W>
+__global__ void __launch_bounds__(W * 64) k_lsd_sweep_mw(LsdConsts c, const LsdConsts *dc, LsdBuffers b) {
+  __shared__ SweepCtl ctl;
+  __shared__ uint32_t rings[W][LF_RING];
+  __shared__ int s_never[W], s_over[W];
+  const int fidx = blockIdx.x, lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+  const size_t NM = (size_t)c.N * c.M;
+  if (threadIdx.x == 0) { ctl.lock = 0; ctl.scan = 0; ctl.next_ticket = 0; ctl.frontier = 0; ctl.ls_count = 0; ctl.done = 0; }
+  __syncthreads();
+  FrameView f;
+  f.N = c.N; f.M = c.M; f.lane = lane;
+  f.angles = b.angles + fidx * NM;
+  f.modgrad = b.modgrad + fidx * NM;
+  f.cosang = b.cosang + fidx * NM;
+  f.sinang = b.sinang + fidx * NM;
+  f.lgam = b.lgam;
+  f.dc = dc;
+  f.used = b.used + fidx * NM;
+  f.tag = b.mw_tag + ((size_t)fidx * W + wave) * NM;
+  uint32_t *reg_small = b.mw_lists + (((size_t)fidx * W + wave) * 4) * LF_MW_CAP;
+  uint32_t *tmp_small = reg_small + LF_MW_CAP;
+  f.ring = rings[wave];
+  f.ever = reg_small + 2 * LF_MW_CAP;
+  f.ever_cap = 2 * LF_MW_CAP;
+  f.n_ever = &s_never[wave];
+  f.overflow = &s_over[wave];
+  uint32_t *reg_big = b.reg + fidx * NM, *tmp_big = b.tmp + fidx * NM;
+  uint16_t *labels = b.labels + fidx * NM;
+  const uint32_t *seeds = b.seeds + fidx * NM;
+  double *segs = b.segs + (size_t)fidx * c.seg_cap * LF_SEG_STRIDE;
+  const int nseeds = b.nseeds[fidx];
+  volatile SweepCtl *vc = &ctl;
+  u64 n_steps = 0, n_nfa = 0, n_px = 0, n_regions = 0, n_redo = 0, n_dropped = 0;
+  for (;;) {
+    // ---- take the next ticket: scan the seed list for the next seed not yet used (committed state)
+    if (lane == 0) { while (atomicCAS(&ctl.lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int pos = vc->scan, ticket = -1, sa = 0;
+    while (pos < nseeds) {
+      int idx = pos + lane;
+      bool v = idx < nseeds;
+      uint32_t addr = v ? seeds[idx] : 0u;
+      bool isfree = v && f.used[addr] == 0;
+      u64 m = __ballot(isfree);
+      if (m == 0) { pos += 64; continue; }
+      int L = __builtin_ctzll(m);
+      sa = rl32((int)addr, L);
+      pos += L + 1;
+      ticket = vc->next_ticket;
+      break;
+    }
+    if (lane == 0) { vc->scan = pos; if (ticket >= 0) vc->next_ticket = ticket + 1; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicExch(&ctl.lock, 0);
+    if (ticket < 0) break;
+    // ---- speculative run on private lists
+    const int sx = sa % c.N, sy = sa / c.N;
+    RegionResult res;
+    f.reg = reg_small; f.tmp = tmp_small; f.cap = LF_MW_CAP;
+    if (lane == 0) { s_never[wave] = 0; s_over[wave] = 0; }
+    wave_mem_order();
+    mw_process(f, c, sx, sy, &res, &n_steps, &n_nfa, &n_px);
+    ++n_regions;
+    // ---- wait for the frontier
+    while (vc->frontier != ticket) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- validate against the committed mask (now == the sequential state before this seed)
+    bool valid = (s_over[wave] == 0);
+    bool seed_used = f.used[sa] != 0;
+    if (valid && !seed_used) {
+      const uint32_t *lst = (s_never[wave] > 0) ? f.ever : f.reg;
+      const int nl = (s_never[wave] > 0) ? s_never[wave] : res.reg_size;
+      bool clash = false;
+      for (int base = 0; base < nl; base += 64) {
+        int i = base + lane;
+        if (i < nl) { uint32_t pk = lst[i]; if (f.used[(int)(pk >> 16) * c.N + (int)(pk & 0xffffu)] != 0) clash = true; }
+      }
+      if (__ballot(clash) != 0) valid = false;
+    }
+    if (seed_used || !valid) {
+      // drop the tentative marks (everything still tagged is in the current list)
+      for (int base = 0; base < res.reg_size; base += 64) {
+        int i = base + lane;
+        if (i < res.reg_size) { uint32_t pk = f.reg[i]; f.tag[(int)(pk >> 16) * c.N + (int)(pk & 0xffffu)] = 0; }
+      }
+      wave_mem_order();
+      if (seed_used) {      // covered by an earlier region: the reference skips this seed
+        ++n_dropped;
+        if (lane == 0) vc->frontier = ticket + 1;
+        continue;
+      }
+      ++n_redo;             // re-run at the frontier (always valid), with the frame's full-size lists
+      f.reg = reg_big; f.tmp = tmp_big; f.cap = (int)NM;
+      uint32_t *ever_save = f.ever;
+      f.ever = nullptr;
+      if (lane == 0) { s_never[wave] = 0; s_over[wave] = 0; }
+      wave_mem_order();
+      mw_process(f, c, sx, sy, &res, &n_steps, &n_nfa, &n_px);
+      f.ever = ever_save;
+    }
+    // ---- commit (only the frontier wavefront is ever here)
+    int ls = 0;
+    if (res.accepted) {
+      ls = vc->ls_count + 1;
+      if (lane == 0) vc->ls_count = ls;
+      Rect rec = res.rec;
+      rec.x1 += 0.5; rec.y1 += 0.5;
+      rec.x2 += 0.5; rec.y2 += 0.5;
+      if (c.scale != 1.0) {
+        rec.x1 /= c.scale; rec.y1 /= c.scale;
+        rec.x2 /= c.scale; rec.y2 /= c.scale;
+        rec.width /= c.scale;
+      }
+      if (ls <= c.seg_cap && lane == 0) {
+        double *o = segs + (size_t)(ls - 1) * LF_SEG_STRIDE;
+        o[0] = rec.x1; o[1] = rec.y1; o[2] = rec.x2; o[3] = rec.y2; o[4] = rec.width;
+      }
+    }
+    for (int base = 0; base < res.reg_size; base += 64) {
+      int i = base + lane;
+      if (i < res.reg_size) {
+        uint32_t pk = f.reg[i];
+        int p = (int)(pk >> 16) * c.N + (int)(pk & 0xffffu);
+        f.used[p] = 1;
+        f.tag[p] = 0;
+        if (res.accepted) labels[p] = (uint16_t)ls;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) vc->frontier = ticket + 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) b.nsegs[fidx] = ctl.ls_count;
+  if (lane == 0 && b.stats) {
+    unsigned long long *st = b.stats + (size_t)fidx * 8;
+    atomicAdd(&st[0], n_regions); atomicAdd(&st[1], n_steps); atomicAdd(&st[2], n_nfa);
+    atomicAdd(&st[3], n_redo); atomicAdd(&st[4], n_dropped); atomicAdd(&st[5], n_px);
+  }
+}
+
 // ----------------------------------------------------------------------------------------------
 void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int B, hipStream_t st) {
   const size_t NM = (size_t)c.N * c.M;
@@ -825,6 +1035,12 @@ void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int B, hipStream_t s
   (void)hipMemsetAsync(b.used, 0, NM * (size_t)B, st);
   (void)hipMemsetAsync(b.labels, 0, NM * (size_t)B * sizeof(uint16_t), st);
   if (b.ev_sweep0) (void)hipEventRecord(b.ev_sweep0, st);
+  if (c.sweep_waves > 1) {
+    (void)hipMemsetAsync(b.stats, 0, sizeof(unsigned long long) * 8 * (size_t)B, st);
+    if (c.sweep_waves >= 8) hipLaunchKernelGGL(k_lsd_sweep_mw<8>, dim3(B), dim3(8 * 64), 0, st, c, b.dconsts, b);
+    else if (c.sweep_waves >= 4) hipLaunchKernelGGL(k_lsd_sweep_mw<4>, dim3(B), dim3(4 * 64), 0, st, c, b.dconsts, b);
+    else hipLaunchKernelGGL(k_lsd_sweep_mw<2>, dim3(B), dim3(2 * 64), 0, st, c, b.dconsts, b);
+  } else
   hipLaunchKernelGGL(k_lsd_sweep, dim3(B), dim3(64), 0, st, c, b.dconsts, b);
   if (b.ev_sweep1) (void)hipEventRecord(b.ev_sweep1, st);
 }
