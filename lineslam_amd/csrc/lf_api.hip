@@ -202,9 +202,11 @@ static int build_lsd_consts(lf_ctx *c) {
   }
   lc.seg_cap = 4096;
   {
-    const char *e = getenv("LF_SWEEP_WAVES");   // 1 = sequential one-wavefront sweep; 2/4/8 = speculative multi-wave sweep
-    lc.sweep_waves = e ? atoi(e) : LF_MW_MAXW;
-    if (lc.sweep_waves < 1) lc.sweep_waves = 1;
+    // wavefronts per frame in the seed sweep: 0 = automatic (speculative 8-wave sweep for small batches,
+    // where per-frame latency is what matters; sequential 1-wave sweep once >= 1 frame per SIMD is in flight)
+    const char *e = getenv("LF_SWEEP_WAVES");
+    lc.sweep_waves = e ? atoi(e) : 0;
+    if (lc.sweep_waves < 0) lc.sweep_waves = 0;
     if (lc.sweep_waves > LF_MW_MAXW) lc.sweep_waves = LF_MW_MAXW;
   }
   return LF_OK;
@@ -400,7 +402,9 @@ int lf_lsd_batch_device(lf_ctx *c, const uint8_t *d_gray, size_t frame_stride, i
   c->lb.gray_frame_stride = frame_stride;
   c->lb.gray_row_stride = row_stride;
   c->lb.ev_pre = c->ev[0]; c->lb.ev_sweep0 = c->ev[1]; c->lb.ev_sweep1 = c->ev[2];
-  lf_lsd_launch(c->lc, c->lb, n_frames, c->stream);
+  LsdConsts lc = c->lc;
+  if (lc.sweep_waves == 0) lc.sweep_waves = (n_frames <= 160) ? LF_MW_MAXW : 1;
+  lf_lsd_launch(lc, c->lb, n_frames, c->stream);
   HIPCHK(c, hipGetLastError());
   c->last_batch = n_frames;
   return LF_OK;

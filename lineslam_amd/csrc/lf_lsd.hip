@@ -229,7 +229,9 @@ struct Rect {   // lsd.cpp:1075-1084, plus the precision level (p = p0 / 2^plev)
   double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p;
   int plev;
 };
-struct FrameView {
+template <bool MW_>
+struct FrameViewT {
+  static constexpr bool kMW = MW_;
   int N, M, lane;
   const double *angles, *modgrad, *lgam, *cosang, *sinang;
   const LsdConsts *dc;
@@ -243,13 +245,15 @@ struct FrameView {
   int *n_ever, *overflow; // (wave-uniform values kept in memory visible to the helpers)
 };
 // `used` as the growing region sees it: committed marks plus its own tentative marks
-__device__ __forceinline__ bool fv_is_used(const FrameView &f, int p) {
+typedef FrameViewT<false> FrameView;      // sequential sweep: marks go straight to `used`
+typedef FrameViewT<true> FrameViewMW;     // multi-wave sweep: private tentative marks
+template <class FV> __device__ __forceinline__ bool fv_is_used(const FV &f, int p) {
   unsigned char u = f.used[p];
-  if (f.tag) u |= f.tag[p];
+  if constexpr (FV::kMW) u |= f.tag[p];
   return u != 0;
 }
-__device__ __forceinline__ void fv_mark(const FrameView &f, int p) { if (f.tag) f.tag[p] = 1; else f.used[p] = 1; }
-__device__ __forceinline__ void fv_unmark(const FrameView &f, int p) { if (f.tag) f.tag[p] = 0; else f.used[p] = 0; }
+template <class FV> __device__ __forceinline__ void fv_mark(const FV &f, int p) { if constexpr (FV::kMW) f.tag[p] = 1; else f.used[p] = 1; }
+template <class FV> __device__ __forceinline__ void fv_unmark(const FV &f, int p) { if constexpr (FV::kMW) f.tag[p] = 0; else f.used[p] = 0; }
 
 // lsd.cpp:147-165
 __device__ __forceinline__ bool d_double_equal(double a, double b) {
@@ -301,7 +305,8 @@ __device__ __forceinline__ double d_angle_diff(double a, double b) {          //
 // lf_sincos values the reference's sums use, lsd.cpp:1652-1653).  prec outside (1e-6, 1.5) -- possible for
 // the tolerance tau of refine() -- always takes the exact path (the wrap quirk of isaligned for angle
 // differences in (pi, 3pi/2] matters once prec > pi/2).
-__device__ int d_region_grow(const FrameView &f, int sx, int sy, double prec, double cos_prec, double *reg_angle_io,
+template <class FV>
+__device__ int d_region_grow(const FV &f, int sx, int sy, double prec, double cos_prec, double *reg_angle_io,
                              u64 *n_steps) {
   uint32_t *ring = f.ring;
   const int N = f.N, M = f.M, lane = f.lane;
@@ -351,7 +356,7 @@ __device__ int d_region_grow(const FrameView &f, int sx, int sy, double prec, do
     }
     u64 mask = __ballot(ok);
     if (mask == 0) { cur += min(64, total - cur); continue; }
-    if (size >= f.cap) { if (f.overflow) *f.overflow = 1; break; }   // speculative list full: caller re-runs at the frontier
+    if constexpr (FV::kMW) { if (size >= f.cap) { *f.overflow = 1; break; } }   // speculative list full: caller re-runs at the frontier
     int L = __builtin_ctzll(mask);
     double cL = rl64(cc, L), sL = rl64(ss, L);
     int caL = rl32(ca, L), cxL = rl32(cx, L), cyL = rl32(cy, L);
@@ -375,7 +380,8 @@ __device__ int d_region_grow(const FrameView &f, int sx, int sy, double prec, do
 // region2rect + get_theta (lsd.cpp:1517-1604, 1474-1512).  The three weighted sums and the three
 // inertia sums are accumulated in the reference's pixel order: lanes prepare the 64 next operands,
 // a uniform loop adds them one by one.
-__device__ void d_region2rect(const FrameView &f, int n, double reg_angle, double prec, double p,
+template <class FV>
+__device__ void d_region2rect(const FV &f, int n, double reg_angle, double prec, double p,
                               int plev, Rect *rec) {
   const int N = f.N, lane = f.lane;
   double x = 0.0, y = 0.0, sum = 0.0;
@@ -455,7 +461,8 @@ __device__ void d_region2rect(const FrameView &f, int n, double reg_angle, doubl
 // log(p), log(1-p), log10(p) from the per-level host tables.  The binomial tail is summed in the
 // reference order; the per-term truncation test (pow, log10) is evaluated for a chunk of terms in
 // parallel lanes and the first term that satisfies it ends the sum, as the sequential `break`.
-__device__ double d_nfa(const FrameView &f, int n, int k, double p, int plev, double logNT) {
+template <class FV>
+__device__ double d_nfa(const FV &f, int n, int k, double p, int plev, double logNT) {
   const int lane = f.lane;
   const double tolerance = 0.1;
   if (n == 0 || k == 0) return -logNT;
@@ -516,7 +523,8 @@ __device__ __forceinline__ double pick4(int i, double a0, double a1, double a2, 
 // column y = ceil(ys).. while y <= ye.  Only in-image pixels are counted by the reference, so both
 // ranges are clipped to the image before any int conversion.  Lanes take (column, row-phase) pairs;
 // the two counters are integers, so their reduction order is irrelevant.
-__device__ double d_rect_nfa(const FrameView &f, const Rect &r, double logNT, u64 *n_px) {
+template <class FV>
+__device__ double d_rect_nfa(const FV &f, const Rect &r, double logNT, u64 *n_px) {
   const int N = f.N, M = f.M, lane = f.lane;
   double hw = r.width / 2.0;
   double rx0 = r.x1 - r.dy * hw, ry0 = r.y1 + r.dx * hw;
@@ -572,7 +580,8 @@ __device__ double d_rect_nfa(const FrameView &f, const Rect &r, double logNT, u6
 }
 
 // rect_improve (lsd.cpp:1662-1768)
-__device__ double d_rect_improve(const FrameView &f, Rect *rec, double logNT, double eps, u64 *n_nfa,
+template <class FV>
+__device__ double d_rect_improve(const FV &f, Rect *rec, double logNT, double eps, u64 *n_nfa,
                                  u64 *n_px) {
   Rect r;
   const double delta = 0.5, delta_2 = delta / 2.0;
@@ -642,7 +651,8 @@ __device__ double d_rect_improve(const FrameView &f, Rect *rec, double logNT, do
 // "reg[i] = reg[last]; --size; --i".  Its result is: every position i < #keep that holds a far
 // pixel ("hole", ascending i) receives the kept pixels found at positions >= #keep, taken from the
 // END backwards.  That permutation is reproduced with two ballot-ranked passes over the list.
-__device__ bool d_reduce_region_radius(const FrameView &f, int *reg_size, double reg_angle, double prec,
+template <class FV>
+__device__ bool d_reduce_region_radius(const FV &f, int *reg_size, double reg_angle, double prec,
                                        double p, Rect *rec, double density_th) {
   const int N = f.N, lane = f.lane;
   const int NM = f.cap;   // scratch capacity: holes grow from the bottom, fillers from the top
@@ -697,7 +707,8 @@ __device__ bool d_reduce_region_radius(const FrameView &f, int *reg_size, double
 }
 
 // refine (lsd.cpp:1853-1921)
-__device__ bool d_refine(const FrameView &f, int *reg_size, double reg_angle, double prec, double p,
+template <class FV>
+__device__ bool d_refine(const FV &f, int *reg_size, double reg_angle, double prec, double p,
                          Rect *rec, double density_th, u64 *n_steps) {
   const int N = f.N, lane = f.lane;
   int size = *reg_size;
@@ -715,7 +726,7 @@ __device__ bool d_refine(const FrameView &f, int *reg_size, double reg_angle, do
     uint32_t pk = v ? f.reg[i] : 0u;
     int rx = (int)(pk & 0xffffu), ry = (int)(pk >> 16);
     if (v) fv_unmark(f, ry * N + rx);
-    if (v && f.ever) { if (i < f.ever_cap) f.ever[i] = pk; }   // first growth, kept for validation
+    if constexpr (FV::kMW) { if (v && f.ever) { if (i < f.ever_cap) f.ever[i] = pk; } }   // first growth, kept for validation
     bool q = v && d_dist(xc, yc, (double)rx, (double)ry) < rec->width;
     double ang_d = q ? d_angle_diff_signed(f.angles[ry * N + rx], ang_c) : 0.0;
     u64 m = __ballot(q);
@@ -731,16 +742,18 @@ __device__ bool d_refine(const FrameView &f, int *reg_size, double reg_angle, do
   wave_mem_order();
   double mean_angle = sum / (double)n;
   double tau = 2.0 * lf_sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
-  if (f.ever) { if (size > f.ever_cap) { *f.overflow = 1; } *f.n_ever = size < f.ever_cap ? size : f.ever_cap; }
+  if constexpr (FV::kMW) { if (f.ever) { if (size > f.ever_cap) { *f.overflow = 1; } *f.n_ever = size < f.ever_cap ? size : f.ever_cap; } }
   size = d_region_grow(f, sx, sy, tau, lf_cos(tau), &reg_angle, n_steps);
   *reg_size = size;
-  if (f.overflow && *f.overflow) return false;
+  if constexpr (FV::kMW) {
+  if (*f.overflow) return false;
   if (f.ever) {   // second growth: append
     int n0 = *f.n_ever;
     if (n0 + size > f.ever_cap) *f.overflow = 1;
     else { for (int i = lane; i < size; i += 64) f.ever[n0 + i] = f.reg[i]; *f.n_ever = n0 + size; }
     wave_mem_order();
     if (*f.overflow) return false;
+  }
   }
   if (size < 2) return false;
   d_region2rect(f, size, reg_angle, prec, p, 0, rec);
@@ -773,8 +786,7 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
   const uint32_t *seeds = b.seeds + fidx * NM;
   double *segs = b.segs + (size_t)fidx * c.seg_cap * LF_SEG_STRIDE;
   const int nseeds = b.nseeds[fidx];
-  u64 n_grow = 0, n_steps = 0, n_nfa = 0, n_px = 0, n_regpx = 0, cyc_grow = 0, cyc_imp = 0, cyc_r2r = 0;
-  const u64 cyc0 = __builtin_readcyclecounter();
+  u64 n_grow = 0, n_steps = 0, n_nfa = 0, n_px = 0, n_regpx = 0;
   int ls_count = 0;
   int s = 0;
   while (s < nseeds) {
@@ -790,23 +802,13 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
     int sx = sa % c.N, sy = sa / c.N;
     double reg_angle;
     ++n_grow;
-    u64 t0 = __builtin_readcyclecounter();
     int reg_size = d_region_grow(f, sx, sy, c.prec, c.cos_prec, &reg_angle, &n_steps);
-    cyc_grow += __builtin_readcyclecounter() - t0;
     n_regpx += (u64)reg_size;
     if (reg_size < c.min_reg_size) continue;
     Rect rec;
-    t0 = __builtin_readcyclecounter();
     d_region2rect(f, reg_size, reg_angle, c.prec, c.p, 0, &rec);
-    cyc_r2r += __builtin_readcyclecounter() - t0;
-    t0 = __builtin_readcyclecounter();
-    bool refined_ok = d_refine(f, &reg_size, reg_angle, c.prec, c.p, &rec, c.density_th, &n_steps);
-    cyc_r2r += __builtin_readcyclecounter() - t0;
-    if (!refined_ok) continue;
-    if (false && !d_refine(f, &reg_size, reg_angle, c.prec, c.p, &rec, c.density_th, &n_steps)) continue;
-    t0 = __builtin_readcyclecounter();
+    if (!d_refine(f, &reg_size, reg_angle, c.prec, c.p, &rec, c.density_th, &n_steps)) continue;
     double log_nfa = d_rect_improve(f, &rec, c.logNT, c.eps, &n_nfa, &n_px);
-    cyc_imp += __builtin_readcyclecounter() - t0;
     if (log_nfa <= c.eps) continue;
     ++ls_count;
     rec.x1 += 0.5; rec.y1 += 0.5;
@@ -833,8 +835,7 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
     if (b.stats) {
       unsigned long long *st = b.stats + (size_t)fidx * 8;
       st[0] = n_grow; st[1] = n_steps; st[2] = n_nfa; st[3] = n_px; st[4] = n_regpx;
-      st[5] = __builtin_readcyclecounter() - cyc0; st[6] = cyc_grow; st[7] = cyc_imp; (void)cyc_r2r;
-      st[3] = cyc_r2r;   /* slot 3 repurposed: cycles in region2rect + refine */
+      st[5] = (u64)nseeds; st[6] = 0; st[7] = 0;
     }
   }
 }
@@ -859,7 +860,8 @@ struct SweepCtl {
 };
 struct RegionResult { int reg_size; int accepted; Rect rec; };
 
-__device__ void mw_process(const FrameView &f, const LsdConsts &c, int sx, int sy, RegionResult *out,
+template <class FV>
+__device__ __noinline__ void mw_process(const FV &f, const LsdConsts &c, int sx, int sy, RegionResult *out,
                            u64 *n_steps, u64 *n_nfa, u64 *n_px) {
   double reg_angle;
   out->accepted = 0;
@@ -888,7 +890,7 @@ __global__ void __launch_bounds__(W * 64) k_lsd_sweep_mw(LsdConsts c, const LsdC
   const size_t NM = (size_t)c.N * c.M;
   if (threadIdx.x == 0) { ctl.lock = 0; ctl.scan = 0; ctl.next_ticket = 0; ctl.frontier = 0; ctl.ls_count = 0; ctl.done = 0; }
   __syncthreads();
-  FrameView f;
+  FrameViewMW f;
   f.N = c.N; f.M = c.M; f.lane = lane;
   f.angles = b.angles + fidx * NM;
   f.modgrad = b.modgrad + fidx * NM;
