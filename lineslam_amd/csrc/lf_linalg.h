@@ -149,4 +149,69 @@ LF_HD int lf_inv3(const double *A, double *Ainv) {
   return 1;
 }
 
+
+/* ---------------------------------------------------------------- 3x3 singular value decomposition
+ * One-sided (Hestenes) Jacobi: A = U diag(sg) V^T, sg descending, for a general 3x3 row-major A.
+ * Stands in for Eigen::JacobiSVD<Matrix3f> inside pcl::TransformationFromCorrespondences
+ * (src/line/motion.cpp:540-578).  A (numerically) zero singular value gets its left vector from the
+ * cross product of the other two, which is what the reflection fix of the Kabsch step needs. */
+LF_HD void lf_svd3(const double *A, double *U, double *sg, double *V) {
+  double W[9];
+  int i, j, k, sweep, p, q;
+  for (i = 0; i < 9; i++) { W[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  for (sweep = 0; sweep < 30; sweep++) {
+    int rotated = 0;
+    for (p = 0; p < 2; p++)
+      for (q = p + 1; q < 3; q++) {
+        double al = 0, be = 0, ga = 0;
+        for (k = 0; k < 3; k++) { al += W[3 * k + p] * W[3 * k + p]; be += W[3 * k + q] * W[3 * k + q]; ga += W[3 * k + p] * W[3 * k + q]; }
+        if (ga == 0.0 || ga * ga <= 1e-30 * al * be) continue;
+        {
+          double zeta = (be - al) / (2.0 * ga);
+          double t = 1.0 / (lf_fabs(zeta) + lf_sqrt(1.0 + zeta * zeta));
+          double c, sn;
+          if (zeta < 0.0) t = -t;
+          c = 1.0 / lf_sqrt(1.0 + t * t);
+          sn = c * t;
+          rotated = 1;
+          for (k = 0; k < 3; k++) {
+            double wp = W[3 * k + p], wq = W[3 * k + q], vp = V[3 * k + p], vq = V[3 * k + q];
+            W[3 * k + p] = c * wp - sn * wq; W[3 * k + q] = sn * wp + c * wq;
+            V[3 * k + p] = c * vp - sn * vq; V[3 * k + q] = sn * vp + c * vq;
+          }
+        }
+      }
+    if (!rotated) break;
+  }
+  for (j = 0; j < 3; j++) sg[j] = lf_sqrt(W[j] * W[j] + W[3 + j] * W[3 + j] + W[6 + j] * W[6 + j]);
+  for (i = 0; i < 2; i++)            /* stable bubble sort of the columns, descending */
+    for (j = 0; j < 2 - i; j++)
+      if (sg[j] < sg[j + 1]) {
+        double t = sg[j]; sg[j] = sg[j + 1]; sg[j + 1] = t;
+        for (k = 0; k < 3; k++) {
+          double tw = W[3 * k + j], tv = V[3 * k + j];
+          W[3 * k + j] = W[3 * k + j + 1]; W[3 * k + j + 1] = tw;
+          V[3 * k + j] = V[3 * k + j + 1]; V[3 * k + j + 1] = tv;
+        }
+      }
+  for (j = 0; j < 3; j++)
+    for (k = 0; k < 3; k++) U[3 * k + j] = (sg[j] > 0.0) ? W[3 * k + j] / sg[j] : 0.0;
+  if (!(sg[2] > 1e-12 * sg[0])) {     /* rank <= 2: complete U by the cross product */
+    if (!(sg[1] > 1e-12 * sg[0])) {   /* rank <= 1: any unit vector orthogonal to u0 */
+      double ax = lf_fabs(U[0]), ay = lf_fabs(U[3]), az = lf_fabs(U[6]);
+      double e0 = (ax <= ay && ax <= az) ? 1.0 : 0.0, e1 = (e0 == 0.0 && ay <= az) ? 1.0 : 0.0, e2 = (e0 == 0.0 && e1 == 0.0) ? 1.0 : 0.0;
+      double d = e0 * U[0] + e1 * U[3] + e2 * U[6], n;
+      double v0 = e0 - d * U[0], v1 = e1 - d * U[3], v2 = e2 - d * U[6];
+      n = lf_sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+      U[1] = v0 / n; U[4] = v1 / n; U[7] = v2 / n;
+    }
+    U[2] = U[3] * U[7] - U[6] * U[4];
+    U[5] = U[6] * U[1] - U[0] * U[7];
+    U[8] = U[0] * U[4] - U[3] * U[1];
+  }
+}
+LF_HD double lf_det3(const double *M) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
 #endif /* LF_LINALG_H */

@@ -360,4 +360,207 @@ LF_HD void lf_older_pose_to_tf(const lf_se3 *X, float *tf) {
   tf[12] = 0.0f; tf[13] = 0.0f; tf[14] = 0.0f; tf[15] = 1.0f;
 }
 
+
+/* ================================================================ point features (config 3)
+ * Point side of getTransform_PtsLines_ransac: the caller supplies Node::feature_locations_3d_
+ * (Eigen::Vector4f x,y,z,1; z = NaN without depth, src/node.cpp:952-1018) and the point matches.     */
+typedef struct {
+  double raster_cov_x, raster_cov_y;   /* (3 tan(58deg/640))^2, (3 tan(45deg/480))^2: misc.cpp:704-711, host libm */
+  double sigma_depth;                  /* ParameterServer "sigma_depth" 0.01 (misc2.h:20-35) */
+} lf_point_model;
+
+LF_HD double lf_depth_covariance(double depth, double sigma_depth) {   /* misc2.h:20-35 */
+  double sd = sigma_depth * depth * depth;
+  return sd * sd;
+}
+/* errorFunction2 (src/misc.cpp:699-786): squared Mahalanobis distance of a point match under tf (query
+ * -> train, the float matrix cast to double), with the isotropic-bound shortcut.  x1 = query point,
+ * x2 = train point (4 floats each).  DBL_MAX = "certainly not an inlier".                          */
+LF_HD double lf_error_function2(const float *x1, const float *x2, const float *tf, const lf_point_model *pm) {
+  const double BIG = 1.7976931348623157e308;
+  double T[16], mu1[3], mu2[3], m12[3], d[3], R[9], cov1[3], cov2[3], S[9], rhs[3], q;
+  int r, c, k;
+  if (x1[2] != x1[2] || x2[2] != x2[2]) return BIG;
+  for (k = 0; k < 16; k++) T[k] = (double)tf[k];
+  for (k = 0; k < 3; k++) { mu1[k] = (double)x1[k]; mu2[k] = (double)x2[k]; }
+  for (r = 0; r < 3; r++) m12[r] = ((T[4 * r] * mu1[0] + T[4 * r + 1] * mu1[1]) + T[4 * r + 2] * mu1[2]) + T[4 * r + 3] * (double)x1[3];
+  for (k = 0; k < 3; k++) d[k] = m12[k] - mu2[k];
+  {
+    double dsq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    double s1 = lf_depth_covariance(mu1[2], pm->sigma_depth), s2 = lf_depth_covariance(mu2[2], pm->sigma_depth);
+    if (s1 < pm->raster_cov_x) s1 = pm->raster_cov_x;
+    if (s2 < pm->raster_cov_x) s2 = pm->raster_cov_x;
+    if (dsq > 2.0 * (s1 + s2)) return BIG;
+  }
+  for (r = 0; r < 3; r++) for (c = 0; c < 3; c++) R[3 * r + c] = T[4 * r + c];
+  cov1[0] = 1 * pm->raster_cov_x * mu1[2]; cov1[1] = 1 * pm->raster_cov_y * mu1[2]; cov1[2] = lf_depth_covariance(mu1[2], pm->sigma_depth);
+  cov2[0] = 1 * pm->raster_cov_x * mu2[2]; cov2[1] = 1 * pm->raster_cov_y * mu2[2]; cov2[2] = lf_depth_covariance(mu2[2], pm->sigma_depth);
+  /* cov1_in_frame_2 = R^T cov1 R  (as written at misc.cpp:765), then + cov2 */
+  for (r = 0; r < 3; r++)
+    for (c = 0; c < 3; c++) {
+      double s = 0;
+      for (k = 0; k < 3; k++) s += (R[3 * k + r] * cov1[k]) * R[3 * k + c];
+      S[3 * r + c] = s + ((r == c) ? cov2[r] : 0.0);
+    }
+  if (d[2] != d[2]) d[2] = 0.0;
+  for (k = 0; k < 3; k++) rhs[k] = d[k];
+  if (!lf_solve3(S, rhs, 1)) return BIG;          /* Eigen LDLT solve in the reference */
+  q = d[0] * rhs[0] + d[1] * rhs[1] + d[2] * rhs[2];
+  if (!(q >= 0.0)) return BIG;
+  return q;
+}
+
+/* projectPt3d2Ln3d_2 (utils.cpp:506-512) */
+LF_HD void lf_project_pt_line(const double *P, const double *A, const double *B, double *out) {
+  double AB[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, AP[3] = {P[0] - A[0], P[1] - A[1], P[2] - A[2]};
+  double s = (AB[0] * AP[0] + AB[1] * AP[1] + AB[2] * AP[2]) / (AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2]);
+  out[0] = A[0] + s * AB[0]; out[1] = A[1] + s * AB[1]; out[2] = A[2] + s * AB[2];
+}
+
+/* pcl::TransformationFromCorrespondences (PCL 1.7 common/transformation_from_correspondences.hpp), float
+ * accumulators as in PCL; the final 3x3 SVD in double (lf_svd3).                                    */
+typedef struct { int n; float wsum; float m1[3], m2[3], cov[9]; } lf_tfc;
+LF_HD void lf_tfc_reset(lf_tfc *t) { int i; t->n = 0; t->wsum = 0.0f; for (i = 0; i < 3; i++) t->m1[i] = t->m2[i] = 0.0f; for (i = 0; i < 9; i++) t->cov[i] = 0.0f; }
+LF_HD void lf_tfc_add(lf_tfc *t, const float *from, const float *to, float w) {
+  float alpha, d1[3], d2[3];
+  int r, c;
+  if (w == 0.0f) return;
+  ++t->n;
+  t->wsum += w;
+  alpha = w / t->wsum;
+  for (r = 0; r < 3; r++) { d1[r] = from[r] - t->m1[r]; d2[r] = to[r] - t->m2[r]; }
+  for (r = 0; r < 3; r++) for (c = 0; c < 3; c++) t->cov[3 * r + c] = (1.0f - alpha) * (t->cov[3 * r + c] + alpha * (d2[r] * d1[c]));
+  for (r = 0; r < 3; r++) { t->m1[r] += alpha * d1[r]; t->m2[r] += alpha * d2[r]; }
+}
+LF_HD void lf_tfc_get(const lf_tfc *t, float *tf) {
+  double C[9], U[9], sg[3], V[9], R[9], s22 = 1.0;
+  int r, c, k;
+  for (k = 0; k < 9; k++) C[k] = (double)t->cov[k];
+  lf_svd3(C, U, sg, V);
+  if (lf_det3(U) * lf_det3(V) < 0.0) s22 = -1.0;
+  for (r = 0; r < 3; r++) for (c = 0; c < 3; c++) R[3 * r + c] = (U[3 * r] * V[3 * c] + U[3 * r + 1] * V[3 * c + 1]) + s22 * U[3 * r + 2] * V[3 * c + 2];
+  for (r = 0; r < 3; r++) {
+    float rf[3] = {(float)R[3 * r], (float)R[3 * r + 1], (float)R[3 * r + 2]};
+    tf[4 * r] = rf[0]; tf[4 * r + 1] = rf[1]; tf[4 * r + 2] = rf[2];
+    tf[4 * r + 3] = t->m2[r] - ((rf[0] * t->m1[0] + rf[1] * t->m1[1]) + rf[2] * t->m1[2]);
+  }
+  tf[12] = tf[13] = tf[14] = 0.0f; tf[15] = 1.0f;
+}
+
+/* compPt3dCov, Eigen overload (utils.cpp:724-745), used for the information of point edges
+ * (transformation_estimation.cpp:267,283): Matrix3f covariance, cast to double, inverted.          */
+LF_HD int lf_point_information(const float *pt, double f, double sig_px, double c1, double c2, double c3, double *info) {
+  double x = (double)pt[0], y = (double)pt[1], z = (double)pt[2];
+  double sz = c1 * z * z + c2 * z + c3, s2 = sig_px * sig_px, sz2 = sz * sz;
+  double j00 = z / f, j02 = x / z, j11 = z / f, j12 = y / z, C[9];
+  int k;
+  C[0] = (j00 * s2) * j00 + (j02 * sz2) * j02; C[1] = (j02 * sz2) * j12; C[2] = (j02 * sz2);
+  C[3] = (j12 * sz2) * j02; C[4] = (j11 * s2) * j11 + (j12 * sz2) * j12; C[5] = (j12 * sz2);
+  C[6] = sz2 * j02; C[7] = sz2 * j12; C[8] = sz2;
+  for (k = 0; k < 9; k++) C[k] = (double)(float)C[k];        /* Eigen::Matrix3f, then .cast<double>() */
+  return lf_inv3(C, info);
+}
+
+/* One point match of the refinement graph: landmark p (3), newer measurement mn with information In,
+ * older measurement mo with information Io (EdgeSE3PointXYZ::computeError, edge_se3_ptxyz.cpp:84-90).  */
+typedef struct { const double *mn, *mo, *In, *Io; } lf_point_meas;
+typedef struct { double V[9], W[18], bl[3], Hpp[36], bp[6]; } lf_point_blocks;
+
+LF_HD void lf_ptmatch_errors(const lf_se3 *X, const double *p, const lf_point_meas *m, double *en, double *eo) {
+  double q[3];
+  int k;
+  for (k = 0; k < 3; k++) en[k] = p[k] - m->mn[k];
+  lf_se3_inv_apply(X, p, q);
+  for (k = 0; k < 3; k++) eo[k] = q[k] - m->mo[k];
+}
+LF_HD double lf_quad3(const double *e, const double *I) {
+  double t0 = I[0] * e[0] + I[1] * e[1] + I[2] * e[2], t1 = I[3] * e[0] + I[4] * e[1] + I[5] * e[2], t2 = I[6] * e[0] + I[7] * e[1] + I[8] * e[2];
+  return e[0] * t0 + e[1] * t1 + e[2] * t2;
+}
+LF_HD double lf_ptmatch_chi2(const lf_se3 *X, const double *p, const lf_point_meas *m, double hdelta, int huber) {
+  double en[3], eo[3], r0, r1, s;
+  lf_ptmatch_errors(X, p, m, en, eo);
+  lf_huber(lf_quad3(en, m->In), hdelta, huber, &r0, &r1);
+  s = r0;
+  lf_huber(lf_quad3(eo, m->Io), hdelta, huber, &r0, &r1);
+  return s + r0;
+}
+LF_HD void lf_ptmatch_blocks(const lf_se3 *X, const double *p, const lf_point_meas *m, double hdelta, int huber,
+                             lf_point_blocks *B) {
+  const double delta = 1e-9, scalar = 1.0 / (2 * 1e-9);
+  double en[3], eo[3], Jn[9], Jo[9], Jp[18], wn, wo, r0, On[9], Oo[9], One[3], Ooe[3];
+  int d, i, j, k;
+  lf_ptmatch_errors(X, p, m, en, eo);
+  for (d = 0; d < 3; d++) {
+    double pp[3], a[3], b[3], a2[3], b2[3];
+    for (i = 0; i < 3; i++) pp[i] = p[i];
+    pp[d] = p[d] + delta; lf_ptmatch_errors(X, pp, m, a, a2);
+    pp[d] = p[d] - delta; lf_ptmatch_errors(X, pp, m, b, b2);
+    for (i = 0; i < 3; i++) { Jn[3 * i + d] = scalar * (a[i] - b[i]); Jo[3 * i + d] = scalar * (a2[i] - b2[i]); }
+  }
+  for (d = 0; d < 6; d++) {
+    double v[6], q[3], a[3], b[3];
+    lf_se3 Xp;
+    for (i = 0; i < 6; i++) v[i] = 0;
+    v[d] = delta; lf_se3_oplus(X, v, &Xp); lf_se3_inv_apply(&Xp, p, q); for (i = 0; i < 3; i++) a[i] = q[i] - m->mo[i];
+    v[d] = -delta; lf_se3_oplus(X, v, &Xp); lf_se3_inv_apply(&Xp, p, q); for (i = 0; i < 3; i++) b[i] = q[i] - m->mo[i];
+    for (i = 0; i < 3; i++) Jp[6 * i + d] = scalar * (a[i] - b[i]);
+  }
+  lf_huber(lf_quad3(en, m->In), hdelta, huber, &r0, &wn);
+  lf_huber(lf_quad3(eo, m->Io), hdelta, huber, &r0, &wo);
+  for (i = 0; i < 9; i++) { On[i] = wn * m->In[i]; Oo[i] = wo * m->Io[i]; }
+  for (i = 0; i < 3; i++) {
+    One[i] = On[3 * i] * en[0] + On[3 * i + 1] * en[1] + On[3 * i + 2] * en[2];
+    Ooe[i] = Oo[3 * i] * eo[0] + Oo[3 * i + 1] * eo[1] + Oo[3 * i + 2] * eo[2];
+  }
+  for (i = 0; i < 3; i++) {
+    double s1 = 0, s2 = 0;
+    for (k = 0; k < 3; k++) { s1 += Jn[3 * k + i] * One[k]; s2 += Jo[3 * k + i] * Ooe[k]; }
+    B->bl[i] = -(s1 + s2);
+  }
+  for (i = 0; i < 6; i++) { double s3 = 0; for (k = 0; k < 3; k++) s3 += Jp[6 * k + i] * Ooe[k]; B->bp[i] = -s3; }
+  {
+    double OJn[9], OJo[9], OJp[18];   /* Omega * J */
+    for (i = 0; i < 3; i++) {
+      for (j = 0; j < 3; j++) {
+        double a = 0, b = 0;
+        for (k = 0; k < 3; k++) { a += On[3 * i + k] * Jn[3 * k + j]; b += Oo[3 * i + k] * Jo[3 * k + j]; }
+        OJn[3 * i + j] = a; OJo[3 * i + j] = b;
+      }
+      for (j = 0; j < 6; j++) { double cc = 0; for (k = 0; k < 3; k++) cc += Oo[3 * i + k] * Jp[6 * k + j]; OJp[6 * i + j] = cc; }
+    }
+    for (i = 0; i < 3; i++)
+      for (j = 0; j < 3; j++) {
+        double a = 0, b = 0;
+        for (k = 0; k < 3; k++) { a += Jn[3 * k + i] * OJn[3 * k + j]; b += Jo[3 * k + i] * OJo[3 * k + j]; }
+        B->V[3 * i + j] = a + b;
+      }
+    for (i = 0; i < 6; i++) {
+      for (j = 0; j < 3; j++) { double a = 0; for (k = 0; k < 3; k++) a += Jp[6 * k + i] * OJo[3 * k + j]; B->W[3 * i + j] = a; }
+      for (j = 0; j < 6; j++) { double a = 0; for (k = 0; k < 3; k++) a += Jp[6 * k + i] * OJp[6 * k + j]; B->Hpp[6 * i + j] = a; }
+    }
+  }
+}
+LF_HD int lf_ptmatch_eliminate(const lf_point_blocks *B, double lambda, double *Vi, double *T, double *u) {
+  double A[9], WV[18];
+  int i, j, k;
+  for (i = 0; i < 9; i++) A[i] = B->V[i];
+  for (i = 0; i < 3; i++) A[4 * i] += lambda;
+  if (!lf_inv3(A, Vi)) return 0;
+  for (i = 0; i < 6; i++) for (j = 0; j < 3; j++) { double s = 0; for (k = 0; k < 3; k++) s += B->W[3 * i + k] * Vi[3 * k + j]; WV[3 * i + j] = s; }
+  for (i = 0; i < 6; i++) {
+    double s = 0;
+    for (k = 0; k < 3; k++) s += WV[3 * i + k] * B->bl[k];
+    u[i] = s;
+    for (j = 0; j < 6; j++) { double s2 = 0; for (k = 0; k < 3; k++) s2 += WV[3 * i + k] * B->W[3 * j + k]; T[6 * i + j] = s2; }
+  }
+  return 1;
+}
+LF_HD void lf_ptmatch_backsub(const lf_point_blocks *B, const double *Vi, const double *dp, double *dl) {
+  double r[3];
+  int i, k;
+  for (i = 0; i < 3; i++) { double s = 0; for (k = 0; k < 6; k++) s += B->W[3 * k + i] * dp[k]; r[i] = B->bl[i] - s; }
+  for (i = 0; i < 3; i++) dl[i] = Vi[3 * i] * r[0] + Vi[3 * i + 1] * r[1] + Vi[3 * i + 2] * r[2];
+}
+
 #endif /* LF_POSE_H */

@@ -103,33 +103,64 @@ int oracle_line_matching(const lf_line_record *f1, int n1, const lf_line_record 
 }
 
 /* ---------------------------------------------------------------------------------------------
- * getTransformFromHybridMatchesG2O, line edges only (transformation_estimation.cpp:218-461):
- * g2o Levenberg on {older camera pose, one 6-d landmark per match}; newer camera fixed at I.    */
+ * getTransformFromHybridMatchesG2O (transformation_estimation.cpp:218-461): g2o Levenberg on
+ * {older camera pose, one 3-d landmark per point match, one 6-d landmark per line match}; newer camera
+ * fixed at I.  Vertices/edges are created points first, then lines (:247-292, :322-440), and that is
+ * the order of every sum below.                                                                       */
+typedef struct { const float *train, *query; int n; const int *mq, *mt; } o_points;   /* xyz1 float4 arrays + matches */
+
 static void p_meas(const lf_line_record *train, const lf_line_record *query, int tq, int tt, lf_line_meas *m) {
   m->nA = query[tq].A; m->nB = query[tq].B; m->nMa = query[tq].DUa; m->nMb = query[tq].DUb;
   m->oA = train[tt].A; m->oB = train[tt].B; m->oMa = train[tt].DUa; m->oMb = train[tt].DUb;
 }
-int oracle_refine_g2o(const lf_line_record *train, const lf_line_record *query, const int *mq, const int *mt,
-                      int n, float *tf, int iterations, const lf_params *P, double *chi_out) {
+static void o_point_model(lf_point_model *pm) {   /* misc.cpp:704-711 + misc2.h:23 */
+  const double cam_angle_x = 58.0 / 180.0 * M_PI, cam_angle_y = 45.0 / 180.0 * M_PI;
+  double sx = 3 * tan(cam_angle_x / 640), sy = 3 * tan(cam_angle_y / 480);
+  pm->raster_cov_x = sx * sx; pm->raster_cov_y = sy * sy; pm->sigma_depth = 0.01;
+}
+
+int oracle_refine_hybrid(const lf_line_record *train, const lf_line_record *query, const int *mq, const int *mt,
+                         int n, const o_points *pp, int npt, const int *pq, const int *pt, double focal, float *tf,
+                         int iterations, const lf_params *P, double *chi_out) {
   lf_se3 X, Xn;
   double *L = (double *)malloc(sizeof(double) * 6 * (size_t)(n + 1)), *Ln = (double *)malloc(sizeof(double) * 6 * (size_t)(n + 1));
   lf_line_meas *M = (lf_line_meas *)malloc(sizeof(lf_line_meas) * (size_t)(n + 1));
   lf_line_blocks *B = (lf_line_blocks *)malloc(sizeof(lf_line_blocks) * (size_t)(n + 1));
   double *Vi = (double *)malloc(sizeof(double) * 36 * (size_t)(n + 1));
+  /* points */
+  double *Pp = (double *)malloc(sizeof(double) * 3 * (size_t)(npt + 1)), *Pn = (double *)malloc(sizeof(double) * 3 * (size_t)(npt + 1));
+  double *PM = (double *)malloc(sizeof(double) * 24 * (size_t)(npt + 1));   /* mn(3) mo(3) In(9) Io(9) */
+  lf_point_meas *Pm = (lf_point_meas *)malloc(sizeof(lf_point_meas) * (size_t)(npt + 1));
+  lf_point_blocks *PB = (lf_point_blocks *)malloc(sizeof(lf_point_blocks) * (size_t)(npt + 1));
+  double *PVi = (double *)malloc(sizeof(double) * 9 * (size_t)(npt + 1));
   double lambda = 0, ni = 2, currentChi = 0, wgt = P->g2o_line_error_weight, hd = P->g2o_BA_kernel_delta;
   int hub = P->g2o_BA_use_kernel, it, k, i, done_iters = 0;
   lf_tf_to_older_pose(tf, &X);
+  for (k = 0; k < npt; k++) {   /* :247-292 */
+    const float *qn = pp->query + 4 * (size_t)pq[k], *qo = pp->train + 4 * (size_t)pt[k];
+    double *m = PM + 24 * (size_t)k;
+    for (i = 0; i < 3; i++) { m[i] = (double)qn[i]; m[3 + i] = (double)qo[i]; Pp[3 * k + i] = (double)qn[i]; }
+    lf_point_information(qn, focal, P->stdev_sample_pt_imgline, P->depth_stdev_coeff_c1, P->depth_stdev_coeff_c2 + 0.0 * 0.5, P->depth_stdev_coeff_c3, m + 6);
+    lf_point_information(qo, focal, P->stdev_sample_pt_imgline, P->depth_stdev_coeff_c1, P->depth_stdev_coeff_c2 + 0.0 * 0.5, P->depth_stdev_coeff_c3, m + 15);
+    Pm[k].mn = m; Pm[k].mo = m + 3; Pm[k].In = m + 6; Pm[k].Io = m + 15;
+  }
   for (k = 0; k < n; k++) {
     p_meas(train, query, mq[k], mt[k], &M[k]);
     for (i = 0; i < 3; i++) { L[6 * k + i] = query[mq[k]].A[i]; L[6 * k + 3 + i] = query[mq[k]].B[i]; }   /* :326-328 */
   }
-  for (it = 0; it < iterations && n > 0; it++) {
+  for (it = 0; it < iterations && (n + npt) > 0; it++) {
     double Hpp[36], bp[6], rho = 0, tempChi;
     int qmax = 0;
     currentChi = 0;
+    for (k = 0; k < npt; k++) currentChi += lf_ptmatch_chi2(&X, &Pp[3 * k], &Pm[k], hd, hub);
     for (k = 0; k < n; k++) currentChi += lf_match_chi2(&X, &L[6 * k], &M[k], wgt, hd, hub);
     for (i = 0; i < 36; i++) Hpp[i] = 0;
     for (i = 0; i < 6; i++) bp[i] = 0;
+    for (k = 0; k < npt; k++) {
+      lf_ptmatch_blocks(&X, &Pp[3 * k], &Pm[k], hd, hub, &PB[k]);
+      for (i = 0; i < 36; i++) Hpp[i] += PB[k].Hpp[i];
+      for (i = 0; i < 6; i++) bp[i] += PB[k].bp[i];
+    }
     for (k = 0; k < n; k++) {
       lf_match_blocks(&X, &L[6 * k], &M[k], wgt, hd, hub, &B[k]);
       for (i = 0; i < 36; i++) Hpp[i] += B[k].Hpp[i];
@@ -138,6 +169,7 @@ int oracle_refine_g2o(const lf_line_record *train, const lf_line_record *query, 
     if (it == 0) {   /* computeLambdaInit: tau * max |diagonal| */
       double mx = 0;
       for (i = 0; i < 6; i++) if (fabs(Hpp[7 * i]) > mx) mx = fabs(Hpp[7 * i]);
+      for (k = 0; k < npt; k++) for (i = 0; i < 3; i++) if (fabs(PB[k].V[4 * i]) > mx) mx = fabs(PB[k].V[4 * i]);
       for (k = 0; k < n; k++) for (i = 0; i < 6; i++) if (fabs(B[k].V[7 * i]) > mx) mx = fabs(B[k].V[7 * i]);
       lambda = 1e-5 * mx;
       ni = 2;
@@ -147,7 +179,13 @@ int oracle_refine_g2o(const lf_line_record *train, const lf_line_record *query, 
       int ok2 = 1;
       for (i = 0; i < 36; i++) S[i] = Hpp[i];
       for (i = 0; i < 6; i++) { S[7 * i] += lambda; g[i] = bp[i]; }
-      for (k = 0; k < n; k++) {
+      for (k = 0; k < npt && ok2; k++) {
+        double T[36], u[6];
+        if (!lf_ptmatch_eliminate(&PB[k], lambda, &PVi[9 * k], T, u)) { ok2 = 0; break; }
+        for (i = 0; i < 36; i++) S[i] -= T[i];
+        for (i = 0; i < 6; i++) g[i] -= u[i];
+      }
+      for (k = 0; k < n && ok2; k++) {
         double T[36], u[6];
         if (!lf_match_eliminate(&B[k], lambda, &Vi[36 * k], T, u)) { ok2 = 0; break; }
         for (i = 0; i < 36; i++) S[i] -= T[i];
@@ -159,12 +197,19 @@ int oracle_refine_g2o(const lf_line_record *train, const lf_line_record *query, 
         lf_se3_oplus(&X, dp, &Xn);
         for (i = 0; i < 6; i++) scale += dp[i] * (lambda * dp[i] + bp[i]);
         tempChi = 0;
+        for (k = 0; k < npt; k++) {
+          double dl[3], sk = 0;
+          lf_ptmatch_backsub(&PB[k], &PVi[9 * k], dp, dl);
+          for (i = 0; i < 3; i++) { Pn[3 * k + i] = Pp[3 * k + i] + dl[i]; sk += dl[i] * (lambda * dl[i] + PB[k].bl[i]); }
+          scale += sk;
+        }
         for (k = 0; k < n; k++) {
           double dl[6], sk = 0;
           lf_match_backsub(&B[k], &Vi[36 * k], dp, dl);
           for (i = 0; i < 6; i++) { Ln[6 * k + i] = L[6 * k + i] + dl[i]; sk += dl[i] * (lambda * dl[i] + B[k].bl[i]); }
           scale += sk;
         }
+        for (k = 0; k < npt; k++) tempChi += lf_ptmatch_chi2(&Xn, &Pn[3 * k], &Pm[k], hd, hub);
         for (k = 0; k < n; k++) tempChi += lf_match_chi2(&Xn, &Ln[6 * k], &M[k], wgt, hd, hub);
       }
       rho = (currentChi - tempChi);
@@ -179,6 +224,7 @@ int oracle_refine_g2o(const lf_line_record *train, const lf_line_record *query, 
         currentChi = tempChi;
         X = Xn;
         memcpy(L, Ln, sizeof(double) * 6 * (size_t)n);
+        memcpy(Pp, Pn, sizeof(double) * 3 * (size_t)npt);
       } else {
         lambda *= ni;
         ni *= 2;
@@ -190,102 +236,175 @@ int oracle_refine_g2o(const lf_line_record *train, const lf_line_record *query, 
   }
   lf_older_pose_to_tf(&X, tf);
   if (chi_out) *chi_out = currentChi;
-  free(L); free(Ln); free(M); free(B); free(Vi);
+  free(L); free(Ln); free(M); free(B); free(Vi); free(Pp); free(Pn); free(PM); free(Pm); free(PB); free(PVi);
   return done_iters;
 }
 
-/* getTransform_PtsLines_ransac with nPt = 0 (motion.cpp:605-849).
- *   train = older node, query = newer node; (mq, mt)[nLn] = all line matches (queryIdx, trainIdx)
- *   tf_out: 4x4 row-major float, query -> train;  inl[]: indices into the match list
- * returns 1 if enough inliers (the function's bool), 0 otherwise.                                 */
-int oracle_pose_lines_ransac(const lf_line_record *train, const lf_line_record *query, const int *mq,
-                             const int *mt, int nLn, int id_train, int id_query, const lf_params *P,
-                             uint64_t stream, float *tf_out, float *rmse_out, int *inl, int *n_inl,
-                             int *dbg /* [4]: best ransac iter, best count, refine rounds, 0 */) {
+/* getTransform_Lns_Pts_pcl (motion.cpp:530-579): mixed minimal sample -> weighted Kabsch.  The random
+ * point each sampled line is paired with: draw index (1<<20) + 3*iteration + position in the line list. */
+static int o_lns_pts_pcl(const lf_line_record *train, const lf_line_record *query, const o_points *pp,
+                         const int *spq, const int *spt, int nsp, const int *slq, const int *slt, int nsl,
+                         const lf_params *P, uint64_t stream, int iter, float *tf) {
+  lf_tfc t;
+  int i, k;
+  if (nsp < 1 || nsp + nsl < 3) return 0;
+  lf_tfc_reset(&t);
+  for (i = 0; i < nsl; ++i) {
+    int ptidx = (int)(lf_rand31(P->rng_seed, stream, (1ull << 20) + 3ull * (uint64_t)iter + (uint64_t)i) % (uint32_t)nsp);
+    const float *tp = pp->train + 4 * (size_t)spt[ptidx], *qp = pp->query + 4 * (size_t)spq[ptidx];
+    double tpd[3] = {tp[0], tp[1], tp[2]}, qpd[3] = {qp[0], qp[1], qp[2]}, tprj[3], qprj[3];
+    float from[3], to[3], w;
+    lf_project_pt_line(tpd, train[slt[i]].A, train[slt[i]].B, tprj);
+    lf_project_pt_line(qpd, query[slq[i]].A, query[slq[i]].B, qprj);
+    for (k = 0; k < 3; k++) { from[k] = (float)qprj[k]; to[k] = (float)tprj[k]; }
+    if (from[2] != from[2] || to[2] != to[2]) continue;
+    w = 1 / (fabsf(to[2]) + fabsf(from[2]));
+    lf_tfc_add(&t, from, to, w);
+  }
+  for (i = 0; i < nsp; ++i) {
+    const float *from = pp->query + 4 * (size_t)spq[i], *to = pp->train + 4 * (size_t)spt[i];
+    float w;
+    if (from[2] != from[2] || to[2] != to[2]) continue;
+    w = 1 / (fabsf(to[2]) + fabsf(from[2]));
+    lf_tfc_add(&t, from, to, w);
+  }
+  if (t.n < 3) return 0;
+  lf_tfc_get(&t, tf);
+  return 1;
+}
+
+static int o_score(const lf_line_record *train, const lf_line_record *query, const o_points *pp, int nPt,
+                   const int *pq, const int *ptm, const int *mq, const int *mt, int nLn, const float *tf,
+                   const lf_point_model *pm, double thr, int *pset, int *npin, int *lset, int *nlin,
+                   float *sse_f, double *sse_d) {
+  int i, np = 0, nl = 0;
+  float sf = 0; double sd = 0;
+  for (i = 0; i < nPt; ++i) {
+    double m = lf_error_function2(pp->query + 4 * (size_t)pq[i], pp->train + 4 * (size_t)ptm[i], tf, pm);
+    if (m < thr * thr) { pset[np++] = i; sf += m; sd += m; }
+  }
+  for (i = 0; i < nLn; ++i) {
+    double add;
+    if (lf_line_inlier(tf, query[mq[i]].A, query[mq[i]].B, train[mt[i]].A, train[mt[i]].B, train[mt[i]].DUa,
+                       train[mt[i]].DUb, thr, &add)) { lset[nl++] = i; sf += add; sd += add; }
+  }
+  *npin = np; *nlin = nl; *sse_f = sf; *sse_d = sd;
+  return np + nl;
+}
+
+/* getTransform_PtsLines_ransac (motion.cpp:605-849).  train = older node, query = newer node.
+ *   point matches (pq, ptm)[nPt] into the float4 arrays of `pp`; line matches (mq, mt)[nLn]
+ *   tf_out: 4x4 row-major float, query -> train;  pinl / linl: indices into the two match lists        */
+int oracle_pose_hybrid_ransac(const lf_line_record *train, const lf_line_record *query, const float *train_pts,
+                              const float *query_pts, const int *pq, const int *ptm, int nPt, const int *mq,
+                              const int *mt, int nLn, int id_train, int id_query, double focal, const lf_params *P,
+                              uint64_t stream, float *tf_out, float *rmse_out, int *pinl, int *n_pinl, int *linl,
+                              int *n_linl, int *dbg) {
   int min_inlier = P->min_feature_matches, lw = P->line_match_number_weight, maxIter = P->ransac_iters_line_motion;
   double thr = P->max_mah_dist_for_inliers;
-  int *indexes, *best_set, *cur_set, *ref_set, nbest = 0, nref = 0, iter, i, best_iter = -1, rounds = 0;
+  int nTot = nPt + nLn, *indexes, *bp, *bl, *cp, *cl, *rp, *rl, nbp = 0, nbl = 0, nrp = 0, nrl = 0, iter, i, best_iter = -1, rounds = 0;
   float tf_best[16], sse_best = 1e9f, refined_tf[16];
   double refined_rmse;
   uint64_t ctr = 0;
   int idd = id_train - id_query;
-  *n_inl = 0;
+  o_points pp;
+  lf_point_model pm;
+  pp.train = train_pts; pp.query = query_pts;
+  o_point_model(&pm);
+  *n_pinl = 0; *n_linl = 0;
   for (i = 0; i < 16; i++) tf_out[i] = (i % 5 == 0) ? 1.0f : 0.0f;
   if (dbg) dbg[0] = dbg[1] = dbg[2] = dbg[3] = 0;
-  if (0 + nLn * lw < min_inlier) { *rmse_out = 1e9f; return 0; }                           /* :621-624 */
-  if (min_inlier > 0.7 * (0 + nLn * lw)) min_inlier = (int)(0.7 * (0 + nLn * lw));          /* :626-628 */
-  if ((idd < 0 ? -idd : idd) > 50) min_inlier = P->min_matches_loopclose;                   /* :631-633 */
-  if (nLn < 3) { *rmse_out = 1e9f; return 0; }   /* random_unique(3) needs 3 elements; the reference would read out of range */
-  indexes = (int *)malloc(sizeof(int) * (size_t)nLn * 4);
-  best_set = indexes + nLn; cur_set = best_set + nLn; ref_set = cur_set + nLn;
-  for (i = 0; i < nLn; i++) indexes[i] = i;
+  if (nPt + nLn * lw < min_inlier) { *rmse_out = 1e9f; return 0; }                          /* :621-624 */
+  if (min_inlier > 0.7 * (nPt + nLn * lw)) min_inlier = (int)(0.7 * (nPt + nLn * lw));       /* :626-628 */
+  if ((idd < 0 ? -idd : idd) > 50) min_inlier = P->min_matches_loopclose;                    /* :631-633 */
+  if (nTot < 3) { *rmse_out = 1e9f; return 0; }   /* random_unique(3) needs 3 elements; the reference would read out of range */
+  indexes = (int *)malloc(sizeof(int) * (size_t)nTot * 8);
+  bp = indexes + nTot; bl = bp + nTot; cp = bl + nTot; cl = cp + nTot; rp = cl + nTot; rl = rp + nTot;
+  for (i = 0; i < nTot; i++) indexes[i] = i;
   for (iter = 0; iter < maxIter; iter++) {
-    double la[18], lb[18], R[9], t[3];
-    float tf[16], sse = 0;
-    int nc = 0, b = 0, left = nLn, s;
+    float tf[16], sse_f; double sse_d;
+    int ncp, ncl, b = 0, left = nTot, s, spq[3], spt[3], slq[3], slt[3], nsp = 0, nsl = 0, valid;
     for (s = 0; s < 3; s++) {   /* random_unique(indexes, 3) */
       int r = b + (int)(lf_rand31(P->rng_seed, stream, ctr++) % (uint32_t)left);
       int tmp = indexes[b]; indexes[b] = indexes[r]; indexes[r] = tmp;
       ++b; --left;
     }
-    for (s = 0; s < 3; s++) {   /* getTransform_Line_svd: computeRelativeMotion_svd(query, train) */
-      int k = indexes[s], c;
-      for (c = 0; c < 3; c++) {
-        la[6 * s + c] = query[mq[k]].A[c]; la[6 * s + 3 + c] = query[mq[k]].B[c];
-        lb[6 * s + c] = train[mt[k]].A[c]; lb[6 * s + 3 + c] = train[mt[k]].B[c];
-      }
+    for (s = 0; s < 3; s++) {
+      if (indexes[s] < nPt) { spq[nsp] = pq[indexes[s]]; spt[nsp] = ptm[indexes[s]]; nsp++; }
+      else { slq[nsl] = mq[indexes[s] - nPt]; slt[nsl] = mt[indexes[s] - nPt]; nsl++; }
     }
-    if (!lf_rel_motion_lines(la, lb, 3, R, t)) continue;
-    for (i = 0; i < 3; i++) { int c; for (c = 0; c < 3; c++) tf[4 * i + c] = (float)R[3 * i + c]; tf[4 * i + 3] = (float)t[i]; }
-    tf[12] = tf[13] = tf[14] = 0.0f; tf[15] = 1.0f;
-    for (i = 0; i < nLn; ++i) {
-      double add;
-      if (lf_line_inlier(tf, query[mq[i]].A, query[mq[i]].B, train[mt[i]].A, train[mt[i]].B, train[mt[i]].DUa,
-                         train[mt[i]].DUb, thr, &add)) { cur_set[nc++] = i; sse += add; }
-    }
-    if (0 + lw * nc > 0 + lw * nbest) {
-      memcpy(best_set, cur_set, sizeof(int) * (size_t)nc);
-      nbest = nc; best_iter = iter;
+    if (nsl == 3) {   /* getTransform_Line_svd: computeRelativeMotion_svd(query, train) */
+      double la[18], lb[18], R[9], t[3];
+      int c;
+      for (s = 0; s < 3; s++)
+        for (c = 0; c < 3; c++) {
+          la[6 * s + c] = query[slq[s]].A[c]; la[6 * s + 3 + c] = query[slq[s]].B[c];
+          lb[6 * s + c] = train[slt[s]].A[c]; lb[6 * s + 3 + c] = train[slt[s]].B[c];
+        }
+      valid = lf_rel_motion_lines(la, lb, 3, R, t);
+      for (i = 0; i < 3; i++) { for (c = 0; c < 3; c++) tf[4 * i + c] = (float)R[3 * i + c]; tf[4 * i + 3] = (float)t[i]; }
+      tf[12] = tf[13] = tf[14] = 0.0f; tf[15] = 1.0f;
+    } else
+      valid = o_lns_pts_pcl(train, query, &pp, spq, spt, nsp, slq, slt, nsl, P, stream, iter, tf);
+    if (!valid) continue;
+    o_score(train, query, &pp, nPt, pq, ptm, mq, mt, nLn, tf, &pm, thr, cp, &ncp, cl, &ncl, &sse_f, &sse_d);
+    if (ncp + lw * ncl > nbp + lw * nbl) {
+      memcpy(bp, cp, sizeof(int) * (size_t)ncp); memcpy(bl, cl, sizeof(int) * (size_t)ncl);
+      nbp = ncp; nbl = ncl; best_iter = iter;
       memcpy(tf_best, tf, sizeof tf);
-      sse_best = sse;
+      sse_best = sse_f;
     }
   }
-  if (dbg) { dbg[0] = best_iter; dbg[1] = nbest; }
-  if (0 + nbest < 3) { free(indexes); *rmse_out = 1e9f; return 0; }                         /* :725-728 */
-  memcpy(refined_tf, tf_best, sizeof tf_best);
+  if (dbg) { dbg[0] = best_iter; dbg[1] = nbp + nbl; }
+  if (nbp + nbl < 3) { free(indexes); *rmse_out = 1e9f; return 0; }                          /* :725-728 */
   {
-    int *bq = (int *)malloc(sizeof(int) * (size_t)nLn * 2), *bt = bq + nLn;
-    for (i = 0; i < nbest; i++) { bq[i] = mq[best_set[i]]; bt[i] = mt[best_set[i]]; }
+    int *q1 = (int *)malloc(sizeof(int) * (size_t)(nTot + 1) * 4), *t1 = q1 + nTot + 1, *q2 = t1 + nTot + 1, *t2 = q2 + nTot + 1;
+    float sse_f; double tmp_sse;
     memcpy(refined_tf, tf_best, sizeof tf_best);
-    oracle_refine_g2o(train, query, bq, bt, nbest, refined_tf, 25, P, NULL);               /* :730 */
-    refined_rmse = sqrt(sse_best / (0 + nbest));                                            /* :731 */
-    for (iter = 0; iter < 20; ++iter) {                                                     /* :775-839 */
-      int nc = 0;
-      double tmp_sse = 0;
-      for (i = 0; i < nLn; ++i) {
-        double add;
-        if (lf_line_inlier(refined_tf, query[mq[i]].A, query[mq[i]].B, train[mt[i]].A, train[mt[i]].B,
-                           train[mt[i]].DUa, train[mt[i]].DUb, thr, &add)) { cur_set[nc++] = i; tmp_sse += add; }
-      }
-      if (0 + nc * lw > 0 + nref * lw) {
-        memcpy(ref_set, cur_set, sizeof(int) * (size_t)nc);
-        nref = nc;
-        refined_rmse = sqrt(tmp_sse / (0 + nc));
-        for (i = 0; i < nref; i++) { bq[i] = mq[ref_set[i]]; bt[i] = mt[ref_set[i]]; }
-        oracle_refine_g2o(train, query, bq, bt, nref, refined_tf, 20, P, NULL);
+    for (i = 0; i < nbp; i++) { q1[i] = pq[bp[i]]; t1[i] = ptm[bp[i]]; }
+    for (i = 0; i < nbl; i++) { q2[i] = mq[bl[i]]; t2[i] = mt[bl[i]]; }
+    oracle_refine_hybrid(train, query, q2, t2, nbl, &pp, nbp, q1, t1, focal, refined_tf, 25, P, NULL);   /* :730 */
+    refined_rmse = sqrt(sse_best / (nbp + nbl));                                                         /* :731 */
+    for (iter = 0; iter < 20; ++iter) {                                                                   /* :775-839 */
+      int ncp, ncl;
+      o_score(train, query, &pp, nPt, pq, ptm, mq, mt, nLn, refined_tf, &pm, thr, cp, &ncp, cl, &ncl, &sse_f, &tmp_sse);
+      if (ncp + ncl * lw > nrp + nrl * lw) {
+        memcpy(rp, cp, sizeof(int) * (size_t)ncp); memcpy(rl, cl, sizeof(int) * (size_t)ncl);
+        nrp = ncp; nrl = ncl;
+        refined_rmse = sqrt(tmp_sse / (ncp + ncl));
+        for (i = 0; i < nrp; i++) { q1[i] = pq[rp[i]]; t1[i] = ptm[rp[i]]; }
+        for (i = 0; i < nrl; i++) { q2[i] = mq[rl[i]]; t2[i] = mt[rl[i]]; }
+        oracle_refine_hybrid(train, query, q2, t2, nrl, &pp, nrp, q1, t1, focal, refined_tf, 20, P, NULL);
         rounds++;
       } else break;
     }
-    free(bq);
+    free(q1);
   }
   if (dbg) dbg[2] = rounds;
-  for (i = 0; i < nref; i++) inl[i] = ref_set[i];
-  *n_inl = nref;
+  for (i = 0; i < nrp; i++) pinl[i] = rp[i];
+  for (i = 0; i < nrl; i++) linl[i] = rl[i];
+  *n_pinl = nrp; *n_linl = nrl;
   *rmse_out = (float)refined_rmse;
   memcpy(tf_out, refined_tf, sizeof refined_tf);
   free(indexes);
-  return (0 + lw * nref) >= min_inlier;
+  return (nrp + lw * nrl) >= min_inlier;
+}
+
+/* lines-only odometry (BASELINE config 2) = the same function with an empty point-match list */
+int oracle_pose_lines_ransac(const lf_line_record *train, const lf_line_record *query, const int *mq,
+                             const int *mt, int nLn, int id_train, int id_query, const lf_params *P,
+                             uint64_t stream, float *tf_out, float *rmse_out, int *inl, int *n_inl, int *dbg) {
+  int npi = 0, dummy[1];
+  return oracle_pose_hybrid_ransac(train, query, NULL, NULL, NULL, NULL, 0, mq, mt, nLn, id_train, id_query, 525.0, P,
+                                   stream, tf_out, rmse_out, dummy, &npi, inl, n_inl, dbg);
+}
+int oracle_refine_g2o(const lf_line_record *train, const lf_line_record *query, const int *mq, const int *mt,
+                      int n, float *tf, int iterations, const lf_params *P, double *chi_out) {
+  o_points pp = {NULL, NULL, 0, NULL, NULL};
+  return oracle_refine_hybrid(train, query, mq, mt, n, &pp, 0, NULL, NULL, 525.0, tf, iterations, P, chi_out);
 }
 
 /* exported primitive wrappers for known-answer tests */
 int oracle_rel_motion_lines(const double *la, const double *lb, int n, double *R, double *t) { return lf_rel_motion_lines(la, lb, n, R, t); }
+double oracle_error_function2(const float *x1, const float *x2, const float *tf) { lf_point_model pm; o_point_model(&pm); return lf_error_function2(x1, x2, tf, &pm); }
+void oracle_kabsch(const float *from, const float *to, const float *w, int n, float *tf) { lf_tfc t; int i; lf_tfc_reset(&t); for (i = 0; i < n; i++) lf_tfc_add(&t, from + 3 * i, to + 3 * i, w[i]); lf_tfc_get(&t, tf); }

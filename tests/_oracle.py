@@ -206,3 +206,27 @@ def pose_oracle(train, query, mq, mt, id_train, id_query, params, stream, flavou
                                       C.byref(params), C.c_uint64(stream), C.c_void_p(tf.ctypes.data), C.byref(rmse),
                                       C.c_void_p(inl.ctypes.data), C.byref(ninl), C.c_void_p(dbg.ctypes.data))
     return bool(ok), tf.reshape(4, 4).copy(), float(rmse.value), inl[:ninl.value].copy(), dbg
+
+
+def pose_hybrid_oracle(train, query, train_pts, query_pts, pq, pt, mq, mt, id_train, id_query, params, stream,
+                       focal=525.0, flavour="lf"):
+    """oracle_pose_hybrid_ransac: getTransform_PtsLines_ransac with point AND line matches.
+    train_pts / query_pts: [n,4] float32 (x,y,z,1), the reference's feature_locations_3d_."""
+    lib = oracle_lib(flavour)
+    tr, qu = np.ascontiguousarray(train), np.ascontiguousarray(query)
+    tp, qp = np.ascontiguousarray(train_pts, np.float32), np.ascontiguousarray(query_pts, np.float32)
+    pq_, pt_ = np.ascontiguousarray(pq, np.int32), np.ascontiguousarray(pt, np.int32)
+    mq_, mt_ = np.ascontiguousarray(mq, np.int32), np.ascontiguousarray(mt, np.int32)
+    tf = np.zeros(16, np.float32)
+    rmse = C.c_float()
+    pinl, linl = np.zeros(max(len(pq_), 1), np.int32), np.zeros(max(len(mq_), 1), np.int32)
+    npi, nli = C.c_int(), C.c_int()
+    dbg = np.zeros(4, np.int32)
+    lib.oracle_pose_hybrid_ransac.restype = C.c_int
+    ok = lib.oracle_pose_hybrid_ransac(
+        C.c_void_p(tr.ctypes.data), C.c_void_p(qu.ctypes.data), C.c_void_p(tp.ctypes.data), C.c_void_p(qp.ctypes.data),
+        C.c_void_p(pq_.ctypes.data), C.c_void_p(pt_.ctypes.data), C.c_int(len(pq_)), C.c_void_p(mq_.ctypes.data),
+        C.c_void_p(mt_.ctypes.data), C.c_int(len(mq_)), C.c_int(id_train), C.c_int(id_query), C.c_double(focal),
+        C.byref(params), C.c_uint64(stream), C.c_void_p(tf.ctypes.data), C.byref(rmse), C.c_void_p(pinl.ctypes.data),
+        C.byref(npi), C.c_void_p(linl.ctypes.data), C.byref(nli), C.c_void_p(dbg.ctypes.data))
+    return bool(ok), tf.reshape(4, 4).copy(), float(rmse.value), pinl[:npi.value].copy(), linl[:nli.value].copy(), dbg

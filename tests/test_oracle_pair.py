@@ -130,3 +130,65 @@ def test_line_matching_rules():
     # non-adjacent frames use the stricter descriptor threshold 0.7 and ignore the overlap test
     mqn, mtn, mdn, _ = O.match_oracle(q, tr, adjacent=False)
     assert np.all(mdn < 0.7)
+
+
+# ---------------------------------------------------------------- points + lines (BASELINE config 3)
+def _points(rng, n, R, t, noise=0.0):
+    q = np.ones((n, 4), np.float32)
+    q[:, :3] = rng.uniform(-1.5, 1.5, (n, 3)) + np.array([0, 0, 3.0])
+    tr = q.copy()
+    tr[:, :3] = q[:, :3].astype(np.float64) @ R.T + t + rng.normal(size=(n, 3)) * noise
+    return q, tr
+
+
+def test_kabsch_restatement_matches_numpy():
+    lib = O.oracle_lib("lf")
+    rng = np.random.default_rng(11)
+    for n in (3, 4, 20):
+        R = _rot(rng.normal(size=3), 0.4)
+        t = rng.normal(size=3)
+        a = rng.normal(size=(n, 3)).astype(np.float32)
+        b = (a.astype(np.float64) @ R.T + t).astype(np.float32)
+        w = rng.uniform(0.2, 1.0, n).astype(np.float32)
+        tf = np.zeros(16, np.float32)
+        lib.oracle_kabsch(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(w.ctypes.data), C.c_int(n),
+                          C.c_void_p(tf.ctypes.data))
+        T = tf.reshape(4, 4)
+        assert np.allclose(T[:3, :3], R, atol=2e-5) and np.allclose(T[:3, 3], t, atol=5e-5)
+
+
+def test_error_function2_semantics():
+    lib = O.oracle_lib("lf")
+    lib.oracle_error_function2.restype = C.c_double
+    I4 = np.eye(4, dtype=np.float32)
+    p = np.array([0.3, -0.2, 2.0, 1.0], np.float32)
+    f = lambda a, b, T=I4: lib.oracle_error_function2(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(np.ascontiguousarray(T).ctypes.data))
+    assert f(p, p) == 0.0
+    q = p.copy(); q[2] += 0.004
+    m = f(p, q)                                          # 4 mm in depth at 2 m: sigma_z = 0.01*4 = 4 cm each
+    assert m == pytest.approx(0.004 ** 2 / (2 * (0.01 * 4.0) ** 2), rel=2e-2)
+    far = p.copy(); far[0] += 0.5
+    assert f(p, far) > 1e300                             # isotropic-bound shortcut (misc.cpp:741-748)
+    nanp = p.copy(); nanp[2] = np.nan
+    assert f(nanp, p) > 1e300 and f(p, nanp) > 1e300     # NaN depth (misc.cpp:716-720)
+
+
+def test_hybrid_ransac_with_points_and_lines():
+    from lineslam_amd import capi
+    rng = np.random.default_rng(12)
+    P = capi.default_params()
+    R, t = _rot([0.1, 1, -0.2], 0.04), np.array([0.03, 0.01, -0.02])
+    q, tr, _, _ = _scene(rng, n=24, noise=0.001, R=R, t=t)
+    qp, tp = _points(rng, 60, R, t, noise=0.002)
+    mq = np.arange(24, dtype=np.int32); mt = mq.copy()
+    pq = np.arange(60, dtype=np.int32); pt = pq.copy()
+    badp = rng.choice(60, 15, replace=False); pt[badp] = np.roll(pt[badp], 1)
+    badl = rng.choice(24, 6, replace=False); mt[badl] = np.roll(mt[badl], 1)
+    ok, tf, rmse, pinl, linl, dbg = O.pose_hybrid_oracle(tr, q, tp, qp, pq, pt, mq, mt, 0, 1, P, 5)
+    assert ok
+    assert np.allclose(tf[:3, :3], R, atol=3e-3) and np.allclose(tf[:3, 3], t, atol=5e-3)
+    assert not (set(pinl.tolist()) & set(badp.tolist())) and not (set(linl.tolist()) & set(badl.tolist()))
+    assert len(pinl) >= 40 and len(linl) >= 15
+    # points only (the legacy getRelativeTransformationTo situation): still solvable
+    ok2, tf2, _, pinl2, linl2, _ = O.pose_hybrid_oracle(tr[:0], q[:0], tp, qp, pq, pt, mq[:0], mt[:0], 0, 1, P, 5)
+    assert ok2 and len(linl2) == 0 and np.allclose(tf2[:3, 3], t, atol=5e-3)
