@@ -189,7 +189,9 @@ typedef struct lf_pair_result {
   int32_t id_newer;       /* edge.id2 */
   int32_t ransac_best_iter;   /* diagnostics: iteration that produced the best minimal-sample model       */
   int32_t refine_rounds;      /* diagnostics: number of re-score + g2o rounds (motion.cpp:775-839)         */
-  double information_scale;   /* edge.informationMatrix = I6 * (n_inl * weight) / rmse^2 (node.cpp:1533)   */
+  int32_t n_point_matches;    /* all_matches.size()    (0 unless the hybrid entry points are used)         */
+  int32_t n_point_inliers;    /* inlier_matches.size()                                                     */
+  double information_scale;   /* edge.informationMatrix = I6 * (n_pt_inl + n_ln_inl * weight) / rmse^2 (node.cpp:1533) */
 } lf_pair_result;
 
 /* For each pair i: newer = frame slot query_frames[i], older = train_frames[i] of the LAST
@@ -207,6 +209,28 @@ LF_API int lf_pair_get_matches(lf_ctx *ctx, int pair, int32_t *query_idx, int32_
 LF_API int lf_pair_get_inliers(lf_ctx *ctx, int pair, int32_t *match_idx, int cap, int *n_out);
 /* descDiff matrix of pair `pair` (n_query x n_train doubles, 100 = gated out) for parity tests. */
 LF_API int lf_pair_get_descdiff(lf_ctx *ctx, int pair, double *D, size_t cap_doubles, int *n_query, int *n_train);
+
+/* ---- points + lines (BASELINE.json config 3) ------------------------------------------------
+ * As lf_match_pairs_device, but getTransform_PtsLines_ransac (motion.cpp:605-849) also receives point
+ * matches, exactly as Node::matchNodePair hands it MatchingResult::all_matches (node.cpp:1519-1530):
+ *   d_points   DEVICE [frames of the last batch][pt_cap][4] floats = Node::feature_locations_3d_
+ *              (x, y, z, 1; z = NaN when the keypoint has no depth, node.cpp:952-1018); must stay valid
+ *              until the call has completed on the context stream
+ *   pm_query / pm_train   HOST [n_pairs][pm_cap]: cv::DMatch::queryIdx / trainIdx into the newer / older
+ *              node's point array;  n_pm HOST [n_pairs] (each <= min(pm_cap, 512), else LF_ERR_CAPACITY)
+ *   K          camera matrix (K[0] is the focal length of compPt3dCov, transformation_estimation.cpp:245)
+ * Keypoint extraction and descriptor matching themselves (Node::featureMatching) stay with the caller. */
+LF_API int lf_match_pairs_hybrid_device(lf_ctx *ctx, const int32_t *query_frames, const int32_t *train_frames,
+                                        int n_pairs, const float *d_points, int pt_cap, const int32_t *pm_query,
+                                        const int32_t *pm_train, const int32_t *n_pm, int pm_cap, const double K[9]);
+/* inlier_matches as indices into the point match list given to lf_match_pairs_hybrid_device. */
+LF_API int lf_pair_get_point_inliers(lf_ctx *ctx, int pair, int32_t *match_idx, int cap, int *n_out);
+/* Node-level convenience (host memory): lf_match_node_pair with the two nodes' 3D points and their matches. */
+LF_API int lf_match_node_pair_hybrid(lf_ctx *ctx, const lf_line_record *newer, int n_newer, uint64_t id_newer,
+                                     const float *pts_newer, int n_pts_newer, const lf_line_record *older,
+                                     int n_older, uint64_t id_older, const float *pts_older, int n_pts_older,
+                                     const int32_t *pm_query, const int32_t *pm_train, int n_pm, const double K[9],
+                                     lf_pair_result *out);
 
 /* Stage durations (ms) of the last launches, measured with HIP events recorded on the context
  * stream: which = 0 LSD data-parallel kernels, 1 the LSD sweep kernel (k_lsd_sweep), 2 the 3D-line

@@ -78,6 +78,10 @@ SYMBOLS = {
     "lf_get_device_records": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _pi]),
     "lf_match_external_device": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i]),
     "lf_match_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, C.c_uint64, _vp]),
+    "lf_match_pairs_hybrid_device": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "lf_pair_get_point_inliers": (_i, [_vp, _i, _vp, _i, _pi]),
+    "lf_match_node_pair_hybrid": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, _vp, _i, C.c_uint64, _vp, _i, _vp, _vp, _i,
+                                       _vp, _vp]),
 }
 
 
@@ -93,7 +97,8 @@ class LfPairResult(C.Structure):
     """struct lf_pair_result: flat MatchingResult of Node::matchNodePair."""
     _fields_ = [("T", C.c_float * 16), ("rmse", C.c_float), ("valid", C.c_int32), ("n_matches", C.c_int32),
                 ("n_inliers", C.c_int32), ("id_older", C.c_int32), ("id_newer", C.c_int32),
-                ("ransac_best_iter", C.c_int32), ("refine_rounds", C.c_int32), ("information_scale", C.c_double)]
+                ("ransac_best_iter", C.c_int32), ("refine_rounds", C.c_int32), ("n_point_matches", C.c_int32),
+                ("n_point_inliers", C.c_int32), ("information_scale", C.c_double)]
 
 
 # numpy view of struct lf_line_record (1040 bytes)
@@ -263,6 +268,26 @@ class Context:
         self._chk(lib().lf_match_pairs_device(self._h, q.ctypes.data, t.ctypes.data, len(q)),
                   "lf_match_pairs_device")
 
+    def match_pairs_hybrid_device(self, query_frames, train_frames, d_points_ptr, pt_cap, pm_query, pm_train, n_pm, K):
+        """As match_pairs_device with point matches (BASELINE config 3).  d_points_ptr: device [frames][pt_cap][4]
+        float32 (feature_locations_3d_); pm_query / pm_train: [n_pairs, pm_cap] int32; n_pm: [n_pairs]."""
+        q = np.ascontiguousarray(query_frames, np.int32)
+        t = np.ascontiguousarray(train_frames, np.int32)
+        a, b = np.ascontiguousarray(pm_query, np.int32), np.ascontiguousarray(pm_train, np.int32)
+        n = np.ascontiguousarray(n_pm, np.int32)
+        Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+        assert q.shape == t.shape == n.shape and a.shape == b.shape and a.ndim == 2 and a.shape[0] == len(q)
+        self._chk(lib().lf_match_pairs_hybrid_device(self._h, q.ctypes.data, t.ctypes.data, len(q), int(d_points_ptr),
+                                                     int(pt_cap), a.ctypes.data, b.ctypes.data, n.ctypes.data,
+                                                     a.shape[1], Kc.ctypes.data), "lf_match_pairs_hybrid_device")
+
+    def pair_point_inliers(self, pair, cap=512):
+        m = np.zeros(cap, np.int32)
+        n = C.c_int()
+        self._chk(lib().lf_pair_get_point_inliers(self._h, pair, m.ctypes.data, cap, C.byref(n)),
+                  "lf_pair_get_point_inliers")
+        return m[:n.value].copy()
+
     def pair_result(self, pair):
         r = LfPairResult()
         self._chk(lib().lf_pair_get_result(self._h, pair, C.byref(r)), "lf_pair_get_result")
@@ -324,4 +349,19 @@ class Context:
         r = LfPairResult()
         self._chk(lib().lf_match_node_pair(self._h, a.ctypes.data, len(a), int(id_newer), b.ctypes.data, len(b),
                                            int(id_older), C.byref(r)), "lf_match_node_pair")
+        return r
+
+    def match_node_pair_hybrid(self, newer_recs, id_newer, newer_pts, older_recs, id_older, older_pts, pm_query,
+                               pm_train, K):
+        """Node::matchNodePair with 3D points ([n,4] float32) and their matches, all host-resident."""
+        a, b = np.ascontiguousarray(newer_recs), np.ascontiguousarray(older_recs)
+        pa, pb = np.ascontiguousarray(newer_pts, np.float32), np.ascontiguousarray(older_pts, np.float32)
+        mq, mt = np.ascontiguousarray(pm_query, np.int32), np.ascontiguousarray(pm_train, np.int32)
+        Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+        assert len(mq) == len(mt)
+        r = LfPairResult()
+        self._chk(lib().lf_match_node_pair_hybrid(self._h, a.ctypes.data, len(a), int(id_newer), pa.ctypes.data, len(pa),
+                                                  b.ctypes.data, len(b), int(id_older), pb.ctypes.data, len(pb),
+                                                  mq.ctypes.data, mt.ctypes.data, len(mq), Kc.ctypes.data, C.byref(r)),
+                  "lf_match_node_pair_hybrid")
         return r

@@ -35,6 +35,10 @@ struct lf_ctx {
   PairBuffers pb;
   int *d_pair_q = nullptr, *d_pair_t = nullptr;
   int last_pairs = 0;
+  bool hybrid_ready = false;         // hybrid (points + lines) buffers are allocated on first use
+  int *d_pm_q = nullptr, *d_pm_t = nullptr, *d_npm = nullptr;
+  float *d_pts_stage = nullptr;      // lf_match_node_pair_hybrid staging: 2 x LF_NODE_PT_CAP float4
+  bool last_hybrid = false;
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint8_t *d_gray_stage = nullptr;   // staging for the host-pointer convenience entry points
   float *d_depth_stage = nullptr;
@@ -135,7 +139,6 @@ const char *lf_status_str(int s) {
   }
 }
 const char *lf_last_error(const lf_ctx *c) { return c ? c->err.c_str() : ""; }
-
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------
@@ -572,9 +575,51 @@ int lf_detect3d(lf_ctx *c, const uint8_t *gray, int gray_row_stride, const float
 }
 
 // ---- a19-a25 -----------------------------------------------------------------------------------
+struct HybridArgs { const float *d_points; int pt_cap; const int32_t *pm_q, *pm_t, *n_pm; int pm_cap; const double *K; };
+#define LF_NODE_PT_CAP 4096
+
+static int hybrid_prepare(lf_ctx *c, const HybridArgs &h, int n_pairs, PairBuffers &pb) {
+  if (!h.d_points || h.pt_cap < 1 || !h.pm_q || !h.pm_t || !h.n_pm || h.pm_cap < 0 || !h.K) return LF_ERR_INVALID;
+  for (int i = 0; i < n_pairs; i++) {
+    if (h.n_pm[i] < 0) return LF_ERR_INVALID;
+    if (h.n_pm[i] > h.pm_cap || h.n_pm[i] > LF_MAX_PT_MATCHES) { c->err = "point matches per pair exceed the capacity (512)"; return LF_ERR_CAPACITY; }
+    for (int k = 0; k < h.n_pm[i]; k++) {
+      int a = h.pm_q[(size_t)i * h.pm_cap + k], b = h.pm_t[(size_t)i * h.pm_cap + k];
+      if (a < 0 || a >= h.pt_cap || b < 0 || b >= h.pt_cap) { c->err = "point match index outside the point array"; return LF_ERR_INVALID; }
+    }
+  }
+  if (!c->hybrid_ready) {
+    const size_t B = (size_t)c->maxB;
+    ALLOC(c, c->d_pm_q, B * LF_MAX_PT_MATCHES); ALLOC(c, c->d_pm_t, B * LF_MAX_PT_MATCHES); ALLOC(c, c->d_npm, B);
+    ALLOC(c, c->pb.pt_inliers, B * LF_MAX_PT_MATCHES);
+    ALLOC(c, c->pb.ws_h, B * lf_pair_hybrid_ws_doubles());
+    ALLOC(c, c->d_pts_stage, (size_t)2 * LF_NODE_PT_CAP * 4);
+    c->pb.pm_q = c->d_pm_q; c->pb.pm_t = c->d_pm_t; c->pb.npm = c->d_npm;
+    c->hybrid_ready = true;
+  }
+  std::vector<int> hq((size_t)n_pairs * LF_MAX_PT_MATCHES, 0), ht((size_t)n_pairs * LF_MAX_PT_MATCHES, 0);
+  for (int i = 0; i < n_pairs; i++)
+    for (int k = 0; k < h.n_pm[i]; k++) {
+      hq[(size_t)i * LF_MAX_PT_MATCHES + k] = h.pm_q[(size_t)i * h.pm_cap + k];
+      ht[(size_t)i * LF_MAX_PT_MATCHES + k] = h.pm_t[(size_t)i * h.pm_cap + k];
+    }
+  HIPCHK(c, hipMemcpyAsync(c->d_pm_q, hq.data(), hq.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_pm_t, ht.data(), ht.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_npm, h.n_pm, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  pb = c->pb;
+  pb.pts = h.d_points; pb.pts_t = h.d_points; pb.pt_cap = h.pt_cap; pb.pt_cap_t = h.pt_cap;
+  // errorFunction2 constants (misc.cpp:704-711) and sigma_depth (misc2.h:23), host libm as in the reference
+  const double cam_angle_x = 58.0 / 180.0 * M_PI, cam_angle_y = 45.0 / 180.0 * M_PI;
+  const double sx = 3 * tan(cam_angle_x / 640), sy = 3 * tan(cam_angle_y / 480);
+  c->pcn.pm.raster_cov_x = sx * sx; c->pcn.pm.raster_cov_y = sy * sy; c->pcn.pm.sigma_depth = 0.01;
+  c->pcn.focal = h.K[0];
+  return LF_OK;
+}
+
 static int match_pairs_impl(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
                             const lf_line_record *d_ext_recs, const int32_t *d_ext_nlines,
-                            const uint64_t *d_ext_ids, int ext_frames, int ext_line_cap) {
+                            const uint64_t *d_ext_ids, int ext_frames, int ext_line_cap, const HybridArgs *hy = nullptr) {
   if (!c || !query_frames || !train_frames || n_pairs < 1) return LF_ERR_INVALID;
   if (n_pairs > c->maxB) return LF_ERR_CAPACITY;
   const int ntrain = d_ext_recs ? ext_frames : c->last_batch;
@@ -587,9 +632,11 @@ static int match_pairs_impl(lf_ctx *c, const int32_t *query_frames, const int32_
   HIPCHK(c, hipStreamSynchronize(c->stream));   // caller's arrays may be temporaries
   c->pcn.P = c->params;
   PairBuffers pb = c->pb;
+  if (hy) { int r = hybrid_prepare(c, *hy, n_pairs, pb); if (r != LF_OK) return r; }
   if (d_ext_recs) { pb.recs_t = d_ext_recs; pb.nlines_t = d_ext_nlines; pb.frame_ids_t = d_ext_ids; pb.line_cap_t = ext_line_cap; }
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-  lf_pair_launch(c->pcn, pb, n_pairs, c->stream);
+  lf_pair_launch(c->pcn, pb, n_pairs, c->stream, hy != nullptr);
+  c->last_hybrid = hy != nullptr;
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   HIPCHK(c, hipGetLastError());
   c->last_pairs = n_pairs;
@@ -605,6 +652,28 @@ int lf_match_external_device(lf_ctx *c, const int32_t *query_frames, const int32
                              const uint64_t *d_ext_ids, int ext_frames, int ext_line_cap) {
   if (!d_ext_recs || !d_ext_nlines || !d_ext_ids || ext_frames < 1 || ext_line_cap < 1) return LF_ERR_INVALID;
   return match_pairs_impl(c, query_frames, train_slots, n_pairs, d_ext_recs, d_ext_nlines, d_ext_ids, ext_frames, ext_line_cap);
+}
+
+int lf_match_pairs_hybrid_device(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
+                                 const float *d_points, int pt_cap, const int32_t *pm_query, const int32_t *pm_train,
+                                 const int32_t *n_pm, int pm_cap, const double K[9]) {
+  if (!c) return LF_ERR_INVALID;
+  HybridArgs h = {d_points, pt_cap, pm_query, pm_train, n_pm, pm_cap, K};
+  return match_pairs_impl(c, query_frames, train_frames, n_pairs, nullptr, nullptr, nullptr, 0, 0, &h);
+}
+
+int lf_pair_get_point_inliers(lf_ctx *c, int pair, int32_t *match_idx, int cap, int *n_out) {
+  if (!c || !n_out || pair < 0 || pair >= c->last_pairs || cap < 0) return LF_ERR_INVALID;
+  lf_pair_result r;
+  int rc = lf_pair_get_result(c, pair, &r);
+  if (rc != LF_OK) return rc;
+  *n_out = r.n_point_inliers;
+  int m = r.n_point_inliers < cap ? r.n_point_inliers : cap;
+  if (m > 0 && match_idx && c->last_hybrid) {
+    HIPCHK(c, hipMemcpyAsync(match_idx, c->pb.pt_inliers + (size_t)pair * LF_MAX_PT_MATCHES, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return LF_OK;
 }
 
 int lf_get_device_records(lf_ctx *c, lf_line_record **d_recs, int32_t **d_nlines, uint64_t **d_ids, int *line_cap) {
@@ -715,6 +784,46 @@ int lf_match_node_pair(lf_ctx *c, const lf_line_record *newer, int n_newer, uint
   if (c->last_batch < 2) c->last_batch = 2;
   const int32_t q = 0, t = 1;
   int r = lf_match_pairs_device(c, &q, &t, 1);
+  if (r != LF_OK) return r;
+  return lf_pair_get_result(c, 0, out);
+}
+
+int lf_match_node_pair_hybrid(lf_ctx *c, const lf_line_record *newer, int n_newer, uint64_t id_newer,
+                              const float *pts_newer, int n_pts_newer, const lf_line_record *older, int n_older,
+                              uint64_t id_older, const float *pts_older, int n_pts_older, const int32_t *pm_query,
+                              const int32_t *pm_train, int n_pm, const double K[9], lf_pair_result *out) {
+  if (!c || !out || n_newer < 0 || n_older < 0 || (n_newer && !newer) || (n_older && !older) || n_pts_newer < 0 ||
+      n_pts_older < 0 || (n_pts_newer && !pts_newer) || (n_pts_older && !pts_older) || n_pm < 0 ||
+      (n_pm && (!pm_query || !pm_train)) || !K)
+    return LF_ERR_INVALID;
+  if (c->maxB < 2) return LF_ERR_CAPACITY;
+  if (n_newer > c->fc.line_cap || n_older > c->fc.line_cap || n_pts_newer > LF_NODE_PT_CAP || n_pts_older > LF_NODE_PT_CAP)
+    return LF_ERR_CAPACITY;
+  for (int k = 0; k < n_pm; k++)
+    if (pm_query[k] < 0 || pm_query[k] >= n_pts_newer || pm_train[k] < 0 || pm_train[k] >= n_pts_older) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t ids[2] = {id_newer, id_older};
+  const int nl[2] = {n_newer, n_older};
+  if (n_newer) HIPCHK(c, hipMemcpyAsync(c->fb.recs, newer, sizeof(lf_line_record) * (size_t)n_newer, hipMemcpyHostToDevice, c->stream));
+  if (n_older) HIPCHK(c, hipMemcpyAsync(c->fb.recs + c->fc.line_cap, older, sizeof(lf_line_record) * (size_t)n_older, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->fb.nlines, nl, sizeof nl, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_frame_ids, ids, sizeof ids, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->last_batch < 2) c->last_batch = 2;
+  // first hybrid call allocates the staging buffer: run an empty prepare through a dummy call path
+  const int32_t q = 0, t = 1, npm = n_pm, zero = 0;
+  if (!c->hybrid_ready) {
+    PairBuffers tmp;
+    float dummy_pt = 0;
+    HybridArgs h0 = {&dummy_pt, 1, &zero, &zero, &zero, 0, K};
+    int r0 = hybrid_prepare(c, h0, 1, tmp);
+    if (r0 != LF_OK) return r0;
+  }
+  if (n_pts_newer) HIPCHK(c, hipMemcpyAsync(c->d_pts_stage, pts_newer, sizeof(float) * 4 * (size_t)n_pts_newer, hipMemcpyHostToDevice, c->stream));
+  if (n_pts_older) HIPCHK(c, hipMemcpyAsync(c->d_pts_stage + (size_t)LF_NODE_PT_CAP * 4, pts_older, sizeof(float) * 4 * (size_t)n_pts_older, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int32_t *pq = n_pm ? pm_query : &zero, *pt = n_pm ? pm_train : &zero;
+  int r = lf_match_pairs_hybrid_device(c, &q, &t, 1, c->d_pts_stage, LF_NODE_PT_CAP, pq, pt, &npm, n_pm > 0 ? n_pm : 1, K);
   if (r != LF_OK) return r;
   return lf_pair_get_result(c, 0, out);
 }

@@ -6,9 +6,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/linefront.h"
+#include "lf_pose.h"
 
 #define LF_MAX_MATCHES 256        // line matches per pair handled by the pose kernel (4 per lane)
 #define LF_RANSAC_MAX_ITERS 1024  // sample table capacity
+#define LF_MAX_PT_MATCHES 512     // point matches per pair handled by the hybrid pose kernel (8 per lane)
 #define LF_PAIR_WS_DOUBLES (LF_MAX_MATCHES * (120 + 36 + 42 + 6 + 6))   // per-pair LM workspace
 
 struct PairConsts {
@@ -16,6 +18,8 @@ struct PairConsts {
   double cos_angle_thresh;   // cos(30 * 3.14159265 / 180), host libm (node.cpp:1624,1647)
   int line_cap;              // records per frame
   int match_cap;             // rows of the match list per pair
+  lf_point_model pm;         // hybrid solver: errorFunction2 constants (misc.cpp:704-711, host libm)
+  double focal;              //   K(0,0) for compPt3dCov (transformation_estimation.cpp:245)
 };
 
 struct PairBuffers {
@@ -34,6 +38,15 @@ struct PairBuffers {
   lf_pair_result *results;      // [n_pairs]
   int *inliers;                 // [n_pairs][LF_MAX_MATCHES] indices into the match list
   double *ws;                   // [n_pairs][LF_PAIR_WS_DOUBLES]
+  // ---- hybrid solver (points + lines, BASELINE config 3); allocated on first use
+  const float *pts, *pts_t;     // [frames][pt_cap][4]  Node::feature_locations_3d_ (x,y,z,1; z NaN = no depth)
+  int pt_cap, pt_cap_t;
+  const int *pm_q, *pm_t;       // [n_pairs][LF_MAX_PT_MATCHES] point matches (queryIdx, trainIdx)
+  const int *npm;               // [n_pairs]
+  int *pt_inliers;              // [n_pairs][LF_MAX_PT_MATCHES] indices into the point match list
+  double *ws_h;                 // [n_pairs][lf_pair_hybrid_ws_doubles()]
 };
 
-void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t stream);
+void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t stream, bool hybrid = false);
+size_t lf_pair_hybrid_ws_doubles();
+void lf_pair_hybrid_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t stream);

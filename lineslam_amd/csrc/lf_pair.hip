@@ -460,6 +460,8 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
     res->valid = valid;
     res->n_matches = n_all;
     res->n_inliers = n_inl;
+    res->n_point_matches = 0;
+    res->n_point_inliers = 0;
     res->id_older = valid ? (int)id_t : -1;        // node.cpp:1606-1607
     res->id_newer = valid ? (int)id_q : -1;
     res->ransac_best_iter = best_iter;
@@ -469,7 +471,8 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
   }
 }
 
-void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t st) {
+void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t st, bool hybrid) {
   hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(256), 0, st, c, b);
-  hipLaunchKernelGGL(k_pose, dim3(n_pairs), dim3(64), 0, st, c, b);
+  if (hybrid) lf_pair_hybrid_launch(c, b, n_pairs, st);
+  else hipLaunchKernelGGL(k_pose, dim3(n_pairs), dim3(64), 0, st, c, b);
 }
