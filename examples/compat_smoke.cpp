@@ -1,0 +1,51 @@
+// Compile check and minimal usage of the C++ mirror of the reference's Node interface
+// (include/linefront_compat.hpp).  Build:  g++ -std=c++17 -Iinclude examples/compat_smoke.cpp -Llineslam_amd -llinefront
+// Usage: compat_smoke gray0.bin depth0.bin gray1.bin depth1.bin   (640x480 u8 / f32 raw images)
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "linefront_compat.hpp"
+
+static std::vector<char> slurp(const char* path) {
+  std::vector<char> v;
+  if (FILE* f = fopen(path, "rb")) {
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    v.resize(n > 0 ? (size_t)n : 0);
+    if (n > 0 && fread(v.data(), 1, (size_t)n, f) != (size_t)n) v.clear();
+    fclose(f);
+  }
+  return v;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 5) { fprintf(stderr, "usage: %s gray0 depth0 gray1 depth1\n", argv[0]); return 2; }
+  const int W = 640, H = 480;
+  const double K[9] = {525.0, 0, 319.5, 0, 525.0, 239.5, 0, 0, 1};
+  try {
+    lf::Context ctx(W, H);
+    lf::Node older(&ctx, 0), newer(&ctx, 1);
+    lf::Node* nodes[2] = {&older, &newer};
+    for (int i = 0; i < 2; i++) {
+      std::vector<char> g = slurp(argv[1 + 2 * i]), d = slurp(argv[2 + 2 * i]);
+      if (g.size() != (size_t)W * H || d.size() != (size_t)W * H * 4) { fprintf(stderr, "bad image size\n"); return 2; }
+      nodes[i]->detect3DLines((const uint8_t*)g.data(), W, (const float*)d.data(), W, W, H, ctx.params.line_segment_len_thresh,
+                              K, ctx.params.ratio_of_collinear_pts, ctx.params.line3d_length_thresh, 1.0, "LSD");
+      printf("node %d: %zu 3D lines\n", i, nodes[i]->lines.size());
+    }
+    lf::MatchingResult mr = newer.matchNodePair(&older);
+    printf("matches %zu inliers %zu rmse %g valid %d\n", mr.all_line_matches.size(), mr.inlier_line_matches.size(),
+           (double)mr.rmse, mr.edge.id1 >= 0);
+    for (int r = 0; r < 4; r++) printf("%+.6f %+.6f %+.6f %+.6f\n", mr.final_trafo[4 * r], mr.final_trafo[4 * r + 1], mr.final_trafo[4 * r + 2], mr.final_trafo[4 * r + 3]);
+    std::vector<lf::DMatch> none, inl;
+    float T[16], rmse;
+    bool ok = newer.getRelativeTransformationTo(&older, &none, T, rmse, inl);
+    printf("getRelativeTransformationTo: %d (%zu inliers)\n", ok, inl.size());
+  } catch (const lf::Error& e) {
+    fprintf(stderr, "linefront error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -20,7 +20,8 @@ struct DMatch { int queryIdx, trainIdx; float distance; };            // cv::DMa
 typedef lf_line_record FrameLine;                                       // src/line/lineslam.h:113-151 (flat)
 
 struct LoadedEdge3D { int id1 = -1, id2 = -1; double transform[16]; double informationMatrix[36]; };   // src/edge.h:25-33
-struct MatchingResult {                                                 // src/matching_result.h:23-49 (line part)
+struct MatchingResult {                                                 // src/matching_result.h:23-49
+  std::vector<DMatch> all_matches, inlier_matches;                      // point matches (filled by the caller / hybrid solver)
   std::vector<DMatch> all_line_matches, inlier_line_matches;
   float rmse = 0.f;
   float ransac_trafo[16], final_trafo[16];
@@ -52,7 +53,9 @@ class Node {
  public:
   int id_ = 0;
   std::vector<FrameLine> lines;     // src/node.h:280
+  std::vector<std::array<float, 4>> feature_locations_3d_;   // src/node.h:  x,y,z,1 per keypoint, z = NaN without depth
   Context* ctx = nullptr;
+  double K[9] = {525.0, 0, 319.5, 0, 525.0, 239.5, 0, 0, 1};   // the reference's global K (set by detect3DLines)
 
   Node(Context* c, int id) : id_(id), ctx(c) {}
 
@@ -66,6 +69,7 @@ class Node {
     p.line_segment_len_thresh = line2d_len_thres; p.ratio_of_collinear_pts = ratio_of_collinear_pts;
     p.line3d_length_thresh = line_3d_len_thres_m; p.depth_scaling = depth_scaling;
     check(lf_ctx_set_params(ctx->h, &p), "lf_ctx_set_params");
+    for (int i = 0; i < 9; i++) this->K[i] = K[i];
     lines.resize(512);
     int n = 0;
     int r = lf_detect3d(ctx->h, gray_uchar, gray_stride, depth_float, depth_stride, width, height, K,
@@ -74,12 +78,32 @@ class Node {
     lines.resize(n < 512 ? n : 512);
   }
 
-  // Node::matchNodePair (src/node.cpp:1494-1615): valid edge <=> mr.edge.id1 >= 0
-  MatchingResult matchNodePair(const Node* older_node) const {
+  // Node::matchNodePair (src/node.cpp:1494-1615): valid edge <=> mr.edge.id1 >= 0.
+  // point_matches = MatchingResult::all_matches, i.e. what Node::featureMatching produced for the two nodes'
+  // feature_locations_3d_ (node.cpp:1519); nullptr / empty = lines only.
+  MatchingResult matchNodePair(const Node* older_node, const std::vector<DMatch>* point_matches = nullptr) const {
     MatchingResult mr;
     lf_pair_result r;
-    check(lf_match_node_pair(ctx->h, lines.data(), (int)lines.size(), (uint64_t)id_, older_node->lines.data(),
-                             (int)older_node->lines.size(), (uint64_t)older_node->id_, &r), "lf_match_node_pair");
+    const bool hybrid = point_matches && !point_matches->empty();
+    if (hybrid) {
+      std::vector<int32_t> pq, pt;
+      for (const DMatch& m : *point_matches) { pq.push_back(m.queryIdx); pt.push_back(m.trainIdx); }
+      mr.all_matches = *point_matches;
+      check(lf_match_node_pair_hybrid(ctx->h, lines.data(), (int)lines.size(), (uint64_t)id_,
+                                      feature_locations_3d_.empty() ? nullptr : feature_locations_3d_[0].data(),
+                                      (int)feature_locations_3d_.size(), older_node->lines.data(),
+                                      (int)older_node->lines.size(), (uint64_t)older_node->id_,
+                                      older_node->feature_locations_3d_.empty() ? nullptr : older_node->feature_locations_3d_[0].data(),
+                                      (int)older_node->feature_locations_3d_.size(), pq.data(), pt.data(), (int)pq.size(), K, &r),
+            "lf_match_node_pair_hybrid");
+      std::vector<int32_t> pin(pq.size());
+      int np = 0;
+      check(lf_pair_get_point_inliers(ctx->h, 0, pin.data(), (int)pin.size(), &np), "lf_pair_get_point_inliers");
+      for (int i = 0; i < np; i++) mr.inlier_matches.push_back(mr.all_matches[pin[i]]);
+    } else {
+      check(lf_match_node_pair(ctx->h, lines.data(), (int)lines.size(), (uint64_t)id_, older_node->lines.data(),
+                               (int)older_node->lines.size(), (uint64_t)older_node->id_, &r), "lf_match_node_pair");
+    }
     std::vector<int32_t> q(256), t(256), inl(256);
     std::vector<double> d(256);
     int n = 0, ni = 0;
@@ -106,13 +130,14 @@ class Node {
   }
 
   // Node::getRelativeTransformationTo (src/node.h:124-128): legacy point-RANSAC entry, routed to the same
-  // solver with the point-match list empty
-  bool getRelativeTransformationTo(const Node* target_node, std::vector<DMatch>* /*initial_matches*/,
+  // solver; initial_matches = the point matches.  `matches` receives the point
+  // inliers when point matches were given, the line inliers otherwise.
+  bool getRelativeTransformationTo(const Node* target_node, std::vector<DMatch>* initial_matches,
                                    float resulting_transformation[16], float& rmse, std::vector<DMatch>& matches) const {
-    MatchingResult mr = matchNodePair(target_node);
+    MatchingResult mr = matchNodePair(target_node, initial_matches);
     for (int i = 0; i < 16; i++) resulting_transformation[i] = mr.final_trafo[i];
     rmse = mr.rmse;
-    matches = mr.inlier_line_matches;
+    matches = (initial_matches && !initial_matches->empty()) ? mr.inlier_matches : mr.inlier_line_matches;
     return mr.edge.id1 >= 0;
   }
 };

@@ -33,7 +33,7 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + sources() + ["-o", LIB]
+    cmd = [hipcc] + FLAGS + os.environ.get("LF_EXTRA_CFLAGS", "").split() + sources() + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -205,7 +205,7 @@ class Context:
         elif which == 3:
             out = np.zeros(nm, np.uint32)
         else:
-            out = np.zeros(8, np.uint64)
+            out = np.zeros(16, np.uint64)
         self._chk(lib().lf_lsd_get_debug(self._h, frame, which, out.ctypes.data, out.nbytes,
                                          C.byref(n)), "lf_lsd_get_debug")
         return out[:n.value].copy() if which == 3 else out

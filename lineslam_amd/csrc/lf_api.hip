@@ -260,6 +260,8 @@ static int upload_lsd_tables(lf_ctx *c) {
   HIPCHK(c, hipMemcpyAsync((void *)c->lb.jy, jy.data(), jy.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync((void *)c->lb.lgam, lg.data(), lg.size() * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync((void *)c->lb.dconsts, &c->lc, sizeof(LsdConsts), hipMemcpyHostToDevice, c->stream));
+  lf_lsd_build_tables(c->lc, c->lb, c->stream);
+  HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));   // host vectors go out of scope
   return LF_OK;
 }
@@ -275,6 +277,10 @@ static int alloc_lsd(lf_ctx *c) {
   ALLOC(c, jx, (size_t)lc.N * lc.ntaps); ALLOC(c, jy, (size_t)lc.M * lc.ntaps);
   ALLOC(c, lgam, NM + 2); ALLOC(c, dc, 1);
   b.kx = kx; b.ky = ky; b.jx = jx; b.jy = jy; b.lgam = lgam; b.dconsts = dc;
+  {
+    const char *e = getenv("LF_NFA_TABLE");   // 0: evaluate nfa() every time (A/B parity test of the table)
+    if (!e || atoi(e) != 0) ALLOC(c, b.nfa_tab, (size_t)LF_MAX_PLEVEL * LF_NFA_TAB_TRI);
+  }
   ALLOC(c, b.aux, B * lc.H * lc.N);
   ALLOC(c, b.scaled, B * NM);
   ALLOC(c, b.angles, B * NM);
@@ -295,7 +301,7 @@ static int alloc_lsd(lf_ctx *c) {
   ALLOC(c, b.labels, B * NM);
   ALLOC(c, b.segs, B * (size_t)lc.seg_cap * LF_SEG_STRIDE);
   ALLOC(c, b.nsegs, B);
-  ALLOC(c, b.stats, B * 8);
+  ALLOC(c, b.stats, B * LF_STATS_STRIDE);
   ALLOC(c, c->d_gray_stage, (size_t)c->W * c->H);
   ALLOC(c, c->d_depth_stage, (size_t)c->W * c->H);
   // ---- 3D-line stage
@@ -462,7 +468,7 @@ int lf_lsd_get_debug(lf_ctx *c, int frame, int which, void *out, size_t out_byte
       HIPCHK(c, hipStreamSynchronize(c->stream));
       src = c->lb.seeds + frame * NM; bytes = (size_t)cnt * 4; break;
     }
-    case 4: src = c->lb.stats + (size_t)frame * 8; bytes = 64; cnt = 8; break;
+    case 4: src = c->lb.stats + (size_t)frame * LF_STATS_STRIDE; bytes = 8 * LF_STATS_STRIDE; cnt = LF_STATS_STRIDE; break;
     default: return LF_ERR_INVALID;
   }
   if (count) *count = cnt;

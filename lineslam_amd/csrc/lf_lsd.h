@@ -40,12 +40,16 @@ struct LsdConsts {
 };
 
 // Per-batch device pointers (frame f uses offset f * per-frame size).
+#define LF_STATS_STRIDE 16
+#define LF_NFA_TAB_N 512              // nfa(n, k, level) is tabulated for n < LF_NFA_TAB_N (triangular: n(n+1)/2 + k)
+#define LF_NFA_TAB_TRI (LF_NFA_TAB_N * (LF_NFA_TAB_N + 1) / 2)
 struct LsdBuffers {
   const uint8_t *gray;   size_t gray_frame_stride;  int gray_row_stride;  // input, bytes
   const double *kx, *ky; // [N][ntaps], [M][ntaps] Gaussian taps
   const int *jx, *jy;    // [N][ntaps], [M][ntaps] source indices after the symmetric boundary
   const double *lgam;    // log_gamma(i), i = 0 .. N*M+1
   const LsdConsts *dconsts; // device copy of the constants (for dynamically indexed tables)
+  double *nfa_tab;       // [LF_MAX_PLEVEL][LF_NFA_TAB_TRI] nfa() of small rectangles, filled by k_nfa_table; may be null
   double *aux;           // [B][H][N]
   double *scaled;        // [B][M][N]
   double *angles;        // [B][M][N]
@@ -63,8 +67,10 @@ struct LsdBuffers {
   uint16_t *labels;      // [B][M*N]   0 = none, k = k-th segment  (the integer pixel support)
   double *segs;          // [B][seg_cap][5]
   int *nsegs;            // [B]  (may exceed seg_cap: overflow)
-  unsigned long long *stats; // [B][8] optional work counters, may be null
+  unsigned long long *stats; // [B][LF_STATS_STRIDE] optional work counters, may be null
   hipEvent_t ev_pre, ev_sweep0, ev_sweep1;   // optional: recorded before the first kernel / around k_lsd_sweep
 };
 
+// (re)computes b.nfa_tab from the constants; call after every change of the LSD parameters
+void lf_lsd_build_tables(const LsdConsts &c, const LsdBuffers &b, hipStream_t stream);
 void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int n_frames, hipStream_t stream);

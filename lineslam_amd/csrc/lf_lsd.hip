@@ -234,6 +234,7 @@ struct FrameViewT {
   static constexpr bool kMW = MW_;
   int N, M, lane;
   const double *angles, *modgrad, *lgam, *cosang, *sinang;
+  const double *nfa_tab;  // tabulated nfa() for small n (null: always evaluate)
   const LsdConsts *dc;
   uint8_t *used;          // committed `used` mask of the frame
   uint8_t *tag;           // multi-wave sweep: this wavefront's PRIVATE marks (null: mark `used` directly)
@@ -243,6 +244,9 @@ struct FrameViewT {
   uint32_t *ever;         // multi-wave sweep: every pixel this region ever accepted (for validation)
   int ever_cap;
   int *n_ever, *overflow; // (wave-uniform values kept in memory visible to the helpers)
+#ifdef LF_SWEEP_PROFILE
+  u64 *gprof;             // [4] grow: windows, ticks waiting for the gathers, ticks deciding, hits
+#endif
 };
 // `used` as the growing region sees it: committed marks plus its own tentative marks
 typedef FrameViewT<false> FrameView;      // sequential sweep: marks go straight to `used`
@@ -290,10 +294,11 @@ __device__ __forceinline__ double d_angle_diff(double a, double b) {          //
 }
 
 // region_grow (lsd.cpp:1610-1656).  Slot s = 9*i + nb enumerates the reference's test order
-// (region pixel i; neighbour nb = 3*(xx-x+1) + (yy-y+1), xx outer, yy inner).  Each step tests the
-// next 64 slots against the CURRENT reg_angle; every slot before the first hit is a final "no";
-// the first hit is committed (used, reg[], sums, reg_angle = atan2) and the step restarts right
-// after it -- exactly the sequential semantics.
+// (region pixel i; neighbour nb = 3*(xx-x+1) + (yy-y+1), xx outer, yy inner).  Each step gathers the
+// next 64 slots once and then decides them in order from registers: every slot before the first hit is
+// a final "no"; the first hit is committed (used, reg[], sums, reg_angle) and the slots behind it are
+// re-tested against the new sums, and so on until the window is exhausted -- exactly the sequential
+// semantics, with one memory round trip per 64 slots.
 #define LF_RING 1024   // most recent region pixels kept in LDS (the growth front reads them back)
 // Alignment test of region_grow without atan2 on the critical path.  The reference decides
 //   | atan2(sumdy, sumdx) - a | (wrapped, lsd.cpp:799-832) < prec.
@@ -320,9 +325,10 @@ __device__ int d_region_grow(const FV &f, int sx, int sy, double prec, double co
   if (lane == 0) { uint32_t pk = (uint32_t)sx | ((uint32_t)sy << 16); f.reg[0] = pk; ring[0] = pk; fv_mark(f, seed); }
   wave_mem_order();
   int size = 1, cur = 0;
+  bool full = false;
   for (;;) {
-    int total = size * 9;
-    if (cur >= total) break;
+    const int total = size * 9;
+    if (cur >= total || full) break;
     (*n_steps)++;
     int slot = cur + lane;
     bool act = slot < total;
@@ -336,41 +342,74 @@ __device__ int d_region_grow(const FV &f, int sx, int sy, double prec, double co
     bool u = fv_is_used(f, ca);            // the gathers are issued together
     double cc = f.cosang[ca], ss = f.sinang[ca];
     bool cand = inb && !u && (cc <= 1.5);   // cos == 2 marks NOTDEF
-    bool ok;
+#ifdef LF_SWEEP_PROFILE
+    u64 tp0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    { int probe = __builtin_amdgcn_readfirstlane((int)cand + (int)(cc > 0.0)); asm volatile("" :: "s"(probe)); }
+    u64 tp1 = __builtin_amdgcn_s_memtime();
+#endif
+    // The window (64 slots) is decided entirely from registers: after a hit is accepted, the slots behind
+    // it are re-tested against the new sums (their pixel data cannot have changed except for the pixel just
+    // accepted, which is masked out) -- one gather latency per window instead of one per accepted pixel.
+    // No memory operation inside the decision loops: accepted lanes are collected in `cmask` and write
+    // their own used / reg / ring entries when the window is finished.
+    const int size0 = size;
+    u64 cmask = 0;
+    int lastL = -1;
+    bool need_exact = !fast;
     if (fast) {
-      double dot = sumdx * cc + sumdy * ss;
-      double lhs = dot * dot, rhs = cp2 * S2, band = 1e-12 * S2;
-      bool yes = cand && dot > 0.0 && lhs > rhs + band;
-      bool no = !cand || !(dot > 0.0) || lhs < rhs - band;
-      u64 amb = __ballot(!yes && !no);
-      if (amb == 0) ok = yes;
-      else {   // exact reference arithmetic for this step
-        if (!angle_valid) { reg_angle = lf_atan2(sumdy, sumdx); angle_valid = true; }
-        double a = cand ? f.angles[ca] : LF_NOTDEF;
-        ok = cand && d_isaligned(a, reg_angle, prec);
+      for (;;) {
+        bool pend = cand && lane > lastL;
+        double dot = sumdx * cc + sumdy * ss;
+        double lhs = dot * dot, rhs = cp2 * S2, band = 1e-12 * S2;
+        bool yes = pend && dot > 0.0 && lhs > rhs + band;
+        bool no = !pend || !(dot > 0.0) || lhs < rhs - band;
+        if (__ballot(!yes && !no) != 0) { need_exact = true; break; }   // ambiguous lane: exact arithmetic below
+        u64 mask = __ballot(yes);
+        if (mask == 0) break;
+        if constexpr (FV::kMW) { if (size >= f.cap) { *f.overflow = 1; full = true; break; } }   // speculative list full: caller re-runs at the frontier
+        int L = __builtin_ctzll(mask);
+        double cL = rl64(cc, L), sL = rl64(ss, L);
+        if (ca == rl32(ca, L)) cand = false;   // the accepted pixel (also when reached through another parent)
+        cmask |= 1ull << L;
+        size++;
+        sumdx += cL;
+        sumdy += sL;
+        S2 = sumdx * sumdx + sumdy * sumdy;
+        angle_valid = false;
+        lastL = L;
       }
-    } else {
-      if (!angle_valid) { reg_angle = lf_atan2(sumdy, sumdx); angle_valid = true; }
-      double a = cand ? f.angles[ca] : LF_NOTDEF;
-      ok = cand && d_isaligned(a, reg_angle, prec);
     }
-    u64 mask = __ballot(ok);
-    if (mask == 0) { cur += min(64, total - cur); continue; }
-    if constexpr (FV::kMW) { if (size >= f.cap) { *f.overflow = 1; break; } }   // speculative list full: caller re-runs at the frontier
-    int L = __builtin_ctzll(mask);
-    double cL = rl64(cc, L), sL = rl64(ss, L);
-    int caL = rl32(ca, L), cxL = rl32(cx, L), cyL = rl32(cy, L);
-    if (lane == 0) {
-      uint32_t npk = (uint32_t)cxL | ((uint32_t)cyL << 16);
-      fv_mark(f, caL); f.reg[size] = npk; ring[size & (LF_RING - 1)] = npk;
+    if (need_exact && !full) {   // the reference's own arithmetic for the rest of the window
+      double a_exact = cand ? f.angles[ca] : LF_NOTDEF;
+      for (;;) {
+        if (!angle_valid) { reg_angle = lf_atan2(sumdy, sumdx); angle_valid = true; }
+        bool ok = cand && lane > lastL && d_isaligned(a_exact, reg_angle, prec);
+        u64 mask = __ballot(ok);
+        if (mask == 0) break;
+        if constexpr (FV::kMW) { if (size >= f.cap) { *f.overflow = 1; full = true; break; } }
+        int L = __builtin_ctzll(mask);
+        double cL = rl64(cc, L), sL = rl64(ss, L);
+        if (ca == rl32(ca, L)) cand = false;
+        cmask |= 1ull << L;
+        size++;
+        sumdx += cL;
+        sumdy += sL;
+        S2 = sumdx * sumdx + sumdy * sumdy;
+        angle_valid = false;
+        lastL = L;
+      }
+    }
+#ifdef LF_SWEEP_PROFILE
+    { u64 tp2 = __builtin_amdgcn_s_memtime(); f.gprof[0]++; f.gprof[1] += tp1 - tp0; f.gprof[2] += tp2 - tp1; f.gprof[3] += (u64)__popcll(cmask); }
+#endif
+    if ((cmask >> lane) & 1ull) {
+      int at = size0 + __popcll(cmask & lanemask_lt());
+      uint32_t npk = (uint32_t)cx | ((uint32_t)cy << 16);
+      fv_mark(f, ca); f.reg[at] = npk; ring[at & (LF_RING - 1)] = npk;
     }
     wave_mem_order();
-    size++;
-    sumdx += cL;
-    sumdy += sL;
-    S2 = sumdx * sumdx + sumdy * sumdy;
-    angle_valid = false;
-    cur += L + 1;
+    cur += min(64, total - cur);
   }
   if (!angle_valid) reg_angle = lf_atan2(sumdy, sumdx);   // value after the last accepted pixel (lsd.cpp:1654)
   *reg_angle_io = reg_angle;
@@ -466,6 +505,7 @@ __device__ double d_nfa(const FV &f, int n, int k, double p, int plev, double lo
   const int lane = f.lane;
   const double tolerance = 0.1;
   if (n == 0 || k == 0) return -logNT;
+  if (n < LF_NFA_TAB_N && f.nfa_tab) return f.nfa_tab[(size_t)plev * LF_NFA_TAB_TRI + (size_t)(n * (n + 1) / 2 + k)];
   if (n == k) return -logNT - (double)n * f.dc->log10p[plev];
   double p_term = p / (1.0 - p);
   double log1term = f.lgam[n + 1] - f.lgam[k + 1] - f.lgam[n - k + 1] + (double)k * f.dc->logp[plev] +
@@ -500,6 +540,45 @@ __device__ double d_nfa(const FV &f, int n, int k, double p, int plev, double lo
     if (chunk < 64) chunk <<= 1;
   }
   return -lf_log10(bin_tail) - logNT;
+}
+
+// nfa (lsd.cpp:980-1065) evaluated sequentially by one thread -- the same arithmetic as d_nfa, term by
+// term -- for every (level, n, k) with n < LF_NFA_TAB_N: nfa depends on nothing else (p = c.p / 2^level,
+// logNT fixed by the image size), and most rectangles rect_improve tests are this small.
+__global__ void __launch_bounds__(256) k_nfa_table(LsdConsts c, const LsdConsts *dc, LsdBuffers b) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, plev = blockIdx.y;
+  if (t >= LF_NFA_TAB_TRI) return;
+  int n = (int)((lf_sqrt(8.0 * (double)t + 1.0) - 1.0) / 2.0);
+  while ((n + 1) * (n + 2) / 2 <= t) ++n;
+  while (n * (n + 1) / 2 > t) --n;
+  const int k = t - n * (n + 1) / 2;
+  const double tolerance = 0.1, logNT = c.logNT;
+  double p = c.p;
+  for (int i = 0; i < plev; i++) p /= 2.0;
+  double *out = b.nfa_tab + (size_t)plev * LF_NFA_TAB_TRI + t;
+  if (n == 0 || k == 0) { *out = -logNT; return; }
+  if (n == k) { *out = -logNT - (double)n * dc->log10p[plev]; return; }
+  double p_term = p / (1.0 - p);
+  double log1term = b.lgam[n + 1] - b.lgam[k + 1] - b.lgam[n - k + 1] + (double)k * dc->logp[plev] +
+                    (double)(n - k) * dc->log1mp[plev];
+  double term = lf_exp(log1term);
+  if (d_double_equal(term, 0.0)) {
+    if ((double)k > (double)n * p) *out = -log1term / LF_LN10 - logNT;
+    else *out = -logNT;
+    return;
+  }
+  double bin_tail = term;
+  for (int i = k + 1; i <= n; i++) {
+    double bin_term = (double)(n - i + 1) * (1.0 / (double)i);
+    double mult_term = bin_term * p_term;
+    term *= mult_term;
+    bin_tail += term;
+    if (bin_term < 1.0) {
+      double err = term * ((1.0 - lf_pow(mult_term, (double)(n - i + 1))) / (1.0 - mult_term) - 1.0);
+      if (err < tolerance * lf_fabs(-lf_log10(bin_tail) - logNT) * bin_tail) break;
+    }
+  }
+  *out = -lf_log10(bin_tail) - logNT;
 }
 
 // lsd.cpp:1183-1215
@@ -773,6 +852,7 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
   f.cosang = b.cosang + fidx * NM;
   f.sinang = b.sinang + fidx * NM;
   f.lgam = b.lgam;
+  f.nfa_tab = b.nfa_tab;
   f.dc = dc;
   __shared__ uint32_t ring1[LF_RING];
   f.used = b.used + fidx * NM;
@@ -787,9 +867,20 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
   double *segs = b.segs + (size_t)fidx * c.seg_cap * LF_SEG_STRIDE;
   const int nseeds = b.nseeds[fidx];
   u64 n_grow = 0, n_steps = 0, n_nfa = 0, n_px = 0, n_regpx = 0;
+#ifdef LF_SWEEP_PROFILE   // build with LF_EXTRA_CFLAGS=-DLF_SWEEP_PROFILE: s_memtime per phase -> stats[8..15]
+  u64 cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u64 gp[4] = {0, 0, 0, 0};
+  f.gprof = gp;
+  u64 t_prev = __builtin_amdgcn_s_memtime();
+  const u64 t_begin = t_prev;
+#define PROF(k) do { u64 t_now = __builtin_amdgcn_s_memtime(); cyc[k] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define PROF(k) do { } while (0)
+#endif
   int ls_count = 0;
   int s = 0;
   while (s < nseeds) {
+    PROF(6);
     int idx = s + lane;
     bool v = idx < nseeds;
     uint32_t addr = v ? seeds[idx] : 0u;
@@ -802,13 +893,19 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
     int sx = sa % c.N, sy = sa / c.N;
     double reg_angle;
     ++n_grow;
+    PROF(0);
     int reg_size = d_region_grow(f, sx, sy, c.prec, c.cos_prec, &reg_angle, &n_steps);
+    PROF(1);
     n_regpx += (u64)reg_size;
     if (reg_size < c.min_reg_size) continue;
     Rect rec;
     d_region2rect(f, reg_size, reg_angle, c.prec, c.p, 0, &rec);
-    if (!d_refine(f, &reg_size, reg_angle, c.prec, c.p, &rec, c.density_th, &n_steps)) continue;
+    PROF(2);
+    bool okr = d_refine(f, &reg_size, reg_angle, c.prec, c.p, &rec, c.density_th, &n_steps);
+    PROF(3);
+    if (!okr) continue;
     double log_nfa = d_rect_improve(f, &rec, c.logNT, c.eps, &n_nfa, &n_px);
+    PROF(4);
     if (log_nfa <= c.eps) continue;
     ++ls_count;
     rec.x1 += 0.5; rec.y1 += 0.5;
@@ -829,16 +926,23 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
         labels[(int)(pk >> 16) * c.N + (int)(pk & 0xffffu)] = (uint16_t)ls_count;
       }
     }
+    PROF(5);
   }
   if (lane == 0) {
     b.nsegs[fidx] = ls_count;
     if (b.stats) {
-      unsigned long long *st = b.stats + (size_t)fidx * 8;
+      unsigned long long *st = b.stats + (size_t)fidx * LF_STATS_STRIDE;
       st[0] = n_grow; st[1] = n_steps; st[2] = n_nfa; st[3] = n_px; st[4] = n_regpx;
       st[5] = (u64)nseeds; st[6] = 0; st[7] = 0;
+#ifdef LF_SWEEP_PROFILE
+      for (int k = 0; k < 7; k++) st[8 + k] = cyc[k];   // 0 seed scan, 1 grow, 2 region2rect, 3 refine, 4 rect_improve, 5 output, 6 loop
+      st[15] = t_prev - t_begin;
+      st[6] = gp[1]; st[7] = gp[2]; st[14] = gp[0];
+#endif
     }
   }
 }
+#undef PROF
 
 
 // ----------------------------------------------------------------------------------------------
@@ -891,12 +995,17 @@ __global__ void __launch_bounds__(W * 64) k_lsd_sweep_mw(LsdConsts c, const LsdC
   if (threadIdx.x == 0) { ctl.lock = 0; ctl.scan = 0; ctl.next_ticket = 0; ctl.frontier = 0; ctl.ls_count = 0; ctl.done = 0; }
   __syncthreads();
   FrameViewMW f;
+#ifdef LF_SWEEP_PROFILE
+  __shared__ u64 gprof_sink[4];
+  f.gprof = gprof_sink;
+#endif
   f.N = c.N; f.M = c.M; f.lane = lane;
   f.angles = b.angles + fidx * NM;
   f.modgrad = b.modgrad + fidx * NM;
   f.cosang = b.cosang + fidx * NM;
   f.sinang = b.sinang + fidx * NM;
   f.lgam = b.lgam;
+  f.nfa_tab = b.nfa_tab;
   f.dc = dc;
   f.used = b.used + fidx * NM;
   f.tag = b.mw_tag + ((size_t)fidx * W + wave) * NM;
@@ -1015,13 +1124,18 @@ __global__ void __launch_bounds__(W * 64) k_lsd_sweep_mw(LsdConsts c, const LsdC
   __syncthreads();
   if (threadIdx.x == 0) b.nsegs[fidx] = ctl.ls_count;
   if (lane == 0 && b.stats) {
-    unsigned long long *st = b.stats + (size_t)fidx * 8;
+    unsigned long long *st = b.stats + (size_t)fidx * LF_STATS_STRIDE;
     atomicAdd(&st[0], n_regions); atomicAdd(&st[1], n_steps); atomicAdd(&st[2], n_nfa);
     atomicAdd(&st[3], n_redo); atomicAdd(&st[4], n_dropped); atomicAdd(&st[5], n_px);
   }
 }
 
 // ----------------------------------------------------------------------------------------------
+void lf_lsd_build_tables(const LsdConsts &c, const LsdBuffers &b, hipStream_t st) {
+  if (!b.nfa_tab) return;
+  hipLaunchKernelGGL(k_nfa_table, dim3((LF_NFA_TAB_TRI + 255) / 256, LF_MAX_PLEVEL), dim3(256), 0, st, c, b.dconsts, b);
+}
+
 void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int B, hipStream_t st) {
   const size_t NM = (size_t)c.N * c.M;
   dim3 blk(256);
@@ -1038,7 +1152,7 @@ void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int B, hipStream_t s
   (void)hipMemsetAsync(b.labels, 0, NM * (size_t)B * sizeof(uint16_t), st);
   if (b.ev_sweep0) (void)hipEventRecord(b.ev_sweep0, st);
   if (c.sweep_waves > 1) {
-    (void)hipMemsetAsync(b.stats, 0, sizeof(unsigned long long) * 8 * (size_t)B, st);
+    (void)hipMemsetAsync(b.stats, 0, sizeof(unsigned long long) * LF_STATS_STRIDE * (size_t)B, st);
     if (c.sweep_waves >= 8) hipLaunchKernelGGL(k_lsd_sweep_mw<8>, dim3(B), dim3(8 * 64), 0, st, c, b.dconsts, b);
     else if (c.sweep_waves >= 4) hipLaunchKernelGGL(k_lsd_sweep_mw<4>, dim3(B), dim3(4 * 64), 0, st, c, b.dconsts, b);
     else hipLaunchKernelGGL(k_lsd_sweep_mw<2>, dim3(B), dim3(2 * 64), 0, st, c, b.dconsts, b);

@@ -7,7 +7,10 @@ meaning as the reference so that the parity tests read like the reference's call
     node.lineMatching(other, adjacent)       <-> Node::lineMatching           (node.cpp:1619-1694)
     node.matchNodePair(older)                <-> Node::matchNodePair          (node.cpp:1494-1615)
     node.getRelativeTransformationTo(older)  <-> Node::getRelativeTransformationTo (node.h:124-128): the
-        legacy point-RANSAC entry, routed to the same solver with the point-match list empty.
+        legacy point-RANSAC entry, routed to the same solver; `initial_matches` are the point matches.
+Points: `node.feature_locations_3d_` ([n,4] float32: x,y,z,1, z = NaN without depth) is filled by the caller
+(keypoint extraction / descriptor matching are outside the accelerated path); when point matches are passed,
+the hybrid solver (BASELINE config 3) runs.
 """
 import numpy as np
 
@@ -18,6 +21,8 @@ class MatchingResult:
     """src/matching_result.h:23-49 (+ LoadedEdge3D, src/edge.h:25-33), line part."""
 
     def __init__(self):
+        self.all_matches = []             # point matches (queryIdx, trainIdx)
+        self.inlier_matches = []
         self.all_line_matches = []        # (queryIdx, trainIdx, distance)
         self.inlier_line_matches = []
         self.rmse = 0.0
@@ -44,6 +49,7 @@ class Node:
             ctx = Node._shared_ctx[key]
         self._ctx = ctx
         self.lines = np.zeros(0, capi.REC_DTYPE)
+        self.feature_locations_3d_ = np.zeros((0, 4), np.float32)
         self.detect3DLines(gray_uchar, depth_float, self.params.line_segment_len_thresh, self.K,
                            self.params.ratio_of_collinear_pts, self.params.line3d_length_thresh,
                            self.params.depth_scaling, "LSD")
@@ -58,24 +64,36 @@ class Node:
         self._ctx.set_params(p)
         self.lines = self._ctx.detect3d(gray_uchar, depth_float, K, frame_id=self.id_)
 
-    def _pair(self, older):
+    def _pair(self, older, point_matches=None):
         p = self.params
         self._ctx.set_params(p)
-        r = self._ctx.match_node_pair(self.lines, self.id_, older.lines, older.id_)
+        pinl = np.zeros(0, np.int32)
+        if point_matches is not None and len(point_matches):
+            pm = np.asarray([(m[0], m[1]) for m in point_matches], np.int32).reshape(-1, 2)
+            r = self._ctx.match_node_pair_hybrid(self.lines, self.id_, self.feature_locations_3d_, older.lines, older.id_,
+                                                 older.feature_locations_3d_, pm[:, 0], pm[:, 1], self.K)
+            if r.n_point_inliers:
+                pinl = self._ctx.pair_point_inliers(0)
+        else:
+            r = self._ctx.match_node_pair(self.lines, self.id_, older.lines, older.id_)
         mq, mt, md = self._ctx.pair_matches(0)
         inl = self._ctx.pair_inliers(0) if r.n_inliers else np.zeros(0, np.int32)
-        return r, mq, mt, md, inl
+        return r, mq, mt, md, inl, pinl
 
     def lineMatching(self, other, adjacentFrame=None, matches=None):
         """Appends (queryIdx, trainIdx, distance) to `matches`; returns the count (node.cpp:1619)."""
-        r, mq, mt, md, _ = self._pair(other)
+        r, mq, mt, md, _, _ = self._pair(other)
         out = matches if matches is not None else []
         out.extend(zip(mq.tolist(), mt.tolist(), md.tolist()))
         return len(out)
 
-    def matchNodePair(self, older_node):
-        r, mq, mt, md, inl = self._pair(older_node)
+    def matchNodePair(self, older_node, point_matches=None):
+        """point_matches: MatchingResult::all_matches as (queryIdx, trainIdx[, distance]) tuples, or None."""
+        r, mq, mt, md, inl, pinl = self._pair(older_node, point_matches)
         mr = MatchingResult()
+        if point_matches is not None:
+            mr.all_matches = list(point_matches)
+            mr.inlier_matches = [mr.all_matches[i] for i in pinl.tolist()]
         mr.all_line_matches = list(zip(mq.tolist(), mt.tolist(), md.tolist()))
         mr.inlier_line_matches = [mr.all_line_matches[i] for i in inl.tolist()]
         mr.rmse = float(r.rmse)
@@ -89,5 +107,6 @@ class Node:
 
     def getRelativeTransformationTo(self, target_node, initial_matches=None):
         """(found, transformation, rmse, inlier matches) -- node.h:124-128."""
-        mr = self.matchNodePair(target_node)
-        return mr.edge_id1 >= 0, mr.final_trafo, mr.rmse, mr.inlier_line_matches
+        mr = self.matchNodePair(target_node, initial_matches)
+        inl = mr.inlier_matches if initial_matches is not None and len(initial_matches) else mr.inlier_line_matches
+        return mr.edge_id1 >= 0, mr.final_trafo, mr.rmse, inl

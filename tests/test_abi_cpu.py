@@ -42,3 +42,15 @@ def test_no_cpu_fallback_without_a_gpu(built_lib):
     with pytest.raises(capi.LinefrontError) as e:
         capi.Context(640, 480)
     assert e.value.status == capi.LF_ERR_NO_DEVICE
+
+
+def test_cpp_mirror_header_compiles():
+    """include/linefront_compat.hpp is header-only C++ on the C ABI: it must at least parse and type-check."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "compat_smoke.cpp")], check=True)

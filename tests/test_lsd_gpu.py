@@ -69,3 +69,24 @@ def test_lsd_flat_and_noise_images(built_lib):
         assert segs.shape == so.shape and np.array_equal(segs, so)
         assert np.array_equal(labels.astype(np.int32), lo)
         ctx.close()
+
+
+@pytest.mark.parametrize("ang", [22.5, 40.0])
+def test_nfa_table_equals_direct_evaluation(built_lib, monkeypatch, ang):
+    """rect_improve reads nfa(n, k, level) of small rectangles from a table filled by k_nfa_table at context
+    creation; LF_NFA_TABLE=0 evaluates every nfa() in the sweep itself.  Both must give the same frames."""
+    import torch
+    from lineslam_amd import capi, synth
+    g, _, _ = synth.sequence(6, seed=11)
+    d = torch.from_numpy(g).cuda()
+    p = capi.default_params()
+    p.lsd_angle_th = ang
+    out = []
+    for tab in ("1", "0"):
+        monkeypatch.setenv("LF_NFA_TABLE", tab)
+        ctx = capi.Context(640, 480, max_batch=6, params=p)
+        ctx.lsd_batch_device(d.data_ptr(), 6)
+        out.append([(ctx.lsd_segments(k), ctx.lsd_labels(k)) for k in range(6)])
+        ctx.close()
+    for (s1, l1), (s0, l0) in zip(*out):
+        assert len(s1) > 50 and np.array_equal(s1, s0) and np.array_equal(l1, l0)

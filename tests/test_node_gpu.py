@@ -25,3 +25,65 @@ def test_node_pair_like_the_reference_call_sites(built_lib):
     assert np.linalg.norm(mr.final_trafo[:3, 3] - Tgt[:3, 3]) < 0.02
     found, T, rmse, inl = newer.getRelativeTransformationTo(older)
     assert found and np.array_equal(T, mr.final_trafo) and len(inl) == len(mr.inlier_line_matches)
+
+
+def test_node_pair_with_point_matches(built_lib):
+    """config 3 through the Node mirror: points + lines, legacy getRelativeTransformationTo with initial_matches."""
+    from lineslam_amd.node import Node
+    g, d, poses = synth.sequence(2, seed=6)
+    older = Node(g[0], d[0], synth.K_TUM, 0)
+    newer = Node(g[1], d[1], synth.K_TUM, 1)
+    rng = np.random.default_rng(2)
+    n = 120
+    Pw = np.c_[rng.uniform(-1, 1, n), rng.uniform(-0.8, 0.8, n), rng.uniform(1.0, 3.0, n), np.ones(n)]
+    Pw = (poses[0] @ Pw.T).T
+    for node, pose in ((older, poses[0]), (newer, poses[1])):
+        pc = (np.linalg.inv(pose) @ Pw.T).T
+        pc[:, :3] += rng.normal(0, 0.002, (n, 3))
+        pc[:, 3] = 1
+        node.feature_locations_3d_ = pc.astype(np.float32)
+    pm = [(i, i, 0.0) for i in range(n)]
+    for i in range(0, n, 6):
+        pm[i] = (i, (i + 7) % n, 0.0)
+    mr = newer.matchNodePair(older, pm)
+    assert mr.edge_id1 == 0 and mr.edge_id2 == 1
+    assert 80 <= len(mr.inlier_matches) <= 100 and all(m[0] == m[1] for m in mr.inlier_matches)
+    assert len(mr.inlier_line_matches) > 10
+    Tgt = np.linalg.inv(poses[0]) @ poses[1]
+    assert np.linalg.norm(mr.final_trafo[:3, 3] - Tgt[:3, 3]) < 0.02
+    found, T, rmse, inl = newer.getRelativeTransformationTo(older, pm)
+    assert found and np.array_equal(T, mr.final_trafo) and inl == mr.inlier_matches
+
+
+def test_cpp_mirror_builds_and_agrees(built_lib, tmp_path):
+    """include/linefront_compat.hpp (the C++ Node mirror) through examples/compat_smoke.cpp vs the Python mirror."""
+    import os
+    import shutil
+    import subprocess
+    from lineslam_amd.node import Node
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "compat_smoke")
+    libdir = os.path.join(root, "lineslam_amd")
+    subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "compat_smoke.cpp"),
+                    "-L" + libdir, "-llinefront", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    g, d, poses = synth.sequence(2, seed=5)
+    files = []
+    for i in range(2):
+        for arr, nm in ((g[i], "g"), (d[i], "d")):
+            f = str(tmp_path / ("%s%d.bin" % (nm, i)))
+            np.ascontiguousarray(arr).tofile(f)
+            files.append(f)
+    import torch
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([exe] + files, check=True, capture_output=True, text=True, env=env, timeout=300).stdout.splitlines()
+    older = Node(g[0], d[0], synth.K_TUM, 0)
+    newer = Node(g[1], d[1], synth.K_TUM, 1)
+    mr = newer.matchNodePair(older)
+    assert out[0] == "node 0: %d 3D lines" % len(older.lines) and out[1] == "node 1: %d 3D lines" % len(newer.lines)
+    assert out[2].startswith("matches %d inliers %d " % (len(mr.all_line_matches), len(mr.inlier_line_matches)))
+    assert out[2].endswith("valid 1")
+    T = np.array([[float(v) for v in ln.split()] for ln in out[3:7]])
+    assert np.allclose(T, mr.final_trafo, atol=1e-6)

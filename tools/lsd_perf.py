@@ -19,4 +19,8 @@ for it in range(3):
     torch.cuda.synchronize(); dt = time.time() - t
     print("iter %d: B=%d  %.1f ms  -> %.0f frames/s" % (it, B, dt * 1e3, B / dt))
 st = ctx.lsd_debug(0, 4)
-print("frame0: grow=%d steps=%d rect_nfa=%d reg_px=%d nseg=%d | cycles total=%.1fM grow=%.1fM rect2rect+refine=%.1fM rect_improve=%.1fM" % (int(st[0]), int(st[1]), int(st[2]), int(st[4]), len(ctx.lsd_segments(0)), st[5]/1e6, st[6]/1e6, st[3]/1e6, st[7]/1e6))
+print("frame0: grows=%d steps=%d rect_nfa=%d rect_px=%d reg_px=%d nseeds=%d nseg=%d" % (int(st[0]), int(st[1]), int(st[2]), int(st[3]), int(st[4]), int(st[5]), len(ctx.lsd_segments(0))))
+if st[15]:
+    names = ["seed scan", "grow", "region2rect", "refine", "rect_improve", "output", "loop"]
+    print("grow windows %d: wait %.2fM decide %.2fM" % (int(st[14]), st[6] / 1e6, st[7] / 1e6))
+    print("s_memtime ticks (100 MHz): total %.2fM | " % (st[15] / 1e6) + ", ".join("%s %.2fM" % (n, st[8 + k] / 1e6) for k, n in enumerate(names)))
