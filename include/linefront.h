@@ -80,6 +80,9 @@ typedef struct lf_params {
   /* the reference draws from the unseeded global rand(); this library uses a counter-based
    * generator keyed by (seed, frame id, line id / pair id, draw index)               */
   uint64_t rng_seed;                  /* 0 */
+  /* lines-only RANSAC computeRelativeMotion_Ransac (src/line/motion.cpp:367-526) */
+  double pt2line3d_dist_relmotion;    /* 0.05 m  3d_pt2line_dst_relmot_m (parameter_server.cpp:188) */
+  double line3d_angle_relmotion;      /* 10 deg  3d_line_angle_relmot_deg (:189) */
 } lf_params;
 
 /* One 3D line of a frame: the flat, fixed-stride form of the reference's FrameLine /
@@ -231,6 +234,18 @@ LF_API int lf_match_node_pair_hybrid(lf_ctx *ctx, const lf_line_record *newer, i
                                      int n_older, uint64_t id_older, const float *pts_older, int n_pts_older,
                                      const int32_t *pm_query, const int32_t *pm_train, int n_pm, const double K[9],
                                      lf_pair_result *out);
+
+/* ---- lines-only RANSAC -------------------------------------------------
+ * As lf_match_pairs_device, but the line matches go to computeRelativeMotion_Ransac
+ * (src/line/motion.cpp:367-526: 3-line samples with the 5-degree degeneracy test, Euclidean consensus
+ * test with pt2line3d_dist_relmotion / line3d_angle_relmotion, optimizeRelmotion = levmar on quaternion + t,
+ * repeated while the consensus set grows) instead of getTransform_PtsLines_ransac.  Results:
+ * lf_pair_get_result (T = (R|t) rounded to float, n_inliers = size of the returned consensus set, valid <=>
+ * that set is not empty; rmse / information_scale are not defined by this solver and are 0),
+ * lf_pair_get_inliers (the returned index vector), lf_pair_get_motion (Ro, to in double).       */
+LF_API int lf_relmotion_pairs_device(lf_ctx *ctx, const int32_t *query_frames, const int32_t *train_frames,
+                                     int n_pairs);
+LF_API int lf_pair_get_motion(lf_ctx *ctx, int pair, double R[9], double t[3]);
 
 /* Stage durations (ms) of the last launches, measured with HIP events recorded on the context
  * stream: which = 0 LSD data-parallel kernels, 1 the LSD sweep kernel (k_lsd_sweep), 2 the 3D-line

@@ -34,6 +34,7 @@ class LfParams(C.Structure):
         ("min_matches_loopclose", C.c_int), ("max_mah_dist_for_inliers", C.c_double),
         ("g2o_line_error_weight", C.c_double), ("g2o_BA_use_kernel", C.c_int),
         ("g2o_BA_kernel_delta", C.c_double), ("rng_seed", C.c_uint64),
+        ("pt2line3d_dist_relmotion", C.c_double), ("line3d_angle_relmotion", C.c_double),
     ]
 
 
@@ -80,6 +81,8 @@ SYMBOLS = {
     "lf_match_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, C.c_uint64, _vp]),
     "lf_match_pairs_hybrid_device": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "lf_pair_get_point_inliers": (_i, [_vp, _i, _vp, _i, _pi]),
+    "lf_relmotion_pairs_device": (_i, [_vp, _vp, _vp, _i]),
+    "lf_pair_get_motion": (_i, [_vp, _i, _vp, _vp]),
     "lf_match_node_pair_hybrid": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, _vp, _i, C.c_uint64, _vp, _i, _vp, _vp, _i,
                                        _vp, _vp]),
 }
@@ -280,6 +283,19 @@ class Context:
         self._chk(lib().lf_match_pairs_hybrid_device(self._h, q.ctypes.data, t.ctypes.data, len(q), int(d_points_ptr),
                                                      int(pt_cap), a.ctypes.data, b.ctypes.data, n.ctypes.data,
                                                      a.shape[1], Kc.ctypes.data), "lf_match_pairs_hybrid_device")
+
+    def relmotion_pairs_device(self, query_frames, train_frames):
+        """Line matching + computeRelativeMotion_Ransac (lines-only RANSAC, motion.cpp:367-526) per pair (async)."""
+        q = np.ascontiguousarray(query_frames, np.int32)
+        t = np.ascontiguousarray(train_frames, np.int32)
+        assert q.shape == t.shape and q.ndim == 1
+        self._chk(lib().lf_relmotion_pairs_device(self._h, q.ctypes.data, t.ctypes.data, len(q)),
+                  "lf_relmotion_pairs_device")
+
+    def pair_motion(self, pair):
+        R, t = np.zeros(9), np.zeros(3)
+        self._chk(lib().lf_pair_get_motion(self._h, pair, R.ctypes.data, t.ctypes.data), "lf_pair_get_motion")
+        return R.reshape(3, 3), t
 
     def pair_point_inliers(self, pair, cap=512):
         m = np.zeros(cap, np.int32)

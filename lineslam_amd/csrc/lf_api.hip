@@ -119,6 +119,8 @@ void lf_params_init(lf_params *p) {
   p->g2o_BA_use_kernel = 1;               // lineslam.cpp:629
   p->g2o_BA_kernel_delta = 10;            // lineslam.cpp:630
   p->rng_seed = 0;
+  p->pt2line3d_dist_relmotion = 0.05;     // :188
+  p->line3d_angle_relmotion = 10;         // :189
 }
 void lf_params_init_launch(lf_params *p) {
   lf_params_init(p);
@@ -328,6 +330,7 @@ static int alloc_lsd(lf_ctx *c) {
   memset(&pb, 0, sizeof pb);
   pcn.line_cap = fc.line_cap; pcn.match_cap = LF_MAX_MATCHES;
   pcn.cos_angle_thresh = cos(30 * 3.14159265 / 180);   // node.cpp:1624 with lineslam.h:38 PI
+  pcn.cos_degeneracy = cos(5 * 3.14159265 / 180);      // motion.cpp:407
   ALLOC(c, c->d_pair_q, B); ALLOC(c, c->d_pair_t, B);
   ALLOC(c, pb.D, B * (size_t)fc.line_cap * fc.line_cap);
   ALLOC(c, pb.match_q, B * (size_t)pcn.match_cap); ALLOC(c, pb.match_t, B * (size_t)pcn.match_cap);
@@ -336,6 +339,7 @@ static int alloc_lsd(lf_ctx *c) {
   ALLOC(c, pb.results, B);
   ALLOC(c, pb.inliers, B * (size_t)LF_MAX_MATCHES);
   ALLOC(c, pb.ws, B * (size_t)LF_PAIR_WS_DOUBLES);
+  ALLOC(c, pb.motion_d, B * (size_t)LF_MOTION_STRIDE);
   pb.recs = fb.recs; pb.nlines = fb.nlines; pb.frame_ids = c->d_frame_ids;
   pb.recs_t = fb.recs; pb.nlines_t = fb.nlines; pb.frame_ids_t = c->d_frame_ids; pb.line_cap_t = fc.line_cap;
   pb.pair_q = c->d_pair_q; pb.pair_t = c->d_pair_t;
@@ -625,7 +629,8 @@ static int hybrid_prepare(lf_ctx *c, const HybridArgs &h, int n_pairs, PairBuffe
 
 static int match_pairs_impl(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
                             const lf_line_record *d_ext_recs, const int32_t *d_ext_nlines,
-                            const uint64_t *d_ext_ids, int ext_frames, int ext_line_cap, const HybridArgs *hy = nullptr) {
+                            const uint64_t *d_ext_ids, int ext_frames, int ext_line_cap, const HybridArgs *hy = nullptr,
+                            bool relmotion = false) {
   if (!c || !query_frames || !train_frames || n_pairs < 1) return LF_ERR_INVALID;
   if (n_pairs > c->maxB) return LF_ERR_CAPACITY;
   const int ntrain = d_ext_recs ? ext_frames : c->last_batch;
@@ -641,7 +646,7 @@ static int match_pairs_impl(lf_ctx *c, const int32_t *query_frames, const int32_
   if (hy) { int r = hybrid_prepare(c, *hy, n_pairs, pb); if (r != LF_OK) return r; }
   if (d_ext_recs) { pb.recs_t = d_ext_recs; pb.nlines_t = d_ext_nlines; pb.frame_ids_t = d_ext_ids; pb.line_cap_t = ext_line_cap; }
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-  lf_pair_launch(c->pcn, pb, n_pairs, c->stream, hy != nullptr);
+  lf_pair_launch(c->pcn, pb, n_pairs, c->stream, hy ? LF_SOLVER_HYBRID : (relmotion ? LF_SOLVER_RELMOTION : LF_SOLVER_LINES));
   c->last_hybrid = hy != nullptr;
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   HIPCHK(c, hipGetLastError());
@@ -666,6 +671,21 @@ int lf_match_pairs_hybrid_device(lf_ctx *c, const int32_t *query_frames, const i
   if (!c) return LF_ERR_INVALID;
   HybridArgs h = {d_points, pt_cap, pm_query, pm_train, n_pm, pm_cap, K};
   return match_pairs_impl(c, query_frames, train_frames, n_pairs, nullptr, nullptr, nullptr, 0, 0, &h);
+}
+
+int lf_relmotion_pairs_device(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs) {
+  return match_pairs_impl(c, query_frames, train_frames, n_pairs, nullptr, nullptr, nullptr, 0, 0, nullptr, true);
+}
+
+int lf_pair_get_motion(lf_ctx *c, int pair, double R[9], double t[3]) {
+  if (!c || !R || !t || pair < 0 || pair >= c->last_pairs) return LF_ERR_INVALID;
+  double h[LF_MOTION_STRIDE];
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(h, c->pb.motion_d + (size_t)pair * LF_MOTION_STRIDE, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 9; i++) R[i] = h[i];
+  for (int i = 0; i < 3; i++) t[i] = h[9 + i];
+  return LF_OK;
 }
 
 int lf_pair_get_point_inliers(lf_ctx *c, int pair, int32_t *match_idx, int cap, int *n_out) {

@@ -30,6 +30,7 @@ LF_HD uint32_t lf_rand31(uint64_t seed, uint64_t stream, uint64_t counter) {
   return (uint32_t)(lf_mix64(k + counter * 0xD1B54A32D192ED03ULL) >> 33);
 }
 #define LF_STREAM_LINE3D(frame, line) ((((uint64_t)(frame)) << 24) ^ (uint64_t)(line) ^ 0x1000000000000000ULL)
+#define LF_STREAM_RELMOTION(fq, ft) ((((uint64_t)(fq)) << 32) ^ (uint64_t)(uint32_t)(ft) ^ 0x3000000000000000ULL)
 #define LF_STREAM_PAIR(fq, ft) ((((uint64_t)(fq)) << 32) ^ (uint64_t)(uint32_t)(ft) ^ 0x2000000000000000ULL)
 
 /* ---------------------------------------------------------------- Jacobi eigen-decomposition

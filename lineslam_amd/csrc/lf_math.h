@@ -95,6 +95,13 @@ LF_HD double lf_atan2(double y, double x) {
   return lf_copysign(z, y);
 }
 
+/* acos(x) = 2 atan2(sqrt(1-x), sqrt(1+x)): 1-x and 1+x are exact or correctly rounded, so the result stays
+ * within a few ulp on the whole of [-1,1] (also next to +-1); NaN outside, as libm. */
+LF_HD double lf_acos(double x) {
+  if (!(x >= -1.0 && x <= 1.0)) return lf_from_bits(0x7ff8000000000000ULL);
+  return 2.0 * lf_atan2(lf_sqrt(1.0 - x), lf_sqrt(1.0 + x));
+}
+
 /* ---------------------------------------------------------------- sin/cos */
 LF_HD double lf_ksin(double x, double y) {
   const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,

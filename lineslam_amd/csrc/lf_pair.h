@@ -10,6 +10,7 @@
 
 #define LF_MAX_MATCHES 256        // line matches per pair handled by the pose kernel (4 per lane)
 #define LF_RANSAC_MAX_ITERS 1024  // sample table capacity
+#define LF_MOTION_STRIDE 16
 #define LF_MAX_PT_MATCHES 512     // point matches per pair handled by the hybrid pose kernel (8 per lane)
 #define LF_PAIR_WS_DOUBLES (LF_MAX_MATCHES * (120 + 36 + 42 + 6 + 6))   // per-pair LM workspace
 
@@ -20,6 +21,7 @@ struct PairConsts {
   int match_cap;             // rows of the match list per pair
   lf_point_model pm;         // hybrid solver: errorFunction2 constants (misc.cpp:704-711, host libm)
   double focal;              //   K(0,0) for compPt3dCov (transformation_estimation.cpp:245)
+  double cos_degeneracy;     // cos(5 * 3.14159265 / 180), host libm (motion.cpp:407,428)
 };
 
 struct PairBuffers {
@@ -45,8 +47,11 @@ struct PairBuffers {
   const int *npm;               // [n_pairs]
   int *pt_inliers;              // [n_pairs][LF_MAX_PT_MATCHES] indices into the point match list
   double *ws_h;                 // [n_pairs][lf_pair_hybrid_ws_doubles()]
+  double *motion_d;             // [n_pairs][LF_MOTION_STRIDE] lines-only RANSAC: R (9), t (3), diagnostics
 };
 
-void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t stream, bool hybrid = false);
+enum { LF_SOLVER_LINES = 0, LF_SOLVER_HYBRID = 1, LF_SOLVER_RELMOTION = 2 };   // what follows k_match
+void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t stream, int solver = LF_SOLVER_LINES);
+void lf_pair_relmotion_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t stream);
 size_t lf_pair_hybrid_ws_doubles();
 void lf_pair_hybrid_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t stream);

@@ -471,8 +471,9 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
   }
 }
 
-void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t st, bool hybrid) {
+void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t st, int solver) {
   hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(256), 0, st, c, b);
-  if (hybrid) lf_pair_hybrid_launch(c, b, n_pairs, st);
+  if (solver == LF_SOLVER_HYBRID) lf_pair_hybrid_launch(c, b, n_pairs, st);
+  else if (solver == LF_SOLVER_RELMOTION) lf_pair_relmotion_launch(c, b, n_pairs, st);
   else hipLaunchKernelGGL(k_pose, dim3(n_pairs), dim3(64), 0, st, c, b);
 }

@@ -361,6 +361,82 @@ LF_HD void lf_older_pose_to_tf(const lf_se3 *X, float *tf) {
 }
 
 
+/* ================================================================ lines-only RANSAC (a24)
+ * computeRelativeMotion_Ransac (src/line/motion.cpp:367-526) + optimizeRelmotion (:98-139).
+ * a = lines of the newer (query) node, b = the matched lines of the older (train) node; x_b = R x_a + t. */
+/* r2q(cv::Mat R), utils.cpp:1696-1707 */
+LF_HD void lf_r2q(const double *R, double *q) {
+  double t = R[0] + R[4] + R[8];
+  double r = lf_sqrt(1 + t);
+  double s = 0.5 / r;
+  q[0] = 0.5 * r;
+  q[1] = (R[7] - R[5]) * s;
+  q[2] = (R[2] - R[6]) * s;
+  q[3] = (R[3] - R[1]) * s;
+}
+/* dist3d_pt_line(cv::Point3d X, A, B), utils.cpp:626-636 (EPS 1e-10, lineslam.h:37) */
+LF_HD double lf_dist3d_pt_line(const double *X, const double *A, const double *B) {
+  double AB[3] = {A[0] - B[0], A[1] - B[1], A[2] - B[2]}, XA[3] = {X[0] - A[0], X[1] - A[1], X[2] - A[2]};
+  double nAB = lf_norm3(AB), ax, inv, nv[3], d;
+  if (nAB < 1e-10) return -1;
+  ax = lf_norm3(XA);
+  inv = 1 / nAB;
+  nv[0] = (B[0] - A[0]) * inv; nv[1] = (B[1] - A[1]) * inv; nv[2] = (B[2] - A[2]) * inv;
+  d = XA[0] * nv[0] + XA[1] * nv[1] + XA[2] * nv[2];
+  return lf_sqrt(lf_fabs(ax * ax - d * d));
+}
+LF_HD void lf_rt_apply(const double *R, const double *t, const double *x, double *out) {       /* R x + t */
+  int r;
+  for (r = 0; r < 3; r++) out[r] = ((R[3 * r] * x[0] + R[3 * r + 1] * x[1]) + R[3 * r + 2] * x[2]) + t[r];
+}
+LF_HD void lf_rt_apply_inv(const double *R, const double *t, const double *x, double *out) {   /* R^T (x - t) */
+  double d[3] = {x[0] - t[0], x[1] - t[1], x[2] - t[2]};
+  int r;
+  for (r = 0; r < 3; r++) out[r] = (R[r] * d[0] + R[3 + r] * d[1]) + R[6 + r] * d[2];
+}
+/* consensus test of motion.cpp:443-455 / 499-510; acos_fn = libm acos (reference flavour) or lf_acos */
+#ifndef LF_ACOS
+#define LF_ACOS lf_acos
+#endif
+LF_HD int lf_relmotion_inlier(const double *R, const double *t, const double *aA, const double *aB, const double *bA,
+                              const double *bB, double distThresh, double angThresh) {
+  double aA_[3], aB_[3], aAB[3] = {aA[0] - aB[0], aA[1] - aB[1], aA[2] - aB[2]}, bAB[3] = {bA[0] - bB[0], bA[1] - bB[1], bA[2] - bB[2]};
+  double rab[3], z[3] = {0, 0, 0}, dist, dot, angle;
+  lf_rt_apply(R, t, aA, aA_);
+  lf_rt_apply(R, t, aB, aB_);
+  dist = 0.5 * lf_dist3d_pt_line(aA_, bA, bB) + 0.5 * lf_dist3d_pt_line(aB_, bA, bB);
+  lf_rt_apply(R, z, aAB, rab);
+  dot = (rab[0] * bAB[0] + rab[1] * bAB[1]) + rab[2] * bAB[2];
+  angle = 180 * LF_ACOS(lf_fabs(dot / lf_norm3(aAB) / lf_norm3(bAB))) / 3.14159265;
+  return dist < distThresh && angle < angThresh;
+}
+/* one residual of costFun_optimizeRelmotion (motion.cpp:60-96, OPT_USE_MAHDIST) */
+LF_HD double lf_relmotion_residual(const double *R, const double *t, const double *aA, const double *aB,
+                                   const double *aDUa, const double *aDUb, const double *bA, const double *bB,
+                                   const double *bDUa, const double *bDUb) {
+  double Xa[3], Xb[3], Ya[3], Yb[3];
+  lf_rt_apply(R, t, aA, Xa);
+  lf_rt_apply(R, t, aB, Xb);
+  lf_rt_apply_inv(R, t, bA, Ya);
+  lf_rt_apply_inv(R, t, bB, Yb);
+  return 0.25 * (lf_mah_dist(bA, bDUa, Xa, Xb) + lf_mah_dist(bB, bDUb, Xa, Xb) + lf_mah_dist(aA, aDUa, Ya, Yb) +
+                 lf_mah_dist(aB, aDUb, Ya, Yb));
+}
+/* degeneracy test of a 3-line sample (motion.cpp:424-437): 1 if every pair is parallel within 5 deg */
+LF_HD int lf_relmotion_degenerate(const double *la /* 3 x (A,B) */, double cos_thresh) {
+  double u[9];
+  int i, j;
+  for (i = 0; i < 3; i++) {
+    double l[3] = {la[6 * i + 3] - la[6 * i], la[6 * i + 4] - la[6 * i + 1], la[6 * i + 5] - la[6 * i + 2]};
+    double inv = 1 / lf_norm3(l);
+    u[3 * i] = l[0] * inv; u[3 * i + 1] = l[1] * inv; u[3 * i + 2] = l[2] * inv;
+  }
+  for (i = 0; i < 3; i++)
+    for (j = i + 1; j < 3; j++)
+      if (lf_fabs((u[3 * i] * u[3 * j] + u[3 * i + 1] * u[3 * j + 1]) + u[3 * i + 2] * u[3 * j + 2]) < cos_thresh) return 0;
+  return 1;
+}
+
 /* ================================================================ point features (config 3)
  * Point side of getTransform_PtsLines_ransac: the caller supplies Node::feature_locations_3d_
  * (Eigen::Vector4f x,y,z,1; z = NaN without depth, src/node.cpp:952-1018) and the point matches.     */

@@ -22,6 +22,9 @@
 #include <float.h>
 
 #include "../include/linefront.h"
+#ifndef ORACLE_LFMATH
+#define LF_ACOS acos   /* reference flavour: host libm, as motion.cpp:449 */
+#endif
 #include "../lineslam_amd/csrc/lf_pose.h"
 
 #define O_EPS 1e-10
@@ -408,3 +411,115 @@ int oracle_refine_g2o(const lf_line_record *train, const lf_line_record *query, 
 int oracle_rel_motion_lines(const double *la, const double *lb, int n, double *R, double *t) { return lf_rel_motion_lines(la, lb, n, R, t); }
 double oracle_error_function2(const float *x1, const float *x2, const float *tf) { lf_point_model pm; o_point_model(&pm); return lf_error_function2(x1, x2, tf, &pm); }
 void oracle_kabsch(const float *from, const float *to, const float *w, int n, float *tf) { lf_tfc t; int i; lf_tfc_reset(&t); for (i = 0; i < n; i++) lf_tfc_add(&t, from + 3 * i, to + 3 * i, w[i]); lf_tfc_get(&t, tf); }
+
+
+/* ---------------------------------------------------------------------------------------------
+ * computeRelativeMotion_Ransac (src/line/motion.cpp:367-526) with optimizeRelmotion (:98-139) and
+ * costFun_optimizeRelmotion (:60-96): the lines-only solver (declared in utils.h:132,
+ * not called by the reference's ROS pipeline).  a = query (newer) lines, b = train (older) lines of the
+ * matches (mq, mt); x_b = R x_a + t.  Returns the size of the consensus set written to inl[]; R/t are
+ * only written when that set is not empty (as the reference leaves Ro/to untouched).
+ * dbg: [0] winning RANSAC iteration, [1] |maxConSet|, [2] optimise rounds, [3] levmar iterations of the first
+ * optimizeRelmotion.                                                                                  */
+typedef void (*o_lm_func)(const double *p, double *hx, int m, int n, void *adata);
+int oracle_levmar_dif(o_lm_func func, double *p, int m, int n, int itmax, const double opts[5], double info[10], void *adata);
+typedef struct { const lf_line_record *a, *b; const int *ia, *ib; } o_relmot_data;
+static void o_relmot_cost(const double *p, double *error, int m, int n, void *adata) {
+  const o_relmot_data *d = (const o_relmot_data *)adata;
+  double R[9];
+  int i;
+  (void)m;
+  lf_q2r(p, R);
+  for (i = 0; i < n; i++) {
+    const lf_line_record *a = &d->a[d->ia[i]], *b = &d->b[d->ib[i]];
+    error[i] = lf_relmotion_residual(R, p + 4, a->A, a->B, a->DUa, a->DUb, b->A, b->B, b->DUa, b->DUb);
+  }
+}
+static int o_optimize_relmotion(const lf_line_record *a, const lf_line_record *b, const int *ia, const int *ib, int n,
+                                double *R, double *t) {
+  double opts[5] = {1E-03, 1E-10, 1E-20, 1E-20, 1E-06}, info[10], para[7];
+  o_relmot_data d;
+  d.a = a; d.b = b; d.ia = ia; d.ib = ib;
+  lf_r2q(R, para);
+  para[4] = t[0]; para[5] = t[1]; para[6] = t[2];
+  oracle_levmar_dif(o_relmot_cost, para, 7, n, 50, opts, info, &d);
+  lf_q2r(para, R);
+  t[0] = para[4]; t[1] = para[5]; t[2] = para[6];
+  return (int)info[5];
+}
+static int o_relmot_consensus(const lf_line_record *a, const lf_line_record *b, const int *mq, const int *mt, int n,
+                              const double *R, const double *t, const lf_params *P, int *set) {
+  int i, c = 0;
+  for (i = 0; i < n; ++i)
+    if (lf_relmotion_inlier(R, t, a[mq[i]].A, a[mq[i]].B, b[mt[i]].A, b[mt[i]].B, P->pt2line3d_dist_relmotion,
+                            P->line3d_angle_relmotion)) set[c++] = i;
+  return c;
+}
+int oracle_relmotion_ransac(const lf_line_record *train, const lf_line_record *query, const int *mq, const int *mt,
+                            int n, const lf_params *P, uint64_t stream, double *R_out, double *t_out, int *inl,
+                            int *dbg) {
+  const lf_line_record *a = query, *b = train;
+  int maxIters = P->ransac_iters_line_motion, iter = 0, nmax = 0, nprev = 0, i, best_iter = -1, rounds = 0;
+  int *indexes, *maxset, *cur, *prev, *ia, *ib;
+  double bR[9], bt[3], R[9], t[3], Ro[9], to[3];
+  const double cos_deg = cos(5 * O_PI_SHORT / 180);
+  uint64_t ctr = 0;
+  if (dbg) dbg[0] = -1, dbg[1] = dbg[2] = dbg[3] = 0;
+  if (n < 3) return 0;
+  indexes = (int *)malloc(sizeof(int) * (size_t)n * 6);
+  maxset = indexes + n; cur = maxset + n; prev = cur + n; ia = prev + n; ib = ia + n;
+  for (i = 0; i < n; i++) indexes[i] = i;
+  while (iter < maxIters) {
+    double la[18], lb[18], Rs[9], ts[3];
+    int bpos = 0, left = n, s, c, nc;
+    iter++;
+    for (s = 0; s < 3; s++) {   /* random_unique(indexes, 3) */
+      int r = bpos + (int)(lf_rand31(P->rng_seed, stream, ctr++) % (uint32_t)left);
+      int tmp = indexes[bpos]; indexes[bpos] = indexes[r]; indexes[r] = tmp;
+      ++bpos; --left;
+    }
+    for (s = 0; s < 3; s++)
+      for (c = 0; c < 3; c++) {
+        la[6 * s + c] = a[mq[indexes[s]]].A[c]; la[6 * s + 3 + c] = a[mq[indexes[s]]].B[c];
+        lb[6 * s + c] = b[mt[indexes[s]]].A[c]; lb[6 * s + 3 + c] = b[mt[indexes[s]]].B[c];
+      }
+    if (lf_relmotion_degenerate(la, cos_deg)) continue;
+    /* the reference ignores a failed computeRelativeMotion_svd (:440) and would go on with empty matrices;
+     * here such a sample is skipped */
+    if (!lf_rel_motion_lines(la, lb, 3, Rs, ts)) continue;
+    nc = o_relmot_consensus(a, b, mq, mt, n, Rs, ts, P, cur);
+    if (nc > nmax) {
+      memcpy(maxset, cur, sizeof(int) * (size_t)nc); nmax = nc; best_iter = iter - 1;
+      memcpy(bR, Rs, sizeof bR); memcpy(bt, ts, sizeof bt);
+    }
+    if (nmax >= n * 1) break;   /* inlierRatio = 1 */
+  }
+  if (dbg) { dbg[0] = best_iter; dbg[1] = nmax; }
+  if (nmax < 1) { free(indexes); return 0; }
+  memcpy(Ro, bR, sizeof Ro); memcpy(to, bt, sizeof to);
+  if (nmax < 4) {
+    memcpy(R_out, Ro, sizeof Ro); memcpy(t_out, to, sizeof to);
+    memcpy(inl, maxset, sizeof(int) * (size_t)nmax);
+    free(indexes);
+    return nmax;
+  }
+  for (i = 0; i < nmax; i++) { ia[i] = mq[maxset[i]]; ib[i] = mt[maxset[i]]; }
+  i = o_optimize_relmotion(a, b, ia, ib, nmax, Ro, to);
+  if (dbg) dbg[3] = i;
+  memcpy(R, Ro, sizeof R); memcpy(t, to, sizeof t);
+  for (;;) {
+    int nc = o_relmot_consensus(a, b, mq, mt, n, R, t, P, cur);
+    if (nc <= nprev) break;
+    memcpy(prev, cur, sizeof(int) * (size_t)nc); nprev = nc;
+    memcpy(Ro, R, sizeof R); memcpy(to, t, sizeof t);
+    for (i = 0; i < nprev; i++) { ia[i] = mq[prev[i]]; ib[i] = mt[prev[i]]; }
+    o_optimize_relmotion(a, b, ia, ib, nprev, R, t);
+    rounds++;
+  }
+  if (dbg) dbg[2] = rounds;
+  memcpy(R_out, Ro, sizeof Ro); memcpy(t_out, to, sizeof to);
+  memcpy(inl, prev, sizeof(int) * (size_t)nprev);
+  free(indexes);
+  return nprev;
+}
+double oracle_acos(double x) { return lf_acos(x); }

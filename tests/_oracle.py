@@ -230,3 +230,20 @@ def pose_hybrid_oracle(train, query, train_pts, query_pts, pq, pt, mq, mt, id_tr
         C.byref(params), C.c_uint64(stream), C.c_void_p(tf.ctypes.data), C.byref(rmse), C.c_void_p(pinl.ctypes.data),
         C.byref(npi), C.c_void_p(linl.ctypes.data), C.byref(nli), C.c_void_p(dbg.ctypes.data))
     return bool(ok), tf.reshape(4, 4).copy(), float(rmse.value), pinl[:npi.value].copy(), linl[:nli.value].copy(), dbg
+
+
+def relmotion_oracle(train, query, mq, mt, params, stream, flavour="lf"):
+    """oracle_relmotion_ransac: computeRelativeMotion_Ransac (motion.cpp:367-526) on the matched lines.
+    Returns (n_inliers, R[3,3], t[3], inlier indices into the match list, dbg)."""
+    lib = oracle_lib(flavour)
+    tr, qu = np.ascontiguousarray(train), np.ascontiguousarray(query)
+    q, t = np.ascontiguousarray(mq, np.int32), np.ascontiguousarray(mt, np.int32)
+    R, tv = np.zeros(9), np.zeros(3)
+    inl = np.zeros(max(len(q), 1), np.int32)
+    dbg = np.zeros(4, np.int32)
+    lib.oracle_relmotion_ransac.restype = C.c_int
+    n = lib.oracle_relmotion_ransac(C.c_void_p(tr.ctypes.data), C.c_void_p(qu.ctypes.data), C.c_void_p(q.ctypes.data),
+                                    C.c_void_p(t.ctypes.data), C.c_int(len(q)), C.byref(params), C.c_uint64(stream),
+                                    C.c_void_p(R.ctypes.data), C.c_void_p(tv.ctypes.data), C.c_void_p(inl.ctypes.data),
+                                    C.c_void_p(dbg.ctypes.data))
+    return n, R.reshape(3, 3).copy(), tv.copy(), inl[:n].copy(), dbg

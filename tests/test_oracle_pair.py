@@ -192,3 +192,40 @@ def test_hybrid_ransac_with_points_and_lines():
     # points only (the legacy getRelativeTransformationTo situation): still solvable
     ok2, tf2, _, pinl2, linl2, _ = O.pose_hybrid_oracle(tr[:0], q[:0], tp, qp, pq, pt, mq[:0], mt[:0], 0, 1, P, 5)
     assert ok2 and len(linl2) == 0 and np.allclose(tf2[:3, 3], t, atol=5e-3)
+
+
+def test_relmotion_ransac_lines_only():
+    """a24 computeRelativeMotion_Ransac: exact motion on clean lines, outliers rejected, both flavours agree."""
+    from lineslam_amd import capi
+    rng = np.random.default_rng(21)
+    P = capi.default_params()
+    R, t = _rot([0.3, 1, 0.2], 0.05), np.array([0.04, -0.02, 0.03])
+    # (perfectly parallel lines can give |cos| = 1 + 1ulp -> acos = NaN -> "not an inlier", in the reference
+    #  as here, so the clean case carries 1e-6 m of noise)
+    q, tr, _, _ = _scene(rng, n=30, noise=1e-6, R=R, t=t)
+    mq = np.arange(30, dtype=np.int32); mt = mq.copy()
+    n, Ro, to, inl, dbg = O.relmotion_oracle(tr, q, mq, mt, P, 9)
+    assert n == 30 and np.allclose(Ro, R, atol=1e-5) and np.allclose(to, t, atol=1e-5)
+    # noise + wrong matches
+    q, tr, _, _ = _scene(rng, n=40, noise=0.002, R=R, t=t)
+    mq = np.arange(40, dtype=np.int32); mt = mq.copy()
+    bad = rng.choice(40, 10, replace=False); mt[bad] = np.roll(mt[bad], 1)
+    n, Ro, to, inl, dbg = O.relmotion_oracle(tr, q, mq, mt, P, 9)
+    assert n >= 24 and not (set(inl.tolist()) & set(bad.tolist()))
+    assert np.allclose(Ro, R, atol=5e-3) and np.allclose(to, t, atol=1e-2)
+    assert dbg[2] >= 1                                   # at least one consensus / optimise round ran
+    n2, R2, t2, inl2, dbg2 = O.relmotion_oracle(tr, q, mq, mt, P, 9, flavour="ref")
+    assert n2 == n and np.array_equal(inl, inl2) and np.allclose(R2, Ro, atol=1e-9) and np.allclose(t2, to, atol=1e-9)
+    # fewer than three matches: nothing (motion.cpp:371-375)
+    assert O.relmotion_oracle(tr, q, mq[:2], mt[:2], P, 9)[0] == 0
+
+
+def test_lf_acos_matches_libm():
+    lib = O.oracle_lib("lf")
+    lib.oracle_acos.restype = C.c_double
+    x = np.r_[np.linspace(-1, 1, 20001), 1 - np.logspace(-16, -1, 200), -1 + np.logspace(-16, -1, 200)]
+    got = np.array([lib.oracle_acos(C.c_double(v)) for v in x])
+    ref = np.arccos(x)
+    ulp = np.abs(got - ref) / np.spacing(np.maximum(ref, 1e-300))
+    assert ulp.max() <= 4, ulp.max()
+    assert np.isnan(lib.oracle_acos(C.c_double(1.0000001)))
