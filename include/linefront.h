@@ -246,6 +246,12 @@ LF_API int lf_match_node_pair_hybrid(lf_ctx *ctx, const lf_line_record *newer, i
 LF_API int lf_relmotion_pairs_device(lf_ctx *ctx, const int32_t *query_frames, const int32_t *train_frames,
                                      int n_pairs);
 LF_API int lf_pair_get_motion(lf_ctx *ctx, int pair, double R[9], double t[3]);
+/* The free function itself, vector<int> computeRelativeMotion_Ransac(vector<RandomLine3d> a, vector<RandomLine3d> b,
+ * cv::Mat& Ro, cv::Mat& to) (src/line/utils.h:132): a[i] <-> b[i] already matched, HOST arrays, n <= 256;
+ * x_b = Ro x_a + to.  Ro / to are written only when the returned set is not empty (as the reference).
+ * id_a / id_b key the counter-based sample generator. */
+LF_API int lf_relmotion_lines(lf_ctx *ctx, const lf_line_record *a, const lf_line_record *b, int n, uint64_t id_a,
+                              uint64_t id_b, double R[9], double t[3], int32_t *inliers, int cap, int *n_inliers);
 
 /* Stage durations (ms) of the last launches, measured with HIP events recorded on the context
  * stream: which = 0 LSD data-parallel kernels, 1 the LSD sweep kernel (k_lsd_sweep), 2 the 3D-line

@@ -142,4 +142,18 @@ class Node {
   }
 };
 
+// std::vector<int> computeRelativeMotion_Ransac(std::vector<RandomLine3d> a, std::vector<RandomLine3d> b, cv::Mat& Ro,
+// cv::Mat& to) (src/line/utils.h:132, motion.cpp:367-526): a[i] <-> b[i]; Ro (3x3 row-major) / to untouched when the
+// returned consensus set is empty.
+inline std::vector<int> computeRelativeMotion_Ransac(Context* ctx, const std::vector<FrameLine>& a,
+                                                     const std::vector<FrameLine>& b, double Ro[9], double to[3],
+                                                     uint64_t id_a = 0, uint64_t id_b = 1) {
+  std::vector<int32_t> inl(a.size() ? a.size() : 1);
+  int n = 0;
+  if (a.size() != b.size()) throw Error(LF_ERR_INVALID, "computeRelativeMotion_Ransac: a.size() != b.size()");
+  check(lf_relmotion_lines(ctx->h, a.data(), b.data(), (int)a.size(), id_a, id_b, Ro, to, inl.data(), (int)inl.size(), &n),
+        "lf_relmotion_lines");
+  return std::vector<int>(inl.begin(), inl.begin() + n);
+}
+
 }  // namespace lf

@@ -83,6 +83,7 @@ SYMBOLS = {
     "lf_pair_get_point_inliers": (_i, [_vp, _i, _vp, _i, _pi]),
     "lf_relmotion_pairs_device": (_i, [_vp, _vp, _vp, _i]),
     "lf_pair_get_motion": (_i, [_vp, _i, _vp, _vp]),
+    "lf_relmotion_lines": (_i, [_vp, _vp, _vp, _i, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _i, _pi]),
     "lf_match_node_pair_hybrid": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, _vp, _i, C.c_uint64, _vp, _i, _vp, _vp, _i,
                                        _vp, _vp]),
 }
@@ -291,6 +292,18 @@ class Context:
         assert q.shape == t.shape and q.ndim == 1
         self._chk(lib().lf_relmotion_pairs_device(self._h, q.ctypes.data, t.ctypes.data, len(q)),
                   "lf_relmotion_pairs_device")
+
+    def relmotion_lines(self, a_recs, b_recs, id_a=0, id_b=1):
+        """computeRelativeMotion_Ransac(a, b, Ro, to) on host-resident matched lines; returns (inliers, R, t)."""
+        a, b = np.ascontiguousarray(a_recs), np.ascontiguousarray(b_recs)
+        assert len(a) == len(b)
+        R, t = np.zeros(9), np.zeros(3)
+        inl = np.zeros(max(len(a), 1), np.int32)
+        n = C.c_int()
+        self._chk(lib().lf_relmotion_lines(self._h, a.ctypes.data, b.ctypes.data, len(a), int(id_a), int(id_b),
+                                           R.ctypes.data, t.ctypes.data, inl.ctypes.data, len(inl), C.byref(n)),
+                  "lf_relmotion_lines")
+        return inl[:n.value].copy(), R.reshape(3, 3), t
 
     def pair_motion(self, pair):
         R, t = np.zeros(9), np.zeros(3)

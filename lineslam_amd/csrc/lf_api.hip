@@ -677,6 +677,48 @@ int lf_relmotion_pairs_device(lf_ctx *c, const int32_t *query_frames, const int3
   return match_pairs_impl(c, query_frames, train_frames, n_pairs, nullptr, nullptr, nullptr, 0, 0, nullptr, true);
 }
 
+// computeRelativeMotion_Ransac(a, b, Ro, to) for two HOST vectors of already matched lines (a[i] <-> b[i]).
+int lf_relmotion_lines(lf_ctx *c, const lf_line_record *a, const lf_line_record *b, int n, uint64_t id_a, uint64_t id_b,
+                       double R[9], double t[3], int32_t *inliers, int cap, int *n_inliers) {
+  if (!c || !R || !t || !n_inliers || n < 0 || (n && (!a || !b)) || cap < 0) return LF_ERR_INVALID;
+  if (c->maxB < 2) return LF_ERR_CAPACITY;
+  if (n > c->fc.line_cap || n > LF_MAX_MATCHES || n > c->pcn.match_cap) return LF_ERR_CAPACITY;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t ids[2] = {id_a, id_b};
+  const int nl[2] = {n, n}, pq = 0, pt = 1;
+  std::vector<int> iota((size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; i++) iota[i] = i;
+  if (n) {
+    HIPCHK(c, hipMemcpyAsync(c->fb.recs, a, sizeof(lf_line_record) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->fb.recs + c->fc.line_cap, b, sizeof(lf_line_record) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pb.match_q, iota.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pb.match_t, iota.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, hipMemcpyAsync(c->fb.nlines, nl, sizeof nl, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_frame_ids, ids, sizeof ids, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->pb.nmatches, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_pair_q, &pq, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_pair_t, &pt, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->last_batch < 2) c->last_batch = 2;
+  c->pcn.P = c->params;
+  lf_pair_relmotion_launch(c->pcn, c->pb, 1, c->stream);
+  HIPCHK(c, hipGetLastError());
+  c->last_pairs = 1;
+  c->last_hybrid = false;
+  lf_pair_result r;
+  int rc = lf_pair_get_result(c, 0, &r);
+  if (rc != LF_OK) return rc;
+  *n_inliers = r.n_inliers;
+  if (r.n_inliers > 0) {
+    rc = lf_pair_get_motion(c, 0, R, t);
+    if (rc != LF_OK) return rc;
+    int m = 0;
+    return lf_pair_get_inliers(c, 0, inliers, cap, &m);
+  }
+  return LF_OK;
+}
+
 int lf_pair_get_motion(lf_ctx *c, int pair, double R[9], double t[3]) {
   if (!c || !R || !t || pair < 0 || pair >= c->last_pairs) return LF_ERR_INVALID;
   double h[LF_MOTION_STRIDE];

@@ -50,3 +50,26 @@ def test_relmotion_pairs_bit_exact_vs_oracle(built_lib):
     P2 = capi.default_params()
     P2.adjacent_linematch_window = 0
     ctx.close()
+
+
+def test_relmotion_free_function_on_host_lines(built_lib):
+    """lf_relmotion_lines == computeRelativeMotion_Ransac(a, b, Ro, to) on already matched host vectors."""
+    import test_oracle_pair as T
+    from lineslam_amd import capi
+    rng = np.random.default_rng(5)
+    P = capi.default_params()
+    R, t = T._rot([0.1, 1, 0.3], 0.06), np.array([0.05, 0.02, -0.03])
+    a, b, _, _ = T._scene(rng, n=50, noise=0.002, R=R, t=t)
+    perm = np.arange(50)
+    bad = rng.choice(50, 12, replace=False)
+    perm[bad] = np.roll(perm[bad], 1)
+    b = b[perm]
+    ctx = capi.Context(640, 480, max_batch=2, params=P)
+    inl, Rg, tg = ctx.relmotion_lines(a, b, id_a=4, id_b=9)
+    stream = (4 << 32) ^ 9 ^ 0x3000000000000000
+    n, Ro, to, oinl, dbg = O.relmotion_oracle(b, a, np.arange(50), np.arange(50), P, stream)
+    assert n == len(inl) >= 30 and np.array_equal(inl, oinl)
+    assert np.array_equal(Rg, Ro) and np.array_equal(tg, to)
+    assert not (set(inl.tolist()) & set(bad.tolist()))
+    assert np.allclose(Rg, R, atol=5e-3) and np.allclose(tg, t, atol=1e-2)
+    ctx.close()
