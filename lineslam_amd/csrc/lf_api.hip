@@ -35,6 +35,11 @@ struct lf_ctx {
   PairBuffers pb;
   int *d_pair_q = nullptr, *d_pair_t = nullptr;
   int last_pairs = 0;
+  // pinned staging for the small host arrays of the batched entry points (frame ids, pair lists): the calls
+  // stay asynchronous, so that several contexts on different streams can be driven from one host thread
+  uint8_t *h_stage = nullptr;
+  hipEvent_t ev_stage_ids = nullptr, ev_stage_pairs = nullptr;
+  bool stage_ids_pending = false, stage_pairs_pending = false;
   bool hybrid_ready = false;         // hybrid (points + lines) buffers are allocated on first use
   int *d_pm_q = nullptr, *d_pm_t = nullptr, *d_npm = nullptr;
   float *d_pts_stage = nullptr;      // lf_match_node_pair_hybrid staging: 2 x LF_NODE_PT_CAP float4
@@ -369,6 +374,13 @@ int lf_ctx_create(lf_ctx **out, int device, void *hip_stream, int width, int hei
     }
     for (int i = 0; i < 8; i++) if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) { r = fail_hip(c, e, "hipEventCreate"); break; }
     if (r != LF_OK) break;
+    if ((e = hipEventCreateWithFlags(&c->ev_stage_ids, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_stage_pairs, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&c->h_stage, (size_t)c->maxB * 16, hipHostMallocDefault)) != hipSuccess) {
+      r = fail_hip(c, e, "staging buffers");
+      break;
+    }
+    if (r != LF_OK) break;
     if ((r = build_lsd_consts(c)) != LF_OK) break;
     if ((r = alloc_lsd(c)) != LF_OK) break;
     if ((r = upload_lsd_tables(c)) != LF_OK) break;
@@ -384,6 +396,9 @@ void lf_ctx_destroy(lf_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (void *p : c->allocs) (void)hipFree(p);
   for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->ev_stage_ids) (void)hipEventDestroy(c->ev_stage_ids);
+  if (c->ev_stage_pairs) (void)hipEventDestroy(c->ev_stage_pairs);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -523,10 +538,14 @@ int lf_detect3d_batch_device(lf_ctx *c, const uint8_t *d_gray, size_t gray_frame
   if (c->params.line_sample_max_num + 1 > LF_MAX_SAMPLES) return LF_ERR_UNSUPPORTED;
   int r = lf_lsd_batch_device(c, d_gray, gray_frame_stride, gray_row_stride, n_frames);
   if (r != LF_OK) return r;
-  std::vector<uint64_t> ids((size_t)n_frames);
-  for (int i = 0; i < n_frames; i++) ids[i] = frame_ids ? frame_ids[i] : (uint64_t)i;
-  HIPCHK(c, hipMemcpyAsync(c->d_frame_ids, ids.data(), ids.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));   // ids is a stack vector (tiny copy)
+  {   // node ids through the pinned staging area (no host synchronisation)
+    if (c->stage_ids_pending) HIPCHK(c, hipEventSynchronize(c->ev_stage_ids));
+    uint64_t *ids = (uint64_t *)c->h_stage;
+    for (int i = 0; i < n_frames; i++) ids[i] = frame_ids ? frame_ids[i] : (uint64_t)i;
+    HIPCHK(c, hipMemcpyAsync(c->d_frame_ids, ids, (size_t)n_frames * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_stage_ids, c->stream));
+    c->stage_ids_pending = true;
+  }
   set_camera(c, K);
   c->fb.gray = d_gray; c->fb.gray_frame_stride = gray_frame_stride; c->fb.gray_row_stride = gray_row_stride;
   c->fb.depth = d_depth; c->fb.depth_frame_stride = depth_frame_stride; c->fb.depth_row_stride = depth_row_stride;
@@ -638,9 +657,16 @@ static int match_pairs_impl(lf_ctx *c, const int32_t *query_frames, const int32_
     if (query_frames[i] < 0 || query_frames[i] >= c->last_batch || train_frames[i] < 0 || train_frames[i] >= ntrain)
       return LF_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemcpyAsync(c->d_pair_q, query_frames, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_pair_t, train_frames, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));   // caller's arrays may be temporaries
+  {   // pair lists through the pinned staging area (the caller's arrays may be temporaries)
+    if (c->stage_pairs_pending) HIPCHK(c, hipEventSynchronize(c->ev_stage_pairs));
+    int *hq = (int *)(c->h_stage + (size_t)c->maxB * 8), *ht = hq + c->maxB;
+    memcpy(hq, query_frames, sizeof(int) * (size_t)n_pairs);
+    memcpy(ht, train_frames, sizeof(int) * (size_t)n_pairs);
+    HIPCHK(c, hipMemcpyAsync(c->d_pair_q, hq, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pair_t, ht, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_stage_pairs, c->stream));
+    c->stage_pairs_pending = true;
+  }
   c->pcn.P = c->params;
   PairBuffers pb = c->pb;
   if (hy) { int r = hybrid_prepare(c, *hy, n_pairs, pb); if (r != LF_OK) return r; }

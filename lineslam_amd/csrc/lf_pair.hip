@@ -154,6 +154,23 @@ __device__ __forceinline__ double p_ordered_sum(const double *v, int n, double s
   return s;
 }
 
+
+// acc (+/-)= base[k * stride] for k = 0..n-1, strictly in that order; the loads of 8 rows are issued together
+// (they do not depend on the running sum), the additions stay sequential.
+template <bool SUB>
+__device__ __forceinline__ double p_walk(const double *base, size_t stride, int n, double acc) {
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = base[(size_t)(k + j) * stride];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc = SUB ? acc - v[j] : acc + v[j];
+  }
+  for (; k < n; k++) acc = SUB ? acc - base[(size_t)k * stride] : acc + base[(size_t)k * stride];
+  return acc;
+}
+
 // getTransformFromHybridMatchesG2O (transformation_estimation.cpp:218-461), line edges only; the
 // sequential twin is oracle_refine_g2o.  set[0..n) = match indices (LDS).
 __device__ void p_refine(const PoseCtx &pc, const int *set, int n, float *tf, int iterations) {
@@ -194,7 +211,7 @@ __device__ void p_refine(const PoseCtx &pc, const int *set, int n, float *tf, in
     currentChi = p_ordered_sum(cv, n, 0.0);
     __syncthreads();
     double accH = 0;   // Hpp | bp: accumulator lane a (< 42) walks the matches in order and keeps entry a
-    if (lane < 42) for (int k = 0; k < n; k++) accH += pc.wsB[(size_t)k * 120 + 78 + lane];
+    if (lane < 42) accH = p_walk<false>(pc.wsB + 78 + lane, 120, n, accH);
 #pragma unroll
     for (int a = 0; a < 36; a++) Hpp[a] = p_rl64(accH, a);
 #pragma unroll
@@ -231,7 +248,7 @@ __device__ void p_refine(const PoseCtx &pc, const int *set, int n, float *tf, in
       {
         double acc = accH;
         if (lane < 36 && lane % 7 == 0) acc = accH + lambda;          // S = Hpp + lambda I ; g = bp
-        if (lane < 42) for (int k = 0; k < n; k++) acc -= pc.wsTU[(size_t)k * 42 + lane];
+        if (lane < 42) acc = p_walk<true>(pc.wsTU + lane, 42, n, acc);
 #pragma unroll
         for (int a = 0; a < 36; a++) S[a] = p_rl64(acc, a);
 #pragma unroll

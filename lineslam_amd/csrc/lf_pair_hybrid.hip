@@ -72,6 +72,23 @@ __device__ __forceinline__ double h_ordered_sum(const double *v, int n, double s
   return s;
 }
 
+
+// acc (+/-)= base[k * stride] for k = 0..n-1, strictly in that order; the loads of 8 rows are issued together
+// (they do not depend on the running sum), the additions stay sequential.
+template <bool SUB>
+__device__ __forceinline__ double h_walk(const double *base, size_t stride, int n, double acc) {
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = base[(size_t)(k + j) * stride];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc = SUB ? acc - v[j] : acc + v[j];
+  }
+  for (; k < n; k++) acc = SUB ? acc - base[(size_t)k * stride] : acc + base[(size_t)k * stride];
+  return acc;
+}
+
 // getTransformFromHybridMatchesG2O with point and line edges; sequential twin: oracle_refine_hybrid.
 __device__ void h_refine(const HCtx &pc, const int *pset, int np, const int *lset, int nl, float *tf, int iterations) {
   const int lane = h_lane();
@@ -143,8 +160,8 @@ __device__ void h_refine(const HCtx &pc, const int *pset, int np, const int *lse
     __syncthreads();
     double accH = 0;   // Hpp | bp: accumulator lane a (< 42): points first, then lines
     if (lane < 42) {
-      for (int k = 0; k < np; k++) accH += ws[WP_B + (size_t)k * 72 + 30 + lane];
-      for (int k = 0; k < nl; k++) accH += ws[WL_B + (size_t)k * 120 + 78 + lane];
+      accH = h_walk<false>(ws + WP_B + 30 + lane, 72, np, accH);
+      accH = h_walk<false>(ws + WL_B + 78 + lane, 120, nl, accH);
     }
 #pragma unroll
     for (int a = 0; a < 36; a++) Hpp[a] = h_rl64(accH, a);
@@ -196,8 +213,8 @@ __device__ void h_refine(const HCtx &pc, const int *pset, int np, const int *lse
         double acc = accH;
         if (lane < 36 && lane % 7 == 0) acc = accH + lambda;
         if (lane < 42) {
-          for (int k = 0; k < np; k++) acc -= ws[WP_TU + (size_t)k * 42 + lane];
-          for (int k = 0; k < nl; k++) acc -= ws[WL_TU + (size_t)k * 42 + lane];
+          acc = h_walk<true>(ws + WP_TU + lane, 42, np, acc);
+          acc = h_walk<true>(ws + WL_TU + lane, 42, nl, acc);
         }
 #pragma unroll
         for (int a = 0; a < 36; a++) S[a] = h_rl64(acc, a);
