@@ -326,6 +326,8 @@ static int alloc_lsd(lf_ctx *c) {
   ALLOC(c, fb.pts, B * (size_t)fc.cand_cap * LF_MAX_SAMPLES * 3);
   ALLOC(c, fb.recs, B * (size_t)fc.line_cap);
   ALLOC(c, fb.nlines, B);
+  ALLOC(c, fb.mle_list, B * 3 * (size_t)fc.line_cap);
+  ALLOC(c, fb.mle_cnt, B * 3);
   fb.frame_ids = c->d_frame_ids;
   fb.segs = b.segs; fb.nsegs = b.nsegs;
   // ---- pair solver (at most one pair per frame slot)

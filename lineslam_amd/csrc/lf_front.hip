@@ -436,12 +436,23 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
   if (nseg > c.cand_cap) nseg = c.cand_cap;
   const int *flag = b.cand_flag + (size_t)f * c.cand_cap;
   lf_line_record *recs = b.recs + (size_t)f * c.line_cap;
-  int base = 0;
+  int *list0 = b.mle_list + (size_t)f * 3 * c.line_cap, *list1 = list0 + c.line_cap, *list2 = list1 + c.line_cap;
+  int base = 0, n0 = 0, n1 = 0, n2 = 0;
   for (int s0 = 0; s0 < nseg; s0 += 64) {
     int s = s0 + lane;
     bool have = s < nseg && flag[s] == 2;
     u64 m = __ballot(have);
     int lid = base + __popcll(m & f_lt());
+    {   // MLE work lists by number of RANSAC support points: <= 32, 33..64, more
+      bool kept = have && lid < c.line_cap;
+      int nsup = kept ? (int)b.cand_out[((size_t)f * c.cand_cap + s) * LF_CAND_STRIDE + 26] : 0;
+      bool small = kept && nsup <= 32, mid = kept && nsup > 32, large = false;   // (a separate launch for > 64 only adds a tail)
+      u64 ms = __ballot(small), mm = __ballot(mid), ml = __ballot(large);
+      if (small) list0[n0 + __popcll(ms & f_lt())] = lid;
+      if (mid) list1[n1 + __popcll(mm & f_lt())] = lid;
+      if (large) list2[n2 + __popcll(ml & f_lt())] = lid;
+      n0 += __popcll(ms); n1 += __popcll(mm); n2 += __popcll(ml);
+    }
     if (have && lid < c.line_cap) {
       lf_line_record *R = &recs[lid];
       const double *sg = b.segs + ((size_t)f * c.seg_cap + s) * 5;
@@ -457,7 +468,7 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
     }
     base += __popcll(m);
   }
-  if (lane == 0) b.nlines[f] = base;
+  if (lane == 0) { b.nlines[f] = base; b.mle_cnt[3 * f] = n0; b.mle_cnt[3 * f + 1] = n1; b.mle_cnt[3 * f + 2] = n2; }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -465,22 +476,59 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
 // Supporting points live in LDS (one or two per lane); residuals and Jacobian rows are evaluated
 // lane-parallel; J^T J / J^T e use one accumulator per lane walking the rows in levmar's order.
 #define MLE_N 104
-struct MState {
-  double pos[MLE_N * 3];
-  double DU[MLE_N * 9];
-  double jac[MLE_N * 6];
-  double hx[MLE_N], e[MLE_N], wrk[MLE_N], wrk2[MLE_N];
+#define MLE_ROW_DOUBLES 19   // LDS doubles per support point: pos 3, DU 9, Jacobian row 6, e 1
+struct MState {   // views into the group's LDS block, sized for the kernel variant's row capacity
+  double *pos;    // [rows][3]
+  double *DU;     // [rows][9]
+  double *jac;    // [rows][6]
+  double *e;      // [rows]
 };
+__device__ __forceinline__ void f_mstate_bind(MState &S, double *lds, int rows) {
+  S.pos = lds; S.DU = S.pos + rows * 3; S.jac = S.DU + rows * 9; S.e = S.jac + rows * 6;
+}
 
-// costFun_MLEstimateLine3d (utils.cpp:954-978): residuals of support points lane and lane+64
-__device__ __forceinline__ void f_mle_cost(const MState &S, int n, int e1, int e2, const double *ci1,
-                                           const double *ci2, const double *p, double *out) {
-  int lane = f_lane();
-  for (int h = 0; h < 2; h++) {
-    int i = lane + 64 * h;
+// ---- lane groups.  A 3D line with n support points is handled by a GROUP of G lanes: G = 64 (one line per
+// wavefront, two row slots per lane, n <= 104) or G = 32 (two lines per wavefront; one row per lane for n <= 32 --
+// three quarters of all lines -- or two rows per lane for n <= 64).  Values that are "uniform" for a line are uniform within its group; control flow
+// that depends on them simply diverges between the two groups of a wavefront.
+template <int G, int ROWS_> struct MleCfgT {
+  static constexpr int NG = 64 / G;
+  static constexpr int ROWS = ROWS_;
+  static constexpr int SLOTS = (ROWS + G - 1) / G;
+};
+struct MleGroup { int gbase, glane; };   // first lane of my group, my lane inside it
+template <int G> __device__ __forceinline__ double g_get(double v, const MleGroup &g, int idx) {   // v of group lane idx
+  if constexpr (G == 64) return f_rl64(v, idx);
+  else return __shfl(v, g.gbase + idx, 64);
+}
+template <int G> __device__ __forceinline__ void g_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+template <int G> __device__ __forceinline__ void g_argmin(double &v, int &i) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) {
+    double ov = __shfl_xor(v, o, 64);
+    int oi = __shfl_xor(i, o, 64);
+    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+template <int G> __device__ __forceinline__ void g_argmax(double &v, int &i) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) {
+    double ov = __shfl_xor(v, o, 64);
+    int oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+// costFun_MLEstimateLine3d (utils.cpp:954-978): residuals of the rows this lane owns, in registers
+template <int G, int RW>
+__device__ __forceinline__ void f_mle_cost(const MState &S, const MleGroup &g, int n, int e1, int e2, const double *ci1,
+                                           const double *ci2, const double *p, double *out /* [SLOTS] */) {
+#pragma unroll
+  for (int h = 0; h < MleCfgT<G, RW>::SLOTS; h++) {
+    int i = g.glane + G * h;
+    double r = 0.0;
     if (i < n) {
       int pi = i;
-      double r;
       if (i == e1 || i == e2) {
         const double *ci = (i == e1) ? ci1 : ci2;
         const double *e = (i == e1) ? p : p + 3;
@@ -492,64 +540,104 @@ __device__ __forceinline__ void f_mle_cost(const MState &S, int n, int e1, int e
         r = t[0] * v[0] + t[1] * v[1] + t[2] * v[2];
       } else
         r = f_mah(&S.pos[3 * pi], &S.DU[9 * pi], p, p + 3);
-      out[i] = r;
     }
+    out[h] = r;
   }
 }
+// sum of v[i]^2 over the rows i = 0..n-1 in that order (row i lives in group lane i % G, slot i / G)
+template <int G, int RW>
+__device__ __forceinline__ double f_ordered_sumsq(const double *v, const MleGroup &g, int n) {
+  double s = 0.0;
+#pragma unroll
+  for (int h = 0; h < MleCfgT<G, RW>::SLOTS; h++) {
+    double sq = v[h] * v[h];
+    int cnt = n - G * h;
+    if (cnt > G) cnt = G;
+    for (int l = 0; l < cnt; l++) s += g_get<G>(sq, g, l);
+  }
+  return s;
+}
 
+#ifdef LF_MLE_PROFILE   // LF_EXTRA_CFLAGS=-DLF_MLE_PROFILE: s_memtime per LM phase of line 7 of frame 0, printed
+__device__ unsigned long long g_mprof[16];
+#define MT(k) do { unsigned long long tn = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 7 && blockIdx.y == 0 && f_lane() == 0 && G == 64) g_mprof[k] += tn - tprev; tprev = tn; } while (0)
+#else
+#define MT(k) do { } while (0)
+#endif
 // dlevmar_dif (external/levmar-2.6/lm_core.c:438-846) for m = 6, x = 0, restated for one wavefront.
-// Residuals/Jacobian rows live in LDS; J^T J and J^T e use one accumulator per lane that walks
-// l = n-1 .. 0 exactly as lm_core.c:581-591.
-__device__ int f_levmar6(MState &S, int n, int e1, int e2, const double *ci1, const double *ci2, double *p,
-                         int itmax, int *stop_out) {
-  const int m = 6, lane = f_lane();
+// Every lane owns the rows lane and lane+64: hx / wrk / wrk2 stay in registers, sums over the rows are taken
+// in row order through readlane; the Jacobian and e live in LDS because J^T J and J^T e use one accumulator per
+// lane that walks ALL rows l = n-1 .. 0 exactly as lm_core.c:581-591.  The 6x6 system is identical in all
+// lanes (lf_solve6_u: pivot decisions are scalar branches).
+template <int G, int RW>
+__device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, const double *ci1, const double *ci2,
+                         double *p, int itmax, int *stop_out) {
+  constexpr int SL = MleCfgT<G, RW>::SLOTS;
+  const int m = 6, lane = g.glane;
   const double tau = 1E-03, eps1 = 1E-10, eps2 = 1E-20, eps2_sq = 1E-20 * 1E-20, eps3 = 1E-20, delta = 1E-06;
   double jacTe[6], jacTjac[36], Dp[6], diag[6], pDp[6];
+  double hx[SL], ev[SL], wrk[SL], wrk2[SL];
   double mu = 0, tmp, p_eL2, jacTe_inf = 0, pDp_eL2, p_L2 = 0, Dp_L2 = DBL_MAX, dF, dL;
   int nu, nu2, stop = 0, K = 10, updjac = 0, updp = 1, newjac = 0, k;
   // accumulator ownership: lanes 0..20 lower triangle (i,j), lanes 21..26 J^T e
   int ai = 0, aj = 0;
   if (lane < 21) { int a = lane; while ((ai + 1) * (ai + 2) / 2 <= a) ai++; aj = a - ai * (ai + 1) / 2; }
   else if (lane < 27) { ai = lane - 21; aj = -1; }
-  f_mle_cost(S, n, e1, e2, ci1, ci2, p, S.hx);
-  f_sync();
-  p_eL2 = 0.0;
-  for (int i = lane; i < n; i += 64) S.e[i] = 0.0 - S.hx[i];
-  f_sync();
-  for (int i = 0; i < n; ++i) { tmp = S.e[i]; p_eL2 += tmp * tmp; }
+#ifdef LF_MLE_PROFILE
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+  f_mle_cost<G, RW>(S, g, n, e1, e2, ci1, ci2, p, hx);
+#pragma unroll
+  for (int h = 0; h < SL; h++) { ev[h] = 0.0 - hx[h]; int i = lane + G * h; if (i < n) S.e[i] = ev[h]; }
+  p_eL2 = f_ordered_sumsq<G, RW>(ev, g, n);
   if (!(lf_fabs(p_eL2) <= DBL_MAX)) stop = 7;
   nu = 20;
   for (k = 0; k < itmax && !stop; ++k) {
     if (p_eL2 <= eps3) { stop = 6; break; }
+    MT(0);
     if ((updp && nu > 16) || updjac == K) {
       for (int j = 0; j < m; ++j) {           // forward differences (misc_core.c:137-171)
         double d = 1E-04 * p[j], t;
         d = lf_fabs(d);
         if (d < delta) d = delta;
         t = p[j]; p[j] += d;
-        f_mle_cost(S, n, e1, e2, ci1, ci2, p, S.wrk);
+        f_mle_cost<G, RW>(S, g, n, e1, e2, ci1, ci2, p, wrk);
         p[j] = t;
         d = 1.0 / d;
-        f_sync();
-        for (int i = lane; i < n; i += 64) S.jac[i * m + j] = (S.wrk[i] - S.hx[i]) * d;
+#pragma unroll
+        for (int h = 0; h < SL; h++) { int i = lane + G * h; if (i < n) S.jac[i * m + j] = (wrk[h] - hx[h]) * d; }
       }
-      f_sync();
       nu = 2; updjac = 0; updp = 0; newjac = 1;
     }
+    MT(1);
     if (newjac) {
       newjac = 0;
+      g_order<G>();                           // Jacobian rows and e of all lanes visible
       double acc = 0.0;
-      if (lane < 27)
-        for (int l = n; l-- > 0;) {
+      if (lane < 27) {
+        const double *colB = (aj >= 0) ? (S.jac + aj) : S.e;   // second factor: J[l][aj] or e[l]
+        const int strideB = (aj >= 0) ? m : 1;
+        int l = n;
+        for (; l >= 4; l -= 4) {              // four rows per trip: loads first, additions in levmar's order
+          double a0 = S.jac[(l - 1) * m + ai], a1 = S.jac[(l - 2) * m + ai], a2 = S.jac[(l - 3) * m + ai], a3 = S.jac[(l - 4) * m + ai];
+          double b0 = colB[(l - 1) * strideB], b1 = colB[(l - 2) * strideB], b2 = colB[(l - 3) * strideB], b3 = colB[(l - 4) * strideB];
+          acc += (aj >= 0) ? b0 * a0 : a0 * b0;
+          acc += (aj >= 0) ? b1 * a1 : a1 * b1;
+          acc += (aj >= 0) ? b2 * a2 : a2 * b2;
+          acc += (aj >= 0) ? b3 * a3 : a3 * b3;
+        }
+        for (; l-- > 0;) {
           double alpha = S.jac[l * m + ai];
           acc += (aj >= 0) ? S.jac[l * m + aj] * alpha : alpha * S.e[l];
         }
+      }
+      MT(2);
 #pragma unroll
       for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) { double v = f_rl64(acc, i * (i + 1) / 2 + j); jacTjac[i * m + j] = v; jacTjac[j * m + i] = v; }
+        for (int j = 0; j <= i; j++) { double v = g_get<G>(acc, g, i * (i + 1) / 2 + j); jacTjac[i * m + j] = v; jacTjac[j * m + i] = v; }
 #pragma unroll
-      for (int i = 0; i < 6; i++) jacTe[i] = f_rl64(acc, 21 + i);
+      for (int i = 0; i < 6; i++) jacTe[i] = g_get<G>(acc, g, 21 + i);
       p_L2 = jacTe_inf = 0.0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -558,6 +646,7 @@ __device__ int f_levmar6(MState &S, int n, int e1, int e2, const double *ci1, co
         p_L2 += p[i] * p[i];
       }
     }
+    MT(3);
     if (jacTe_inf <= eps1) { Dp_L2 = 0.0; stop = 1; break; }
     if (k == 0) {
       tmp = DBL_MIN;
@@ -574,36 +663,43 @@ __device__ int f_levmar6(MState &S, int n, int e1, int e2, const double *ci1, co
       for (int i = 0; i < 36; i++) A[i] = jacTjac[i];
 #pragma unroll
       for (int i = 0; i < 6; i++) Bv[i] = jacTe[i];
-      issolved = lf_solve6(A, Bv, 1);
+      if constexpr (G == 64) issolved = lf_solve6_u(A, Bv, 1);   // one system per wavefront: scalar pivot branches
+      else issolved = lf_solve6(A, Bv, 1);
 #pragma unroll
       for (int i = 0; i < 6; i++) Dp[i] = Bv[i];
     }
+    MT(4);
     if (issolved) {
       Dp_L2 = 0.0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) { pDp[i] = p[i] + (tmp = Dp[i]); Dp_L2 += tmp * tmp; }
       if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
       if (Dp_L2 >= (p_L2 + eps2) / (1E-12 * 1E-12)) { stop = 4; break; }
-      f_mle_cost(S, n, e1, e2, ci1, ci2, pDp, S.wrk);
-      f_sync();
-      for (int i = lane; i < n; i += 64) S.wrk2[i] = 0.0 - S.wrk[i];
-      f_sync();
-      pDp_eL2 = 0.0;
-      for (int i = 0; i < n; ++i) { tmp = S.wrk2[i]; pDp_eL2 += tmp * tmp; }
+      f_mle_cost<G, RW>(S, g, n, e1, e2, ci1, ci2, pDp, wrk);
+      MT(5);
+#pragma unroll
+      for (int h = 0; h < SL; h++) wrk2[h] = 0.0 - wrk[h];
+      pDp_eL2 = f_ordered_sumsq<G, RW>(wrk2, g, n);
+      MT(6);
       if (!(lf_fabs(pDp_eL2) <= DBL_MAX)) { stop = 7; break; }
       dF = p_eL2 - pDp_eL2;
       if (updp || dF > 0) {                       // Broyden rank-one update, row-parallel
-        for (int i = lane; i < n; i += 64) {
-          double t2 = 0.0;
+        g_order<G>();                             // the accumulator lanes are done reading the old rows
 #pragma unroll
-          for (int l = 0; l < 6; ++l) t2 += S.jac[i * m + l] * Dp[l];
-          t2 = (S.wrk[i] - S.hx[i] - t2) / Dp_L2;
+        for (int h = 0; h < SL; h++) {
+          int i = lane + G * h;
+          if (i < n) {
+            double t2 = 0.0;
 #pragma unroll
-          for (int j = 0; j < 6; ++j) S.jac[i * m + j] += t2 * Dp[j];
+            for (int l = 0; l < 6; ++l) t2 += S.jac[i * m + l] * Dp[l];
+            t2 = (wrk[h] - hx[h] - t2) / Dp_L2;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) S.jac[i * m + j] += t2 * Dp[j];
+          }
         }
-        f_sync();
         ++updjac; newjac = 1;
       }
+      MT(7);
       dL = 0.0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) dL += Dp[i] * (mu * Dp[i] + jacTe[i]);
@@ -614,8 +710,8 @@ __device__ int f_levmar6(MState &S, int n, int e1, int e2, const double *ci1, co
         nu = 2;
 #pragma unroll
         for (int i = 0; i < 6; ++i) p[i] = pDp[i];
-        for (int i = lane; i < n; i += 64) { S.e[i] = S.wrk2[i]; S.hx[i] = S.wrk[i]; }
-        f_sync();
+#pragma unroll
+        for (int h = 0; h < SL; h++) { int i = lane + G * h; hx[h] = wrk[h]; if (i < n) S.e[i] = wrk2[h]; }
         p_eL2 = pDp_eL2;
         updp = 1;
         continue;
@@ -630,24 +726,43 @@ __device__ int f_levmar6(MState &S, int n, int e1, int e2, const double *ci1, co
   }
   if (k >= itmax) stop = 3;
   *stop_out = stop;
+#ifdef LF_MLE_PROFILE
+  MT(8);
+  if (blockIdx.x == 7 && blockIdx.y == 0 && lane == 0 && G == 64) {
+    printf("k_mle prof (kcycles) n=%d iters=%d: loop/tail %.1f fdjac %.1f acc %.1f gather %.1f solve %.1f cost %.1f sumsq %.1f broyden %.1f end %.1f\n", n, k,
+           g_mprof[0] / 1e3, g_mprof[1] / 1e3, g_mprof[2] / 1e3, g_mprof[3] / 1e3, g_mprof[4] / 1e3, g_mprof[5] / 1e3, g_mprof[6] / 1e3, g_mprof[7] / 1e3, g_mprof[8] / 1e3);
+    for (int i = 0; i < 16; i++) g_mprof[i] = 0;
+  }
+#endif
   return (stop != 4 && stop != 7) ? k : -1;
 }
+#undef MT
 
-__global__ void __launch_bounds__(64) k_mle(FrontConsts c, FrontBuffers b) {
-  __shared__ MState S;
-  const int f = blockIdx.y, lane = f_lane(), lid = blockIdx.x;
-  int nl = b.nlines[f];
-  if (nl > c.line_cap) nl = c.line_cap;
-  if (lid >= nl) return;
+
+template <int G, int RW, int WHICH>
+__global__ void __launch_bounds__(64, 2) k_mle(FrontConsts c, FrontBuffers b) {
+  typedef MleCfgT<G, RW> Cfg;
+  __shared__ double lds_rows[Cfg::NG][Cfg::ROWS * MLE_ROW_DOUBLES];
+  const int f = blockIdx.y, wl = f_lane();
+  MleGroup g;
+  g.gbase = (wl / G) * G; g.glane = wl % G;
+  const int lane = g.glane;
+  // work lists of k_records: [0] lines with <= 32 support points (two lines per wavefront), [1] more, [2] unused
+  const int which = WHICH;
+  const int item = blockIdx.x * Cfg::NG + wl / G;
+  if (item >= b.mle_cnt[3 * f + which]) return;
+  const int lid = b.mle_list[((size_t)f * 3 + which) * c.line_cap + item];
+  MState S;
+  f_mstate_bind(S, lds_rows[wl / G], Cfg::ROWS);
   const lf_params &P = c.P;
   lf_line_record *R = b.recs + (size_t)f * c.line_cap + lid;
   const int seg = R->seg;
   double *out = b.cand_out + ((size_t)f * c.cand_cap + seg) * LF_CAND_STRIDE;
   const double *pts = b.pts + ((size_t)f * c.cand_cap + seg) * (LF_MAX_SAMPLES * 3);
   int ns = (int)out[26];
-  if (ns > MLE_N) ns = MLE_N;
+  if (ns > Cfg::ROWS) ns = Cfg::ROWS;
   double LA[3] = {out[0], out[1], out[2]}, LB[3] = {out[3], out[4], out[5]};
-  for (int i = lane; i < ns; i += 64) {
+  for (int i = lane; i < ns; i += G) {
     double pos[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, cov[9], DU[9], Wsq[3];
     f_pt_cov(pos, c.K[0], P, cov);
     f_whiten(cov, DU, Wsq);
@@ -656,14 +771,14 @@ __global__ void __launch_bounds__(64) k_mle(FrontConsts c, FrontBuffers b) {
 #pragma unroll
     for (int k = 0; k < 9; k++) S.DU[9 * i + k] = DU[k];
   }
-  f_sync();
+  g_order<G>();
   int e1, e2;
   {   // extremities along the line (utils.cpp:985-999), first occurrence on ties
     double AmB[3] = {LA[0] - LB[0], LA[1] - LB[1], LA[2] - LB[2]};
     double vmin = 100.0, vmax = -100.0;
     int imin = 1 << 30, imax = 1 << 30;
-    for (int h = 0; h < 2; h++) {
-      int i = lane + 64 * h;
+    for (int h = 0; h < Cfg::SLOTS; h++) {
+      int i = lane + G * h;
       if (i < ns) {
         const double *x = &S.pos[3 * i];
         double dp = (x[0] - LA[0]) * AmB[0] + (x[1] - LA[1]) * AmB[1] + (x[2] - LA[2]) * AmB[2];
@@ -671,8 +786,8 @@ __global__ void __launch_bounds__(64) k_mle(FrontConsts c, FrontBuffers b) {
         if (dp > vmax) { vmax = dp; imax = i; }
       }
     }
-    f_argmin(vmin, imin);
-    f_argmax(vmax, imax);
+    g_argmin<G>(vmin, imin);
+    g_argmax<G>(vmax, imax);
     e1 = (imin == (1 << 30)) ? 0 : imin;
     e2 = (imax == (1 << 30)) ? 0 : imax;
     if (e1 > e2) { int t = e1; e1 = e2; e2 = t; }
@@ -688,7 +803,7 @@ __global__ void __launch_bounds__(64) k_mle(FrontConsts c, FrontBuffers b) {
     for (int k = 0; k < 3; k++) { para[k] = S.pos[3 * e1 + k]; para[3 + k] = S.pos[3 * e2 + k]; }
   }
   int stop = 0;
-  int nit = f_levmar6(S, ns, e1, e2, ci1, ci2, para, P.line3d_mle_iter_num, &stop);
+  int nit = f_levmar6<G, RW>(S, g, ns, e1, e2, ci1, ci2, para, P.line3d_mle_iter_num, &stop);
   // ---- MleLine3dCov (utils.cpp:1138-1159): H = J^T J in point order, cov = H^-1
   double H[36], I6[36];
 #pragma unroll
@@ -891,6 +1006,8 @@ void lf_front_launch(const FrontConsts &c, const FrontBuffers &b, int B, hipStre
   hipLaunchKernelGGL(k_sobel5, dim3((c.W + 255) / 256, c.H, B), dim3(256), 0, st, c, b);
   hipLaunchKernelGGL(k_line3d, dim3(c.cand_cap, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_records, dim3(B), dim3(64), 0, st, c, b);
-  hipLaunchKernelGGL(k_mle, dim3(c.line_cap, B), dim3(64), 0, st, c, b);
+  hipLaunchKernelGGL((k_mle<32, 32, 0>), dim3((c.line_cap + 1) / 2, B), dim3(64), 0, st, c, b);
+  // (pairing the 33..64-point lines as <32, 64> was measured slower: two row slots per lane, select-based pivoting)
+  hipLaunchKernelGGL((k_mle<64, MLE_N, 1>), dim3(c.line_cap, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_describe, dim3(c.line_cap, B), dim3(64), 0, st, c, b);
 }

@@ -100,7 +100,16 @@ LF_DEFINE_JACOBI(lf_jacobi4, 4)
 /* ---------------------------------------------------------------- linear solve
  * Gaussian elimination with partial pivoting on the n x n row-major matrix A (overwritten) and the
  * n x m right-hand side B (row-major, overwritten with the solution).  Returns 0 if singular. */
-#define LF_DEFINE_SOLVE(NAME, N)                                                               \
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LF_UNI_I(x) __builtin_amdgcn_readfirstlane(x)   /* the value is the same in every lane: branch, do not select */
+#else
+#define LF_UNI_I(x) (x)
+#endif
+#define LF_SAME_I(x) (x)
+/* UNI = LF_SAME_I: lanes may hold different systems.  UNI = LF_UNI_I (the *_u variants): the caller guarantees
+ * that all lanes of the wavefront hold the SAME system, so pivot decisions become scalar branches (same
+ * arithmetic, same result; on the host the two variants are identical). */
+#define LF_DEFINE_SOLVE(NAME, N, UNI)                                                          \
   LF_HD int NAME(double *A, double *B, int m) {                                                \
     int i, j, k;                                                                               \
     double rp[N];                         /* reciprocals of the pivots (one division each) */  \
@@ -111,7 +120,8 @@ LF_DEFINE_JACOBI(lf_jacobi4, 4)
         double v = lf_fabs(A[i * N + k]);                                                      \
         if (v > big) { big = v; piv = i; }                                                     \
       }                                                                                        \
-      if (!(big > 0.0)) return 0;                                                              \
+      piv = UNI(piv);                                                                          \
+      if (UNI((int)!(big > 0.0))) return 0;                                                    \
       if (piv != k)                                                                            \
         for (i = k + 1; i < N; i++)          /* row swap with constant indices */              \
           if (i == piv) {                                                                      \
@@ -121,7 +131,7 @@ LF_DEFINE_JACOBI(lf_jacobi4, 4)
       rp[k] = 1.0 / A[k * N + k];                                                              \
       for (i = k + 1; i < N; i++) {                                                            \
         double f = A[i * N + k] * rp[k];                                                       \
-        if (f != 0.0) {                                                                        \
+        if (UNI((int)(f != 0.0))) {                                                            \
           for (j = k + 1; j < N; j++) A[i * N + j] -= f * A[k * N + j];                        \
           for (j = 0; j < m; j++) B[i * m + j] -= f * B[k * m + j];                            \
         }                                                                                      \
@@ -136,9 +146,11 @@ LF_DEFINE_JACOBI(lf_jacobi4, 4)
       }                                                                                        \
     return 1;                                                                                  \
   }
-LF_DEFINE_SOLVE(lf_solve3, 3)
-LF_DEFINE_SOLVE(lf_solve6, 6)
-LF_DEFINE_SOLVE(lf_solve7, 7)
+LF_DEFINE_SOLVE(lf_solve3, 3, LF_SAME_I)
+LF_DEFINE_SOLVE(lf_solve6, 6, LF_SAME_I)
+LF_DEFINE_SOLVE(lf_solve7, 7, LF_SAME_I)
+LF_DEFINE_SOLVE(lf_solve6_u, 6, LF_UNI_I)
+LF_DEFINE_SOLVE(lf_solve7_u, 7, LF_UNI_I)
 
 /* inverse of a symmetric/any 3x3 (row-major) through lf_solve3; returns 0 if singular */
 LF_HD int lf_inv3(const double *A, double *Ainv) {
