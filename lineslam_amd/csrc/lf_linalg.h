@@ -106,6 +106,13 @@ LF_DEFINE_JACOBI(lf_jacobi4, 4)
 #define LF_UNI_I(x) (x)
 #endif
 #define LF_SAME_I(x) (x)
+/* "does any lane of the wavefront need this?" -- a uniform guard around rarely needed, select-heavy blocks (the
+ * lanes that do not need it are still protected by their own condition inside); plain condition on the host. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LF_ANY(c) (__builtin_amdgcn_ballot_w64((c)) != 0ull)
+#else
+#define LF_ANY(c) (c)
+#endif
 /* UNI = LF_SAME_I: lanes may hold different systems.  UNI = LF_UNI_I (the *_u variants): the caller guarantees
  * that all lanes of the wavefront hold the SAME system, so pivot decisions become scalar branches (same
  * arithmetic, same result; on the host the two variants are identical). */
@@ -122,7 +129,7 @@ LF_DEFINE_JACOBI(lf_jacobi4, 4)
       }                                                                                        \
       piv = UNI(piv);                                                                          \
       if (UNI((int)!(big > 0.0))) return 0;                                                    \
-      if (piv != k)                                                                            \
+      if (LF_ANY(piv != k))                                                                    \
         for (i = k + 1; i < N; i++)          /* row swap with constant indices */              \
           if (i == piv) {                                                                      \
             for (j = 0; j < N; j++) { double t = A[k * N + j]; A[k * N + j] = A[i * N + j]; A[i * N + j] = t; } \

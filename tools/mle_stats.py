@@ -21,4 +21,5 @@ print("3D lines per frame %.0f | numSmp mean %.1f | RANSAC inliers (LM rows) mea
       (len(ns) / B, ns.mean(), ninl.mean(), np.percentile(ninl, 50), np.percentile(ninl, 90), ninl.max()))
 print("levmar iterations mean %.1f p50 %.0f p90 %.0f max %.0f; stop reasons:" % (its.mean(), np.percentile(its, 50), np.percentile(its, 90), its.max()),
       {int(s): int((stops == s).sum()) for s in np.unique(stops)})
+print("support points: <=16 %.2f  <=32 %.2f  <=64 %.2f; iterations of those <=16: mean %.1f, 17..32: %.1f, >32: %.1f" % ((ninl <= 16).mean(), (ninl <= 32).mean(), (ninl <= 64).mean(), its[ninl <= 16].mean(), its[(ninl > 16) & (ninl <= 32)].mean(), its[ninl > 32].mean()))
 print("stage ms:", [round(ctx.stage_ms(i), 2) for i in range(3)])
