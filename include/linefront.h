@@ -217,7 +217,7 @@ LF_API int lf_pair_get_descdiff(lf_ctx *ctx, int pair, double *D, size_t cap_dou
  * As lf_match_pairs_device, but getTransform_PtsLines_ransac (motion.cpp:605-849) also receives point
  * matches, exactly as Node::matchNodePair hands it MatchingResult::all_matches (node.cpp:1519-1530):
  *   d_points   DEVICE [frames of the last batch][pt_cap][4] floats = Node::feature_locations_3d_
- *              (x, y, z, 1; z = NaN when the keypoint has no depth, node.cpp:952-1018); must stay valid
+ *              (x, y, z, 1 as Node::projectTo3D builds them, node.cpp:952-1018; a NaN z is treated as errorFunction2 does); must stay valid
  *              until the call has completed on the context stream
  *   pm_query / pm_train   HOST [n_pairs][pm_cap]: cv::DMatch::queryIdx / trainIdx into the newer / older
  *              node's point array;  n_pm HOST [n_pairs] (each <= min(pm_cap, 512), else LF_ERR_CAPACITY)
@@ -252,6 +252,34 @@ LF_API int lf_pair_get_motion(lf_ctx *ctx, int pair, double R[9], double t[3]);
  * id_a / id_b key the counter-based sample generator. */
 LF_API int lf_relmotion_lines(lf_ctx *ctx, const lf_line_record *a, const lf_line_record *b, int n, uint64_t id_a,
                               uint64_t id_b, double R[9], double t[3], int32_t *inliers, int cap, int *n_inliers);
+
+/* ---- point side feeding the hybrid solver (without the ORB extractor) ----------
+ * Node::projectTo3D (src/node.cpp:952-1018): key points (cv::KeyPoint::pt, x then y) + depth image ->
+ * feature_locations_3d_ (x, y, Z, 1).  Key points outside the image, NaN, or on a NaN depth are dropped (ordered
+ * compaction; d_kept_out receives the indices of the survivors, may be NULL); at most max_keypoints points.
+ * All pointers are DEVICE memory; d_depth as in lf_detect3d_batch_device.  Asynchronous. */
+LF_API int lf_project_keypoints_device(lf_ctx *ctx, const float *d_depth, size_t depth_frame_stride,
+                                       int depth_row_stride, int n_frames, const float *d_kp_xy,
+                                       const int32_t *d_nkp, int kp_cap, const double K[9], double depth_scaling,
+                                       int max_keypoints, float *d_points_out, int32_t *d_npts_out,
+                                       int32_t *d_kept_out);
+/* Node::featureMatching, BRUTEFORCE / ORB branch (src/node.cpp:606-641): for every pair (newer = query_frames[i],
+ * older = train_frames[i], slots of the last batch -- their node ids key the random distance offset) the two
+ * nearest Hamming neighbours of every query descriptor (256-bit ORB, 32 bytes), the ratio test
+ * d1/d2 < nn_distance_ratio, the unique-train filter in query order.  d_desc [frames][desc_cap][32], d_ndesc
+ * [frames]; outputs [n_pairs][desc_cap] (cv::DMatch queryIdx / trainIdx / distance) + [n_pairs] counts; all DEVICE
+ * memory except the two HOST frame lists; desc_cap <= 1024.  Asynchronous. */
+LF_API int lf_feature_match_pairs_device(lf_ctx *ctx, const uint8_t *d_desc, const int32_t *d_ndesc, int desc_cap,
+                                         const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
+                                         double nn_distance_ratio, int32_t *d_match_q, int32_t *d_match_t,
+                                         float *d_match_dist, int32_t *d_nmatch);
+/* lf_match_pairs_hybrid_device with the point matches already on the DEVICE (e.g. straight from
+ * lf_feature_match_pairs_device): rows of pm_stride entries, counts above 512 are truncated to the first 512
+ * (lf_pair_result::n_point_matches still reports the full count). */
+LF_API int lf_match_pairs_hybrid_device_pm(lf_ctx *ctx, const int32_t *query_frames, const int32_t *train_frames,
+                                           int n_pairs, const float *d_points, int pt_cap, const int32_t *d_pm_query,
+                                           const int32_t *d_pm_train, const int32_t *d_n_pm, int pm_stride,
+                                           const double K[9]);
 
 /* Stage durations (ms) of the last launches, measured with HIP events recorded on the context
  * stream: which = 0 LSD data-parallel kernels, 1 the LSD sweep kernel (k_lsd_sweep), 2 the 3D-line

@@ -81,6 +81,9 @@ SYMBOLS = {
     "lf_match_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, C.c_uint64, _vp]),
     "lf_match_pairs_hybrid_device": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "lf_pair_get_point_inliers": (_i, [_vp, _i, _vp, _i, _pi]),
+    "lf_project_keypoints_device": (_i, [_vp, _vp, C.c_size_t, _i, _i, _vp, _vp, _i, _vp, C.c_double, _i, _vp, _vp, _vp]),
+    "lf_feature_match_pairs_device": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, C.c_double, _vp, _vp, _vp, _vp]),
+    "lf_match_pairs_hybrid_device_pm": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "lf_relmotion_pairs_device": (_i, [_vp, _vp, _vp, _i]),
     "lf_pair_get_motion": (_i, [_vp, _i, _vp, _vp]),
     "lf_relmotion_lines": (_i, [_vp, _vp, _vp, _i, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _i, _pi]),
@@ -309,6 +312,34 @@ class Context:
         R, t = np.zeros(9), np.zeros(3)
         self._chk(lib().lf_pair_get_motion(self._h, pair, R.ctypes.data, t.ctypes.data), "lf_pair_get_motion")
         return R.reshape(3, 3), t
+
+    def project_keypoints_device(self, d_depth_ptr, n_frames, d_kp_ptr, d_nkp_ptr, kp_cap, K, d_points_ptr, d_npts_ptr,
+                                 d_kept_ptr=0, depth_scaling=1.0, max_keypoints=600):
+        """Node::projectTo3D for a batch of frames, everything device-resident (async)."""
+        Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+        self._chk(lib().lf_project_keypoints_device(self._h, int(d_depth_ptr), self.width * self.height, self.width, n_frames,
+                                                    int(d_kp_ptr), int(d_nkp_ptr), kp_cap, Kc.ctypes.data,
+                                                    float(depth_scaling), int(max_keypoints), int(d_points_ptr),
+                                                    int(d_npts_ptr), int(d_kept_ptr) or None),
+                  "lf_project_keypoints_device")
+
+    def feature_match_pairs_device(self, d_desc_ptr, d_ndesc_ptr, desc_cap, query_frames, train_frames, d_mq, d_mt,
+                                   d_md, d_nm, nn_distance_ratio=0.5):
+        """Node::featureMatching (ORB / Hamming brute force) for pairs of frames, device-resident (async)."""
+        q = np.ascontiguousarray(query_frames, np.int32)
+        t = np.ascontiguousarray(train_frames, np.int32)
+        self._chk(lib().lf_feature_match_pairs_device(self._h, int(d_desc_ptr), int(d_ndesc_ptr), desc_cap, q.ctypes.data,
+                                                      t.ctypes.data, len(q), float(nn_distance_ratio), int(d_mq), int(d_mt),
+                                                      int(d_md), int(d_nm)), "lf_feature_match_pairs_device")
+
+    def match_pairs_hybrid_device_pm(self, query_frames, train_frames, d_points_ptr, pt_cap, d_pm_q, d_pm_t, d_npm,
+                                     pm_stride, K):
+        q = np.ascontiguousarray(query_frames, np.int32)
+        t = np.ascontiguousarray(train_frames, np.int32)
+        Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+        self._chk(lib().lf_match_pairs_hybrid_device_pm(self._h, q.ctypes.data, t.ctypes.data, len(q), int(d_points_ptr),
+                                                        int(pt_cap), int(d_pm_q), int(d_pm_t), int(d_npm), int(pm_stride),
+                                                        Kc.ctypes.data), "lf_match_pairs_hybrid_device_pm")
 
     def pair_point_inliers(self, pair, cap=512):
         m = np.zeros(cap, np.int32)

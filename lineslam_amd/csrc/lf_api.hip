@@ -8,6 +8,7 @@
 #include "lf_lsd.h"
 #include "lf_front.h"
 #include "lf_pair.h"
+#include "lf_points.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -606,12 +607,12 @@ int lf_detect3d(lf_ctx *c, const uint8_t *gray, int gray_row_stride, const float
 }
 
 // ---- a19-a25 -----------------------------------------------------------------------------------
-struct HybridArgs { const float *d_points; int pt_cap; const int32_t *pm_q, *pm_t, *n_pm; int pm_cap; const double *K; };
+struct HybridArgs { const float *d_points; int pt_cap; const int32_t *pm_q, *pm_t, *n_pm; int pm_cap; const double *K; bool pm_on_device; };
 #define LF_NODE_PT_CAP 4096
 
 static int hybrid_prepare(lf_ctx *c, const HybridArgs &h, int n_pairs, PairBuffers &pb) {
   if (!h.d_points || h.pt_cap < 1 || !h.pm_q || !h.pm_t || !h.n_pm || h.pm_cap < 0 || !h.K) return LF_ERR_INVALID;
-  for (int i = 0; i < n_pairs; i++) {
+  for (int i = 0; i < n_pairs && !h.pm_on_device; i++) {
     if (h.n_pm[i] < 0) return LF_ERR_INVALID;
     if (h.n_pm[i] > h.pm_cap || h.n_pm[i] > LF_MAX_PT_MATCHES) { c->err = "point matches per pair exceed the capacity (512)"; return LF_ERR_CAPACITY; }
     for (int k = 0; k < h.n_pm[i]; k++) {
@@ -628,17 +629,21 @@ static int hybrid_prepare(lf_ctx *c, const HybridArgs &h, int n_pairs, PairBuffe
     c->pb.pm_q = c->d_pm_q; c->pb.pm_t = c->d_pm_t; c->pb.npm = c->d_npm;
     c->hybrid_ready = true;
   }
-  std::vector<int> hq((size_t)n_pairs * LF_MAX_PT_MATCHES, 0), ht((size_t)n_pairs * LF_MAX_PT_MATCHES, 0);
-  for (int i = 0; i < n_pairs; i++)
-    for (int k = 0; k < h.n_pm[i]; k++) {
-      hq[(size_t)i * LF_MAX_PT_MATCHES + k] = h.pm_q[(size_t)i * h.pm_cap + k];
-      ht[(size_t)i * LF_MAX_PT_MATCHES + k] = h.pm_t[(size_t)i * h.pm_cap + k];
-    }
-  HIPCHK(c, hipMemcpyAsync(c->d_pm_q, hq.data(), hq.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_pm_t, ht.data(), ht.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_npm, h.n_pm, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!h.pm_on_device) {
+    std::vector<int> hq((size_t)n_pairs * LF_MAX_PT_MATCHES, 0), ht((size_t)n_pairs * LF_MAX_PT_MATCHES, 0);
+    for (int i = 0; i < n_pairs; i++)
+      for (int k = 0; k < h.n_pm[i]; k++) {
+        hq[(size_t)i * LF_MAX_PT_MATCHES + k] = h.pm_q[(size_t)i * h.pm_cap + k];
+        ht[(size_t)i * LF_MAX_PT_MATCHES + k] = h.pm_t[(size_t)i * h.pm_cap + k];
+      }
+    HIPCHK(c, hipMemcpyAsync(c->d_pm_q, hq.data(), hq.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pm_t, ht.data(), ht.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_npm, h.n_pm, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  c->pb.pm_q = c->d_pm_q; c->pb.pm_t = c->d_pm_t; c->pb.npm = c->d_npm; c->pb.pm_stride = LF_MAX_PT_MATCHES;
   pb = c->pb;
+  if (h.pm_on_device) { pb.pm_q = h.pm_q; pb.pm_t = h.pm_t; pb.npm = h.n_pm; pb.pm_stride = h.pm_cap; }
   pb.pts = h.d_points; pb.pts_t = h.d_points; pb.pt_cap = h.pt_cap; pb.pt_cap_t = h.pt_cap;
   // errorFunction2 constants (misc.cpp:704-711) and sigma_depth (misc2.h:23), host libm as in the reference
   const double cam_angle_x = 58.0 / 180.0 * M_PI, cam_angle_y = 45.0 / 180.0 * M_PI;
@@ -697,8 +702,72 @@ int lf_match_pairs_hybrid_device(lf_ctx *c, const int32_t *query_frames, const i
                                  const float *d_points, int pt_cap, const int32_t *pm_query, const int32_t *pm_train,
                                  const int32_t *n_pm, int pm_cap, const double K[9]) {
   if (!c) return LF_ERR_INVALID;
-  HybridArgs h = {d_points, pt_cap, pm_query, pm_train, n_pm, pm_cap, K};
+  HybridArgs h = {d_points, pt_cap, pm_query, pm_train, n_pm, pm_cap, K, false};
   return match_pairs_impl(c, query_frames, train_frames, n_pairs, nullptr, nullptr, nullptr, 0, 0, &h);
+}
+
+int lf_match_pairs_hybrid_device_pm(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
+                                    const float *d_points, int pt_cap, const int32_t *d_pm_query, const int32_t *d_pm_train,
+                                    const int32_t *d_n_pm, int pm_stride, const double K[9]) {
+  if (!c || pm_stride < 1) return LF_ERR_INVALID;
+  HybridArgs h = {d_points, pt_cap, d_pm_query, d_pm_train, d_n_pm, pm_stride, K, true};
+  return match_pairs_impl(c, query_frames, train_frames, n_pairs, nullptr, nullptr, nullptr, 0, 0, &h);
+}
+
+int lf_project_keypoints_device(lf_ctx *c, const float *d_depth, size_t depth_frame_stride, int depth_row_stride,
+                                int n_frames, const float *d_kp_xy, const int32_t *d_nkp, int kp_cap, const double K[9],
+                                double depth_scaling, int max_keypoints, float *d_points_out, int32_t *d_npts_out,
+                                int32_t *d_kept_out) {
+  if (!c || !d_depth || !d_kp_xy || !d_nkp || !K || !d_points_out || !d_npts_out || n_frames < 1 || kp_cap < 1 ||
+      max_keypoints < 1 || depth_row_stride < c->W)
+    return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  PointConsts pc;
+  memset(&pc, 0, sizeof pc);
+  pc.W = c->W; pc.H = c->H;
+  for (int i = 0; i < 9; i++) pc.K[i] = K[i];
+  pc.depth_scaling = depth_scaling; pc.max_keyp = max_keypoints < kp_cap ? max_keypoints : kp_cap; pc.kp_cap = kp_cap;
+  PointBuffers pb;
+  memset(&pb, 0, sizeof pb);
+  pb.depth = d_depth; pb.depth_frame_stride = depth_frame_stride; pb.depth_row_stride = depth_row_stride;
+  pb.kp_xy = d_kp_xy; pb.nkp = d_nkp; pb.points = d_points_out; pb.npts = d_npts_out; pb.kept = d_kept_out;
+  lf_points_project_launch(pc, pb, n_frames, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return LF_OK;
+}
+
+int lf_feature_match_pairs_device(lf_ctx *c, const uint8_t *d_desc, const int32_t *d_ndesc, int desc_cap,
+                                  const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
+                                  double nn_distance_ratio, int32_t *d_match_q, int32_t *d_match_t, float *d_match_dist,
+                                  int32_t *d_nmatch) {
+  if (!c || !d_desc || !d_ndesc || !query_frames || !train_frames || !d_match_q || !d_match_t || !d_match_dist ||
+      !d_nmatch || n_pairs < 1 || desc_cap < 1)
+    return LF_ERR_INVALID;
+  if (desc_cap > 1024 || n_pairs > c->maxB) return LF_ERR_CAPACITY;
+  for (int i = 0; i < n_pairs; i++)
+    if (query_frames[i] < 0 || query_frames[i] >= c->last_batch || train_frames[i] < 0 || train_frames[i] >= c->last_batch)
+      return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  {   // pair lists through the pinned staging area
+    if (c->stage_pairs_pending) HIPCHK(c, hipEventSynchronize(c->ev_stage_pairs));
+    int *hq = (int *)(c->h_stage + (size_t)c->maxB * 8), *ht = hq + c->maxB;
+    memcpy(hq, query_frames, sizeof(int) * (size_t)n_pairs);
+    memcpy(ht, train_frames, sizeof(int) * (size_t)n_pairs);
+    HIPCHK(c, hipMemcpyAsync(c->d_pair_q, hq, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pair_t, ht, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_stage_pairs, c->stream));
+    c->stage_pairs_pending = true;
+  }
+  PointConsts pc;
+  memset(&pc, 0, sizeof pc);
+  pc.desc_cap = desc_cap; pc.nn_ratio = nn_distance_ratio; pc.rng_seed = c->params.rng_seed;
+  PointBuffers pb;
+  memset(&pb, 0, sizeof pb);
+  pb.desc = d_desc; pb.ndesc = d_ndesc; pb.frame_ids = c->d_frame_ids; pb.pair_q = c->d_pair_q; pb.pair_t = c->d_pair_t;
+  pb.fm_q = d_match_q; pb.fm_t = d_match_t; pb.fm_d = d_match_dist; pb.fm_n = d_nmatch;
+  lf_points_match_launch(pc, pb, n_pairs, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return LF_OK;
 }
 
 int lf_relmotion_pairs_device(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs) {

@@ -43,7 +43,8 @@ struct PairBuffers {
   // ---- hybrid solver (points + lines, BASELINE config 3); allocated on first use
   const float *pts, *pts_t;     // [frames][pt_cap][4]  Node::feature_locations_3d_ (x,y,z,1; z NaN = no depth)
   int pt_cap, pt_cap_t;
-  const int *pm_q, *pm_t;       // [n_pairs][LF_MAX_PT_MATCHES] point matches (queryIdx, trainIdx)
+  const int *pm_q, *pm_t;       // [n_pairs][pm_stride] point matches (queryIdx, trainIdx)
+  int pm_stride;
   const int *npm;               // [n_pairs]
   int *pt_inliers;              // [n_pairs][LF_MAX_PT_MATCHES] indices into the point match list
   double *ws_h;                 // [n_pairs][lf_pair_hybrid_ws_doubles()]

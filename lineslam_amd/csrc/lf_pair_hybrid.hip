@@ -405,8 +405,8 @@ __global__ void __launch_bounds__(64) k_pose_hybrid(PairConsts c, PairBuffers b)
   pc.qpts = b.pts + (size_t)fq * b.pt_cap * 4;
   pc.mq = b.match_q + (size_t)pr * c.match_cap;
   pc.mt = b.match_t + (size_t)pr * c.match_cap;
-  pc.pq = b.pm_q + (size_t)pr * LF_MAX_PT_MATCHES;
-  pc.pt = b.pm_t + (size_t)pr * LF_MAX_PT_MATCHES;
+  pc.pq = b.pm_q + (size_t)pr * b.pm_stride;
+  pc.pt = b.pm_t + (size_t)pr * b.pm_stride;
   pc.ws = b.ws_h + (size_t)pr * W_TOTAL;
   pc.P = c.P;
   pc.pm = c.pm;

@@ -247,3 +247,29 @@ def relmotion_oracle(train, query, mq, mt, params, stream, flavour="lf"):
                                     C.c_void_p(R.ctypes.data), C.c_void_p(tv.ctypes.data), C.c_void_p(inl.ctypes.data),
                                     C.c_void_p(dbg.ctypes.data))
     return n, R.reshape(3, 3).copy(), tv.copy(), inl[:n].copy(), dbg
+
+
+def feature_match_oracle(qdesc, tdesc, ratio=0.5, seed=0, stream=0, flavour="lf"):
+    """oracle_feature_match: Node::featureMatching, BRUTEFORCE/ORB branch.  Returns (queryIdx, trainIdx, distance)."""
+    lib = oracle_lib(flavour)
+    q, t = np.ascontiguousarray(qdesc, np.uint8), np.ascontiguousarray(tdesc, np.uint8)
+    oq, ot, od = np.zeros(max(len(q), 1), np.int32), np.zeros(max(len(q), 1), np.int32), np.zeros(max(len(q), 1), np.float32)
+    lib.oracle_feature_match.restype = C.c_int
+    n = lib.oracle_feature_match(C.c_void_p(q.ctypes.data), C.c_int(len(q)), C.c_void_p(t.ctypes.data), C.c_int(len(t)),
+                                 C.c_double(ratio), C.c_uint64(seed), C.c_uint64(stream), C.c_void_p(oq.ctypes.data),
+                                 C.c_void_p(ot.ctypes.data), C.c_void_p(od.ctypes.data))
+    return oq[:n].copy(), ot[:n].copy(), od[:n].copy()
+
+
+def project_to_3d_oracle(kp, depth, K, depth_scaling=1.0, max_keyp=600, flavour="lf"):
+    """oracle_project_to_3d: Node::projectTo3D.  Returns (points [m,4] float32, kept indices)."""
+    lib = oracle_lib(flavour)
+    k = np.ascontiguousarray(kp, np.float32).reshape(-1, 2)
+    d = np.ascontiguousarray(depth, np.float32)
+    Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+    pts, kept = np.zeros((max(len(k), 1), 4), np.float32), np.zeros(max(len(k), 1), np.int32)
+    lib.oracle_project_to_3d.restype = C.c_int
+    m = lib.oracle_project_to_3d(C.c_void_p(k.ctypes.data), C.c_int(len(k)), C.c_void_p(d.ctypes.data), C.c_int(d.shape[1]),
+                                 C.c_int(d.shape[1]), C.c_int(d.shape[0]), C.c_void_p(Kc.ctypes.data), C.c_double(depth_scaling),
+                                 C.c_int(max_keyp), C.c_void_p(pts.ctypes.data), C.c_void_p(kept.ctypes.data))
+    return pts[:m].copy(), kept[:m].copy()

@@ -1,0 +1,102 @@
+"""GPU parity for the point side (run with -m gpu): k_project3d / k_featmatch vs oracle/point_oracle.c, bit for bit,
+and the fully device-resident chain projectTo3D -> featureMatching -> hybrid solver (BASELINE config 3)."""
+import numpy as np
+import pytest
+
+import _oracle as O
+from lineslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+NF, KP, DC = 3, 700, 640
+
+
+def _keypoints(rng, poses, depth):
+    """synthetic 'ORB' output: scene points (pixels of frame 0 with depth) seen from every frame -> pixel coordinates +
+    256-bit descriptors, in a different order in every frame"""
+    n = 620
+    K = synth.K_TUM
+    u, v = rng.uniform(40, 600, n), rng.uniform(40, 440, n)
+    z = depth[0][np.round(v).astype(int), np.round(u).astype(int)].astype(np.float64)
+    good = np.isfinite(z)
+    u, v, z = u[good], v[good], z[good]
+    n = len(u)
+    Pc = np.c_[(u - K[0, 2]) * z / K[0, 0], (v - K[1, 2]) * z / K[1, 1], z, np.ones(n)]
+    Pw = (poses[0] @ Pc.T).T
+    base = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    kps, descs = [], []
+    for f in range(NF):
+        pc = (np.linalg.inv(poses[f]) @ Pw.T).T
+        uv = (K @ (pc[:, :3] / pc[:, 2:3]).T).T[:, :2] + rng.normal(0, 0.2, (n, 2))
+        perm = rng.permutation(n)
+        noise = rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8) & \
+            rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        kps.append(uv[perm].astype(np.float32))
+        descs.append((base ^ noise)[perm])
+    return kps, descs
+
+
+def test_point_side_and_device_chain(built_lib):
+    import torch
+    from lineslam_amd import capi
+    g, d, poses = synth.sequence(NF, seed=9)
+    d = d.copy()
+    d[:, 50:60, 50:200] = np.nan
+    P = capi.default_params()
+    ctx = capi.Context(640, 480, max_batch=NF, params=P)
+    dg, dd = torch.from_numpy(g).cuda(), torch.from_numpy(d).cuda()
+    ids = np.array([40, 41, 42], np.uint64)
+    ctx.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), NF, synth.K_TUM, ids)
+    recs = [ctx.frame_lines(k) for k in range(NF)]
+    rng = np.random.default_rng(6)
+    kps, descs = _keypoints(rng, poses, d)
+    kp = np.zeros((NF, KP, 2), np.float32)
+    nkp = np.zeros(NF, np.int32)
+    for f in range(NF):
+        kp[f, :len(kps[f])] = kps[f]
+        nkp[f] = len(kps[f])
+    kp[0, 3] = [-5.0, 10.0]; kp[1, 7] = [np.nan, 3.0]                 # invalid key points are dropped
+    dkp, dnkp = torch.from_numpy(kp).cuda(), torch.from_numpy(nkp).cuda()
+    dpts = torch.zeros((NF, KP, 4), dtype=torch.float32, device="cuda")
+    dnp = torch.zeros(NF, dtype=torch.int32, device="cuda")
+    dkept = torch.zeros((NF, KP), dtype=torch.int32, device="cuda")
+    ctx.project_keypoints_device(dd.data_ptr(), NF, dkp.data_ptr(), dnkp.data_ptr(), KP, synth.K_TUM, dpts.data_ptr(),
+                                 dnp.data_ptr(), dkept.data_ptr(), max_keypoints=500)
+    ctx.synchronize()
+    pts_h, np_h, kept_h = dpts.cpu().numpy(), dnp.cpu().numpy(), dkept.cpu().numpy()
+    desc = np.zeros((NF, DC, 32), np.uint8)
+    for f in range(NF):
+        op, ok = O.project_to_3d_oracle(kp[f, :nkp[f]], d[f], synth.K_TUM, max_keyp=500)
+        assert np_h[f] == len(op) == 500 and np.array_equal(kept_h[f, :len(ok)], ok)   # capped by max_keypoints
+        assert np.array_equal(pts_h[f, :len(op)].view(np.uint32), op.view(np.uint32))
+        desc[f, :len(ok)] = descs[f][ok]                              # descriptors follow the surviving key points
+    ddesc, dnd = torch.from_numpy(desc).cuda(), dnp.clone()
+    q, t = np.array([1, 2, 2], np.int32), np.array([0, 1, 0], np.int32)
+    dmq = torch.zeros((3, DC), dtype=torch.int32, device="cuda")
+    dmt, dmd = torch.zeros_like(dmq), torch.zeros((3, DC), dtype=torch.float32, device="cuda")
+    dnm = torch.zeros(3, dtype=torch.int32, device="cuda")
+    ctx.feature_match_pairs_device(ddesc.data_ptr(), dnd.data_ptr(), DC, q, t, dmq.data_ptr(), dmt.data_ptr(), dmd.data_ptr(),
+                                   dnm.data_ptr())
+    ctx.match_pairs_hybrid_device_pm(q, t, dpts.data_ptr(), KP, dmq.data_ptr(), dmt.data_ptr(), dnm.data_ptr(), DC, synth.K_TUM)
+    ctx.synchronize()
+    mq_h, mt_h, md_h, nm_h = dmq.cpu().numpy(), dmt.cpu().numpy(), dmd.cpu().numpy(), dnm.cpu().numpy()
+    for i in range(3):
+        fq, ft = int(q[i]), int(t[i])
+        stream = (int(ids[fq]) << 32) ^ int(ids[ft]) ^ 0x4000000000000000
+        oq, ot, od = O.feature_match_oracle(desc[fq, :np_h[fq]], desc[ft, :np_h[ft]], 0.5, seed=P.rng_seed, stream=stream)
+        assert nm_h[i] == len(oq) > 250
+        assert np.array_equal(mq_h[i, :len(oq)], oq) and np.array_equal(mt_h[i, :len(oq)], ot)
+        assert np.array_equal(md_h[i, :len(oq)].view(np.uint32), od.view(np.uint32))
+        # the hybrid solver on exactly these device-resident matches
+        adjacent = abs(int(ids[fq]) - int(ids[ft])) <= P.adjacent_linematch_window
+        lmq, lmt, _, _ = O.match_oracle(recs[fq], recs[ft], adjacent)
+        ps = (int(ids[fq]) << 32) ^ int(ids[ft]) ^ 0x2000000000000000
+        ok, tf, rmse, pinl, linl, dbg = O.pose_hybrid_oracle(recs[ft], recs[fq], pts_h[ft], pts_h[fq], oq, ot, lmq, lmt,
+                                                             int(ids[ft]), int(ids[fq]), P, ps, focal=synth.K_TUM[0, 0])
+        r = ctx.pair_result(i)
+        assert bool(r.valid) == ok and r.n_point_matches == len(oq)
+        assert np.array_equal(np.array(list(r.T), np.float32).reshape(4, 4), tf)
+        assert np.array_equal(ctx.pair_point_inliers(i), pinl) and np.array_equal(ctx.pair_inliers(i), linl)
+        if ok:
+            Tgt = np.linalg.inv(poses[ft]) @ poses[fq]
+            assert np.linalg.norm(tf[:3, 3] - Tgt[:3, 3]) < 0.02
+    ctx.close()
