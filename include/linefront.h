@@ -253,6 +253,15 @@ LF_API int lf_pair_get_motion(lf_ctx *ctx, int pair, double R[9], double t[3]);
 LF_API int lf_relmotion_lines(lf_ctx *ctx, const lf_line_record *a, const lf_line_record *b, int n, uint64_t id_a,
                               uint64_t id_b, double R[9], double t[3], int32_t *inliers, int cap, int *n_inliers);
 
+/* ---- raw TUM frames ------------------------------------------------------------------
+ * The pixel conversions of OpenNIListener::loadRawData (src/openni_listener.cpp:1233-1246) and Node::Node
+ * (src/node.cpp:193) for a batch of decoded frames: d_rgb [n][H][W][3] bytes R,G,B as stored in the PNG files,
+ * d_depth16 [n][H][W] 16-bit depth -> the grey image LSD receives (the reference applies CV_RGB2GRAY to a BGR
+ * matrix: blue is weighted as red) and depth in metres (value / depth_factor, 0 -> NaN).  The outputs are laid
+ * out as lf_detect3d_batch_device expects them (dense, row stride W).  DEVICE pointers.  Asynchronous. */
+LF_API int lf_ingest_tum_device(lf_ctx *ctx, const uint8_t *d_rgb, const uint16_t *d_depth16, int n_frames,
+                                double depth_factor, uint8_t *d_gray_out, float *d_depth_out);
+
 /* ---- point side feeding the hybrid solver (without the ORB extractor) ----------
  * Node::projectTo3D (src/node.cpp:952-1018): key points (cv::KeyPoint::pt, x then y) + depth image ->
  * feature_locations_3d_ (x, y, Z, 1).  Key points outside the image, NaN, or on a NaN depth are dropped (ordered

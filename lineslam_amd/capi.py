@@ -81,6 +81,7 @@ SYMBOLS = {
     "lf_match_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, C.c_uint64, _vp]),
     "lf_match_pairs_hybrid_device": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "lf_pair_get_point_inliers": (_i, [_vp, _i, _vp, _i, _pi]),
+    "lf_ingest_tum_device": (_i, [_vp, _vp, _vp, _i, C.c_double, _vp, _vp]),
     "lf_project_keypoints_device": (_i, [_vp, _vp, C.c_size_t, _i, _i, _vp, _vp, _i, _vp, C.c_double, _i, _vp, _vp, _vp]),
     "lf_feature_match_pairs_device": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, C.c_double, _vp, _vp, _vp, _vp]),
     "lf_match_pairs_hybrid_device_pm": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
@@ -312,6 +313,11 @@ class Context:
         R, t = np.zeros(9), np.zeros(3)
         self._chk(lib().lf_pair_get_motion(self._h, pair, R.ctypes.data, t.ctypes.data), "lf_pair_get_motion")
         return R.reshape(3, 3), t
+
+    def ingest_tum_device(self, d_rgb_ptr, d_depth16_ptr, n_frames, d_gray_ptr, d_depth_ptr, depth_factor=5000.0):
+        """loadRawData pixel conversions on the device: RGB + 16-bit depth -> grey u8 + depth in metres (async)."""
+        self._chk(lib().lf_ingest_tum_device(self._h, int(d_rgb_ptr), int(d_depth16_ptr), n_frames, float(depth_factor),
+                                             int(d_gray_ptr), int(d_depth_ptr)), "lf_ingest_tum_device")
 
     def project_keypoints_device(self, d_depth_ptr, n_frames, d_kp_ptr, d_nkp_ptr, kp_cap, K, d_points_ptr, d_npts_ptr,
                                  d_kept_ptr=0, depth_scaling=1.0, max_keypoints=600):

@@ -736,6 +736,15 @@ int lf_project_keypoints_device(lf_ctx *c, const float *d_depth, size_t depth_fr
   return LF_OK;
 }
 
+int lf_ingest_tum_device(lf_ctx *c, const uint8_t *d_rgb, const uint16_t *d_depth16, int n_frames, double depth_factor,
+                         uint8_t *d_gray_out, float *d_depth_out) {
+  if (!c || !d_rgb || !d_depth16 || !d_gray_out || !d_depth_out || n_frames < 1 || !(depth_factor > 0)) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  lf_points_ingest_launch(d_rgb, d_depth16, d_gray_out, d_depth_out, (size_t)n_frames * c->W * c->H, depth_factor, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return LF_OK;
+}
+
 int lf_feature_match_pairs_device(lf_ctx *c, const uint8_t *d_desc, const int32_t *d_ndesc, int desc_cap,
                                   const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
                                   double nn_distance_ratio, int32_t *d_match_q, int32_t *d_match_t, float *d_match_dist,

@@ -32,3 +32,5 @@ struct PointBuffers {
 };
 void lf_points_project_launch(const PointConsts &c, const PointBuffers &b, int n_frames, hipStream_t stream);
 void lf_points_match_launch(const PointConsts &c, const PointBuffers &b, int n_pairs, hipStream_t stream);
+void lf_points_ingest_launch(const uint8_t *rgb, const uint16_t *depth16, uint8_t *gray, float *depth, size_t npix,
+                             double depth_factor, hipStream_t stream);

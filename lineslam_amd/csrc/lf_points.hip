@@ -114,6 +114,26 @@ __global__ void __launch_bounds__(FM_THREADS) k_featmatch(PointConsts c, PointBu
   if (tid == 0) b.fm_n[pr] = total;
 }
 
+// OpenNIListener::loadRawData pixel conversions (src/openni_listener.cpp:1233-1246) + the grey image of Node::Node
+// (src/node.cpp:193: cvtColor(CV_RGB2GRAY) applied to the BGR matrix of cv::imread, i.e. memory channel 0 = BLUE is
+// weighted as red): gray = (4899 B + 9617 G + 1868 R + 8192) >> 14 (OpenCV 2.4 fixed point), depth = u16 -> float,
+// values < 1e-5 -> NaN, times (float)(1/5000.0).
+__global__ void __launch_bounds__(256) k_ingest_tum(const uint8_t *rgb, const uint16_t *depth16, uint8_t *gray, float *depth,
+                                                    size_t npix, float inv_factor) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  unsigned r = rgb[3 * i], g = rgb[3 * i + 1], bl = rgb[3 * i + 2];
+  gray[i] = (uint8_t)((bl * 4899u + g * 9617u + r * 1868u + 8192u) >> 14);
+  float d = (float)depth16[i];
+  if (d < 1e-5) d = __builtin_nanf("");
+  depth[i] = d * inv_factor;
+}
+void lf_points_ingest_launch(const uint8_t *rgb, const uint16_t *depth16, uint8_t *gray, float *depth, size_t npix,
+                             double depth_factor, hipStream_t st) {
+  hipLaunchKernelGGL(k_ingest_tum, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, rgb, depth16, gray, depth, npix,
+                     (float)(1.0 / depth_factor));
+}
+
 void lf_points_project_launch(const PointConsts &c, const PointBuffers &b, int n_frames, hipStream_t st) {
   hipLaunchKernelGGL(k_project3d, dim3(n_frames), dim3(64), 0, st, c, b);
 }

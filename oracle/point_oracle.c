@@ -81,3 +81,18 @@ int oracle_project_to_3d(const float *kp, int n, const float *depth, int stride_
   }
   return m;
 }
+
+/* loadRawData pixel conversions (openni_listener.cpp:1233-1246) + Node::Node grey image (node.cpp:193), restated from
+ * OpenCV 2.4 (cvtColor fixed point: 4899 / 9617 / 1868, shift 14; convertTo float with the scale cast to float). */
+void oracle_ingest_tum(const uint8_t *rgb, const uint16_t *depth16, size_t npix, double depth_factor, uint8_t *gray,
+                       float *depth) {
+  size_t i;
+  float inv = (float)(1.0 / depth_factor);
+  for (i = 0; i < npix; i++) {
+    unsigned r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+    float d = (float)depth16[i];
+    gray[i] = (uint8_t)((b * 4899u + g * 9617u + r * 1868u + 8192u) >> 14);
+    if (d < 1e-5) d = NAN;
+    depth[i] = d * inv;
+  }
+}

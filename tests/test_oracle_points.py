@@ -53,3 +53,47 @@ def test_project_to_3d_rules():
         assert np.isclose(p[0], (x - K[0, 2]) * Z / K[0, 0], rtol=1e-6) and np.isclose(p[1], (y - K[1, 2]) * Z / K[1, 1], rtol=1e-6)
     pts2, kept2 = O.project_to_3d_oracle(kp, depth, K, max_keyp=2)
     assert kept2.tolist() == [0, 3]
+
+
+def test_tum_folder_roundtrip_and_ate(tmp_path):
+    """tum.py: PNG codec, syncidx.txt loader, trajectory writer and ATE with the reference scripts' semantics."""
+    import ctypes as C
+    from lineslam_amd import tum
+    rng = np.random.default_rng(1)
+    n, h, w = 3, 48, 64
+    rgb = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    dep = rng.integers(0, 30000, (n, h, w)).astype(np.uint16)
+    dep[:, 5:8, 5:20] = 0
+    (tmp_path / "rgb").mkdir(); (tmp_path / "depth").mkdir()
+    with open(tmp_path / "syncidx.txt", "w") as f:
+        for k in range(n):
+            tum.write_png(str(tmp_path / "rgb" / ("%d.png" % k)), rgb[k])
+            tum.write_png(str(tmp_path / "depth" / ("%d.png" % k)), dep[k])
+            f.write("%.6f rgb/%d.png %.6f depth/%d.png\n" % (100 + 0.033 * k, k, 100.005 + 0.033 * k, k))
+    r2, d2, ts = tum.load_raw_data(str(tmp_path))
+    assert np.array_equal(r2, rgb) and np.array_equal(d2, dep) and np.allclose(ts, 100 + 0.033 * np.arange(n))
+    assert len(tum.load_raw_data(str(tmp_path), data_skip_step=2)[2]) == 2
+    # pixel conversions of the oracle: blue weighted as red, 0 -> NaN, /5000 in float
+    lib = O.oracle_lib("lf")
+    g, dm = np.zeros((n, h, w), np.uint8), np.zeros((n, h, w), np.float32)
+    lib.oracle_ingest_tum(C.c_void_p(rgb.ctypes.data), C.c_void_p(dep.ctypes.data), C.c_size_t(n * h * w), C.c_double(5000.0),
+                          C.c_void_p(g.ctypes.data), C.c_void_p(dm.ctypes.data))
+    ref = (rgb[..., 2].astype(np.uint32) * 4899 + rgb[..., 1].astype(np.uint32) * 9617 + rgb[..., 0].astype(np.uint32) * 1868 + 8192) >> 14
+    assert np.array_equal(g, ref.astype(np.uint8))
+    assert np.isnan(dm[dep == 0]).all() and np.allclose(dm[dep > 0], dep[dep > 0] / 5000.0, rtol=1e-6)
+    # trajectory writer / reader / ATE: a rigidly moved, noise-free copy has zero error
+    F = 30
+    poses = np.tile(np.eye(4), (F, 1, 1))
+    poses[:, :3, 3] = np.c_[np.linspace(0, 1, F), np.sin(np.linspace(0, 3, F)), np.linspace(0, 0.3, F)]
+    tsF = 50 + 0.03 * np.arange(F)
+    tum.write_poses(str(tmp_path / "gt.txt"), tsF, poses)
+    th = 0.3
+    Rz = np.array([[np.cos(th), -np.sin(th), 0, 0.5], [np.sin(th), np.cos(th), 0, -0.2], [0, 0, 1, 0.1], [0, 0, 0, 1]])
+    est = np.einsum("ij,fjk->fik", Rz, poses)
+    tum.write_poses(str(tmp_path / "est.txt"), tsF + 0.004, est, valid=np.arange(F) % 7 != 3)
+    line = open(tmp_path / "est.txt").readline().split("\t")
+    assert len(line) == 8 and np.isclose(float(line[7]), np.cos(th / 2))            # qw last
+    assert tum.evaluate_ate(str(tmp_path / "gt.txt"), str(tmp_path / "est.txt")) < 1e-9
+    est[:, 0, 3] += 0.01 * (np.arange(F) % 2)
+    tum.write_poses(str(tmp_path / "est2.txt"), tsF + 0.004, est)
+    assert 0.003 < tum.evaluate_ate(str(tmp_path / "gt.txt"), str(tmp_path / "est2.txt")) < 0.006

@@ -100,3 +100,30 @@ def test_point_side_and_device_chain(built_lib):
             Tgt = np.linalg.inv(poses[ft]) @ poses[fq]
             assert np.linalg.norm(tf[:3, 3] - Tgt[:3, 3]) < 0.02
     ctx.close()
+
+
+def test_ingest_tum_on_device(built_lib):
+    import ctypes as C
+    import torch
+    from lineslam_amd import capi
+    rng = np.random.default_rng(2)
+    n = 2
+    rgb = rng.integers(0, 256, (n, 480, 640, 3), dtype=np.uint8)
+    dep = rng.integers(0, 40000, (n, 480, 640)).astype(np.uint16)
+    dep[:, 100:110] = 0
+    ctx = capi.Context(640, 480, max_batch=n)
+    drgb, ddep = torch.from_numpy(rgb).cuda(), torch.from_numpy(dep.view(np.int16)).cuda()
+    dg = torch.zeros((n, 480, 640), dtype=torch.uint8, device="cuda")
+    dd = torch.zeros((n, 480, 640), dtype=torch.float32, device="cuda")
+    ctx.ingest_tum_device(drgb.data_ptr(), ddep.data_ptr(), n, dg.data_ptr(), dd.data_ptr())
+    ctx.synchronize()
+    lib = O.oracle_lib("lf")
+    g, dm = np.zeros((n, 480, 640), np.uint8), np.zeros((n, 480, 640), np.float32)
+    lib.oracle_ingest_tum(C.c_void_p(rgb.ctypes.data), C.c_void_p(dep.ctypes.data), C.c_size_t(rgb.size // 3), C.c_double(5000.0),
+                          C.c_void_p(g.ctypes.data), C.c_void_p(dm.ctypes.data))
+    assert np.array_equal(dg.cpu().numpy(), g)
+    assert np.array_equal(dd.cpu().numpy().view(np.uint32), dm.view(np.uint32))
+    # and straight into the front end
+    ctx.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), n, synth.K_TUM, np.arange(n, dtype=np.uint64))
+    ctx.synchronize()
+    ctx.close()
