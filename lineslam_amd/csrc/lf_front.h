@@ -32,7 +32,7 @@ struct FrontBuffers {
   double *pts;               // [B][cand_cap][LF_MAX_SAMPLES*3] supporting points of each RANSAC line
   lf_line_record *recs;      // [B][line_cap]
   int *nlines;               // [B]  (may exceed line_cap: overflow)
-  int *mle_list;             // [B][3][line_cap] line ids for the MLE stage by #support points: <= 32, 33..64, more
+  int *mle_list;             // [B][3][line_cap] line ids for the MLE stage by #support points: <= 16, 17..32, more
   int *mle_cnt;              // [B][3]
 };
 

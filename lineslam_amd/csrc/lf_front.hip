@@ -443,10 +443,11 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
     bool have = s < nseg && flag[s] == 2;
     u64 m = __ballot(have);
     int lid = base + __popcll(m & f_lt());
-    {   // MLE work lists by number of RANSAC support points: <= 32, 33..64, more
+    {   // MLE work lists by number of RANSAC support points: <= 16, 17..32, more
       bool kept = have && lid < c.line_cap;
       int nsup = kept ? (int)b.cand_out[((size_t)f * c.cand_cap + s) * LF_CAND_STRIDE + 26] : 0;
-      bool small = kept && nsup <= 32, mid = kept && nsup > 32, large = false;   // (a separate launch for > 64 only adds a tail)
+      // (a G = 16 variant, four lines per wavefront for <= 16 points, was measured slower: list 0 stays empty)
+      bool small = false, mid = kept && nsup <= 32, large = kept && nsup > 32;
       u64 ms = __ballot(small), mm = __ballot(mid), ml = __ballot(large);
       if (small) list0[n0 + __popcll(ms & f_lt())] = lid;
       if (mid) list1[n1 + __popcll(mm & f_lt())] = lid;
@@ -488,8 +489,8 @@ __device__ __forceinline__ void f_mstate_bind(MState &S, double *lds, int rows) 
 }
 
 // ---- lane groups.  A 3D line with n support points is handled by a GROUP of G lanes: G = 64 (one line per
-// wavefront, two row slots per lane, n <= 104) or G = 32 (two lines per wavefront; one row per lane for n <= 32 --
-// three quarters of all lines -- or two rows per lane for n <= 64).  Values that are "uniform" for a line are uniform within its group; control flow
+// wavefront, two row slots per lane, n <= 104) or G = 32 (two lines per wavefront, one row per lane, n <= 32: 80 % of
+// the lines).  The code also instantiates for G = 16 (two accumulator slots per lane); measured slower, not launched.  Values that are "uniform" for a line are uniform within its group; control flow
 // that depends on them simply diverges between the two groups of a wavefront.
 template <int G, int ROWS_> struct MleCfgT {
   static constexpr int NG = 64 / G;
@@ -579,10 +580,17 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
   double hx[SL], ev[SL], wrk[SL], wrk2[SL];
   double mu = 0, tmp, p_eL2, jacTe_inf = 0, pDp_eL2, p_L2 = 0, Dp_L2 = DBL_MAX, dF, dL;
   int nu, nu2, stop = 0, K = 10, updjac = 0, updp = 1, newjac = 0, k;
-  // accumulator ownership: lanes 0..20 lower triangle (i,j), lanes 21..26 J^T e
-  int ai = 0, aj = 0;
-  if (lane < 21) { int a = lane; while ((ai + 1) * (ai + 2) / 2 <= a) ai++; aj = a - ai * (ai + 1) / 2; }
-  else if (lane < 27) { ai = lane - 21; aj = -1; }
+  // accumulator ownership: entries 0..20 lower triangle (i,j), 21..26 J^T e; entry a lives in group lane a % G,
+  // slot a / G (one slot for G >= 32, two for G = 16)
+  constexpr int NACC = (27 + G - 1) / G;
+  int ai[NACC], aj[NACC];
+#pragma unroll
+  for (int q = 0; q < NACC; q++) {
+    int a = lane + G * q;
+    ai[q] = 0; aj[q] = 0;
+    if (a < 21) { while ((ai[q] + 1) * (ai[q] + 2) / 2 <= a) ai[q]++; aj[q] = a - ai[q] * (ai[q] + 1) / 2; }
+    else if (a < 27) { ai[q] = a - 21; aj[q] = -1; }
+  }
 #ifdef LF_MLE_PROFILE
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
@@ -613,31 +621,42 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
     if (newjac) {
       newjac = 0;
       g_order<G>();                           // Jacobian rows and e of all lanes visible
-      double acc = 0.0;
-      if (lane < 27) {
-        const double *colB = (aj >= 0) ? (S.jac + aj) : S.e;   // second factor: J[l][aj] or e[l]
-        const int strideB = (aj >= 0) ? m : 1;
-        int l = n;
-        for (; l >= 4; l -= 4) {              // four rows per trip: loads first, additions in levmar's order
-          double a0 = S.jac[(l - 1) * m + ai], a1 = S.jac[(l - 2) * m + ai], a2 = S.jac[(l - 3) * m + ai], a3 = S.jac[(l - 4) * m + ai];
-          double b0 = colB[(l - 1) * strideB], b1 = colB[(l - 2) * strideB], b2 = colB[(l - 3) * strideB], b3 = colB[(l - 4) * strideB];
-          acc += (aj >= 0) ? b0 * a0 : a0 * b0;
-          acc += (aj >= 0) ? b1 * a1 : a1 * b1;
-          acc += (aj >= 0) ? b2 * a2 : a2 * b2;
-          acc += (aj >= 0) ? b3 * a3 : a3 * b3;
-        }
-        for (; l-- > 0;) {
-          double alpha = S.jac[l * m + ai];
-          acc += (aj >= 0) ? S.jac[l * m + aj] * alpha : alpha * S.e[l];
+      double acc[NACC];
+#pragma unroll
+      for (int q = 0; q < NACC; q++) {
+        acc[q] = 0.0;
+        if (lane + G * q < 27) {
+          const int ai_ = ai[q], aj_ = aj[q];
+          const double *colB = (aj_ >= 0) ? (S.jac + aj_) : S.e;   // second factor: J[l][aj] or e[l]
+          const int strideB = (aj_ >= 0) ? m : 1;
+          double s = 0.0;
+          int l = n;
+          for (; l >= 4; l -= 4) {              // four rows per trip: loads first, additions in levmar's order
+            double a0 = S.jac[(l - 1) * m + ai_], a1 = S.jac[(l - 2) * m + ai_], a2 = S.jac[(l - 3) * m + ai_], a3 = S.jac[(l - 4) * m + ai_];
+            double b0 = colB[(l - 1) * strideB], b1 = colB[(l - 2) * strideB], b2 = colB[(l - 3) * strideB], b3 = colB[(l - 4) * strideB];
+            s += (aj_ >= 0) ? b0 * a0 : a0 * b0;
+            s += (aj_ >= 0) ? b1 * a1 : a1 * b1;
+            s += (aj_ >= 0) ? b2 * a2 : a2 * b2;
+            s += (aj_ >= 0) ? b3 * a3 : a3 * b3;
+          }
+          for (; l-- > 0;) {
+            double alpha = S.jac[l * m + ai_];
+            s += (aj_ >= 0) ? S.jac[l * m + aj_] * alpha : alpha * S.e[l];
+          }
+          acc[q] = s;
         }
       }
       MT(2);
 #pragma unroll
       for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) { double v = g_get<G>(acc, g, i * (i + 1) / 2 + j); jacTjac[i * m + j] = v; jacTjac[j * m + i] = v; }
+        for (int j = 0; j <= i; j++) {
+          const int a = i * (i + 1) / 2 + j;
+          double v = g_get<G>(acc[a / G], g, a % G);
+          jacTjac[i * m + j] = v; jacTjac[j * m + i] = v;
+        }
 #pragma unroll
-      for (int i = 0; i < 6; i++) jacTe[i] = g_get<G>(acc, g, 21 + i);
+      for (int i = 0; i < 6; i++) jacTe[i] = g_get<G>(acc[(21 + i) / G], g, (21 + i) % G);
       p_L2 = jacTe_inf = 0.0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -747,7 +766,7 @@ __global__ void __launch_bounds__(64, 2) k_mle(FrontConsts c, FrontBuffers b) {
   MleGroup g;
   g.gbase = (wl / G) * G; g.glane = wl % G;
   const int lane = g.glane;
-  // work lists of k_records: [0] lines with <= 32 support points (two lines per wavefront), [1] more, [2] unused
+  // work lists of k_records: [0] unused, [1] lines with <= 32 support points (two per wavefront), [2] more (one)
   const int which = WHICH;
   const int item = blockIdx.x * Cfg::NG + wl / G;
   if (item >= b.mle_cnt[3 * f + which]) return;
@@ -1006,8 +1025,8 @@ void lf_front_launch(const FrontConsts &c, const FrontBuffers &b, int B, hipStre
   hipLaunchKernelGGL(k_sobel5, dim3((c.W + 255) / 256, c.H, B), dim3(256), 0, st, c, b);
   hipLaunchKernelGGL(k_line3d, dim3(c.cand_cap, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_records, dim3(B), dim3(64), 0, st, c, b);
-  hipLaunchKernelGGL((k_mle<32, 32, 0>), dim3((c.line_cap + 1) / 2, B), dim3(64), 0, st, c, b);
+  hipLaunchKernelGGL((k_mle<32, 32, 1>), dim3((c.line_cap + 1) / 2, B), dim3(64), 0, st, c, b);   // 2 lines per wavefront
   // (pairing the 33..64-point lines as <32, 64> was measured slower: two row slots per lane, select-based pivoting)
-  hipLaunchKernelGGL((k_mle<64, MLE_N, 1>), dim3(c.line_cap, B), dim3(64), 0, st, c, b);
+  hipLaunchKernelGGL((k_mle<64, MLE_N, 2>), dim3(c.line_cap, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_describe, dim3(c.line_cap, B), dim3(64), 0, st, c, b);
 }
