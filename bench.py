@@ -93,17 +93,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # LF_BENCH_FORCE_EXCHANGE=1: run the multi-rank code path (process group, keyframe all-gather, loop-closure
+    # matching against the gathered map) even with one rank -- the only way to exercise it on a 1-GPU box
+    dist_on = world > 1 or os.environ.get("LF_BENCH_FORCE_EXCHANGE") == "1"
     import torch
     import torch.distributed as dist
     from lineslam_amd import ate, build, capi, synth
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if dist_on:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if rank == 0:
         build.build()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     P = capi.default_params(launch=not a.default_params)
     F = a.frames
@@ -118,10 +125,13 @@ def main():
     pq, pt = np.arange(1, F, dtype=np.int32), np.arange(0, F - 1, dtype=np.int32)
     K = synth.K_TUM
     # keyframe line maps for the loop-closure exchange (config 5): fixed-stride records, one all-gather per step
-    kf = np.linspace(0, F - 1, a.keyframes).astype(np.int64) if world > 1 else None
+    kf = np.linspace(0, F - 1, a.keyframes).astype(np.int64) if dist_on else None
     rec_bytes, line_cap = 1040, 512
 
     n_lc = 64   # loop-closure queries per step on every rank (config 4 style: local frames vs all keyframes)
+    sel = torch.from_numpy(kf).cuda() if dist_on else None      # (device-resident: nothing in a step blocks the host)
+    lc_q = np.full(n_lc, F - 1, np.int32)
+    lc_t = (np.arange(n_lc) % (world * len(kf))).astype(np.int32) if dist_on else None
 
     def step(i):
         ctx = ctxs[i % nfl]
@@ -131,9 +141,8 @@ def main():
     def step_on(ctx):
         ctx.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), F, K, ids)
         ctx.match_pairs_device(pq, pt)
-        if world > 1:
-            recs_t, nl_t, ids_t = ctx.device_records(torch)
-            sel = torch.from_numpy(kf).cuda()
+        if dist_on:
+            recs_t, nl_t, ids_t = views[id(ctx)]
             mine_r = recs_t[sel].contiguous()                                   # [kf, line_cap*1040] u8
             mine_n = nl_t[sel].contiguous()
             mine_i = (ids_t[sel] + 100000 * (rank + 1)).contiguous()           # node ids far apart: loop closures
@@ -144,24 +153,24 @@ def main():
             dist.all_gather_into_tensor(all_n, mine_n)
             dist.all_gather_into_tensor(all_i, mine_i)
             # loop-closure candidates: the rank's newest frames against every gathered keyframe slot (round robin)
-            q = np.full(n_lc, F - 1, np.int32)
-            t = (np.arange(n_lc) % (world * len(kf))).astype(np.int32)
-            ctx.match_external_device(q, t, all_r.data_ptr(), all_n.data_ptr(), all_i.data_ptr(), world * len(kf), ctx.line_cap)
+            ctx.match_external_device(lc_q, lc_t, all_r.data_ptr(), all_n.data_ptr(), all_i.data_ptr(), world * len(kf), ctx.line_cap)
             return all_r
         return None
 
+    # zero-copy torch views of every context's line maps (taken once: importing a device array may synchronise)
+    views = {id(c): c.device_records(torch) for c in ctxs} if dist_on else {}
     sweep_ms, pre_ms, front_ms, pair_ms = [], [], [], []
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -184,7 +193,7 @@ def main():
         dts = time.perf_counter() - ts
         serial = {"value": F * ks / dts, "ms_per_step": dts / ks * 1e3, "steps": ks,
                   "stage_ms": {k: float(np.mean(v)) for k, v in sst.items()}}
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -193,7 +202,10 @@ def main():
 
     out = None
     if rank == 0:
-        # result quality on this rank's sequence: odometry chain vs ground truth
+        # result quality on this rank's sequence: odometry chain vs ground truth.  With the exchange enabled the
+        # pair slots hold the loop-closure results of the last step: run the odometry pairs once more (untimed).
+        if dist_on:
+            ctx.match_pairs_device(pq, pt)
         res = [ctx.pair_result(i) for i in range(F - 1)]
         valid = np.array([r.valid for r in res], bool)
         Ts = [np.array(list(r.T), np.float64).reshape(4, 4) for r in res]
@@ -239,7 +251,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
     for c in ctxs:
         c.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
