@@ -25,6 +25,7 @@
 // All fp64 arithmetic is IEEE without contraction (-ffp-contract=off); the transcendental
 // functions evaluated on the device come from lf_math.h.
 #include "lf_lsd.h"
+#define LF_SINCOS_DD_LANES   // double-double sin/cos: both series at once in two lanes (callers are wavefront-uniform)
 #include "lf_math.h"
 #include <float.h>
 
@@ -457,10 +458,17 @@ __device__ void d_region2rect(const FV &f, int n, double reg_angle, double prec,
     }
   }
   double lambda = 0.5 * (Ixx + Iyy - lf_sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-  double theta = lf_fabs(Ixx) > lf_fabs(Iyy) ? lf_atan2(lambda - Ixx, Ixy) : lf_atan2(Ixy, lambda - Iyy);
-  if (d_angle_diff(theta, reg_angle) > prec) theta += LF_PI;
+  // correctly rounded atan2 / sin / cos here: the rectangle's end pixel lies exactly on its end edge, so this is
+  // the one place where LSD's output depends on the last bit of libm
+  double t0;
+  lf_dd s0, c0;
+  const bool xx = lf_fabs(Ixx) > lf_fabs(Iyy);
+  const double th = lf_atan2_cr_sc(xx ? lambda - Ixx : Ixy, xx ? Ixy : lambda - Iyy, &t0, &s0, &c0);
+  double theta = th;
+  int flipped = 0;
+  if (d_angle_diff(theta, reg_angle) > prec) { theta += LF_PI; flipped = 1; }
   double dy, dx;
-  lf_sincos(theta, &dy, &dx);
+  lf_sincos_cr_near(theta, flipped, th, t0, s0, c0, &dy, &dx);   // one double-double sin/cos evaluation serves both
   // extents: max/min over the region including 0 (lsd.cpp:1571-1580); order independent
   double l_min = 0.0, l_max = 0.0, w_min = 0.0, w_max = 0.0;
   for (int base = 0; base < n; base += 64) {

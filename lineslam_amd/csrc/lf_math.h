@@ -146,6 +146,165 @@ LF_HD void lf_sincos(double x, double *s, double *c) {
 LF_HD double lf_sin(double x) { double s, c; lf_sincos(x, &s, &c); return s; }
 LF_HD double lf_cos(double x) { double s, c; lf_sincos(x, &s, &c); return c; }
 
+/* ------------------------------------------- correctly rounded sin/cos/atan2 (double-double)
+ * Used where LSD is sensitive to the last bit of libm (region2rect's rectangle angle and axes: every rectangle's
+ * end pixel lies exactly on its end edge).  Error-free transformations without FMA (Dekker / Veltkamp); the results
+ * are accurate to ~2^-100 before the final rounding, i.e. correctly rounded except for inputs whose exact value
+ * lies within 2^-47 ulp of a rounding boundary.  glibc's sin/cos/atan2 are (almost always) correctly rounded too,
+ * so these agree with the reference's libm where the 1-ulp versions above do not. */
+typedef struct { double hi, lo; } lf_dd;
+LF_HD lf_dd lf_dd_make(double hi, double lo) { lf_dd r; r.hi = hi; r.lo = lo; return r; }
+LF_HD lf_dd lf_two_sum(double a, double b) { double s = a + b, bb = s - a; return lf_dd_make(s, (a - (s - bb)) + (b - bb)); }
+LF_HD lf_dd lf_quick_two_sum(double a, double b) { double s = a + b; return lf_dd_make(s, b - (s - a)); }
+LF_HD lf_dd lf_two_prod(double a, double b) {
+  double p = a * b, ca = 134217729.0 * a, cb = 134217729.0 * b;
+  double ah = ca - (ca - a), al = a - ah, bh = cb - (cb - b), bl = b - bh;
+  return lf_dd_make(p, ((ah * bh - p) + ah * bl + al * bh) + al * bl);
+}
+LF_HD lf_dd lf_dd_add(lf_dd a, lf_dd b) {
+  lf_dd s = lf_two_sum(a.hi, b.hi), t = lf_two_sum(a.lo, b.lo);
+  s.lo += t.hi; s = lf_quick_two_sum(s.hi, s.lo);
+  s.lo += t.lo; return lf_quick_two_sum(s.hi, s.lo);
+}
+LF_HD lf_dd lf_dd_neg(lf_dd a) { return lf_dd_make(-a.hi, -a.lo); }
+LF_HD lf_dd lf_dd_mul(lf_dd a, lf_dd b) {
+  lf_dd p = lf_two_prod(a.hi, b.hi);
+  p.lo += a.hi * b.lo + a.lo * b.hi;
+  return lf_quick_two_sum(p.hi, p.lo);
+}
+LF_HD lf_dd lf_dd_mul_d(lf_dd a, double b) {
+  lf_dd p = lf_two_prod(a.hi, b);
+  p.lo += a.lo * b;
+  return lf_quick_two_sum(p.hi, p.lo);
+}
+/* sin and cos of the DOUBLE x as double-doubles, |x| < 2^20, in three steps so that a wavefront can run the two
+ * polynomial chains in two lanes at once (lf_lsd.hip) with exactly the arithmetic of the sequential version:
+ *   reduce : r = x - n pi/2 (double-double), quadrant n
+ *   poly   : Horner chain in z = r^2 of the sine (sel = 0) or cosine (sel = 1) series
+ *   finish : sin r = r + r (ps z), cos r = 1 + pc z, quadrant rotation                                        */
+LF_HD lf_dd lf_sincos_dd_reduce(double x, int *n_out) {
+  const double INVPIO2 = 6.36619772367581382433e-01;
+  const double P1 = 1.5707963267341256, P2 = 6.077100506303966e-11, P3 = 2.0222662487959506e-21, P4 = 1.0085854035872483e-37;
+  double q = x * INVPIO2;
+  int n = (int)(q + (q < 0.0 ? -0.5 : 0.5));
+  double fn = (double)n;
+  /* r = x - n (P1 + P2 + P3 + P4): n P1 and n P2 are exact (33-bit constants) */
+  lf_dd r = lf_two_sum(x - fn * P1, -(fn * P2));
+  lf_dd w = lf_two_prod(fn, P3);
+  r = lf_dd_add(r, lf_dd_neg(w));
+  r = lf_dd_add(r, lf_dd_make(-(fn * P4), 0.0));
+  *n_out = n;
+  return r;
+}
+LF_HD lf_dd lf_sincos_dd_poly(lf_dd z, int sel) {
+  /* (-1)^k / (2k+1)!  and  (-1)^k / (2k)!,  k = 1..13, as double-doubles */
+  static const double SC[13][2] = {
+      {-0.16666666666666666, -9.25185853854297e-18},   {0.008333333333333333, 1.1564823173178714e-19},
+      {-0.0001984126984126984, -1.7209558293420705e-22}, {2.7557319223985893e-06, -1.858393274046472e-22},
+      {-2.505210838544172e-08, 1.448814070935912e-24},  {1.6059043836821613e-10, 1.2585294588752098e-26},
+      {-7.647163731819816e-13, -7.03872877733453e-30},  {2.8114572543455206e-15, 1.6508842730861433e-31},
+      {-8.22063524662433e-18, -2.2141894119604265e-34}, {1.9572941063391263e-20, -1.3643503830087908e-36},
+      {-3.868170170630684e-23, 8.843177655482344e-40},  {6.446950284384474e-26, -1.9330404233703465e-42},
+      {-9.183689863795546e-29, -1.4303150396787322e-45}};
+  static const double CC[13][2] = {
+      {-0.5, 0.0},                                      {0.041666666666666664, 2.3129646346357427e-18},
+      {-0.001388888888888889, 5.300543954373577e-20},   {2.48015873015873e-05, 2.1511947866775882e-23},
+      {-2.755731922398589e-07, -2.3767714622250297e-23}, {2.08767569878681e-09, -1.20734505911326e-25},
+      {-1.1470745597729725e-11, -2.0655512752830745e-28}, {4.779477332387385e-14, 4.399205485834081e-31},
+      {-1.5619206968586225e-16, -1.1910679660273754e-32}, {4.110317623312165e-19, 1.4412973378659527e-36},
+      {-8.896791392450574e-22, 7.911402614872376e-38},  {1.6117375710961184e-24, -3.6846573564509766e-41},
+      {-2.4795962632247976e-27, 1.2953730964765229e-43}};
+  lf_dd p = sel ? lf_dd_make(CC[12][0], CC[12][1]) : lf_dd_make(SC[12][0], SC[12][1]);
+  int k;
+  for (k = 11; k >= 0; k--) p = lf_dd_add(lf_dd_mul(p, z), sel ? lf_dd_make(CC[k][0], CC[k][1]) : lf_dd_make(SC[k][0], SC[k][1]));
+  return p;
+}
+LF_HD void lf_sincos_dd_finish(lf_dd r, lf_dd z, lf_dd ps, lf_dd pc, int n, lf_dd *s, lf_dd *c) {
+  lf_dd ks = lf_dd_add(r, lf_dd_mul(r, lf_dd_mul(ps, z)));
+  lf_dd kc = lf_dd_add(lf_dd_make(1.0, 0.0), lf_dd_mul(pc, z));
+  switch (n & 3) {
+    case 0:  *s = ks;             *c = kc;             break;
+    case 1:  *s = kc;             *c = lf_dd_neg(ks);  break;
+    case 2:  *s = lf_dd_neg(ks);  *c = lf_dd_neg(kc);  break;
+    default: *s = lf_dd_neg(kc);  *c = ks;             break;
+  }
+}
+#if defined(LF_SINCOS_DD_LANES) && defined(__HIP_DEVICE_COMPILE__)
+/* wavefront-uniform callers only (lf_lsd.hip): lane parity picks the series, the two chains run at once */
+LF_HD double lf_bcast_lane(double v, int l) {
+  int lo = __builtin_amdgcn_readlane((int)(lf_bits(v) & 0xffffffffu), l), hi = __builtin_amdgcn_readlane((int)(lf_bits(v) >> 32), l);
+  return lf_from_bits(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+LF_HD void lf_sincos_dd(double x, lf_dd *s, lf_dd *c) {
+  int n;
+  lf_dd r = lf_sincos_dd_reduce(x, &n);
+  lf_dd z = lf_dd_mul(r, r);
+  lf_dd p = lf_sincos_dd_poly(z, (int)(__builtin_amdgcn_mbcnt_lo(~0u, 0u) & 1u));
+  lf_dd ps = lf_dd_make(lf_bcast_lane(p.hi, 0), lf_bcast_lane(p.lo, 0)), pc = lf_dd_make(lf_bcast_lane(p.hi, 1), lf_bcast_lane(p.lo, 1));
+  lf_sincos_dd_finish(r, z, ps, pc, n, s, c);
+}
+#else
+LF_HD void lf_sincos_dd(double x, lf_dd *s, lf_dd *c) {
+  int n;
+  lf_dd r = lf_sincos_dd_reduce(x, &n);
+  lf_dd z = lf_dd_mul(r, r);
+  lf_sincos_dd_finish(r, z, lf_sincos_dd_poly(z, 0), lf_sincos_dd_poly(z, 1), n, s, c);
+}
+#endif
+#define LF_SINCOS_DD(x, s, c) lf_sincos_dd((x), (s), (c))
+LF_HD void lf_sincos_cr(double x, double *s, double *c) {
+  lf_dd sd, cd;
+  LF_SINCOS_DD(x, &sd, &cd);
+  *s = sd.hi + sd.lo;
+  *c = cd.hi + cd.lo;
+}
+/* atan2: one Newton step on the 1-ulp result t0:  t = t0 + (y cos t0 - x sin t0) / (x cos t0 + y sin t0).
+ * Optionally hands back t0 and its double-double sine / cosine for lf_sincos_cr_near below. */
+LF_HD double lf_atan2_cr_sc(double y, double x, double *t0_out, lf_dd *s_out, lf_dd *c_out) {
+  double t0 = lf_atan2(y, x);
+  lf_dd s, c, num, den;
+  *t0_out = t0;
+  if (!(t0 == t0) || (x == 0.0 && y == 0.0) || !(lf_fabs(x) <= 1.7e308) || !(lf_fabs(y) <= 1.7e308)) {
+    LF_SINCOS_DD(t0 == t0 ? t0 : 0.0, s_out, c_out);
+    return t0;
+  }
+  {  /* scale so that the products below can neither overflow nor lose their low parts */
+    double m = lf_fabs(x) > lf_fabs(y) ? lf_fabs(x) : lf_fabs(y);
+    int e = (int)((lf_bits(m) >> 52) & 0x7ff) - 1023;
+    if (e > 400 || e < -400) { double sc = lf_pow2i(e > 0 ? -400 : 400); x *= sc; y *= sc; if (e > 800 || e < -800) { x *= sc; y *= sc; } }
+  }
+  LF_SINCOS_DD(t0, &s, &c);
+  *s_out = s; *c_out = c;
+  num = lf_dd_add(lf_dd_mul_d(c, y), lf_dd_neg(lf_dd_mul_d(s, x)));
+  den = lf_dd_add(lf_dd_mul_d(c, x), lf_dd_mul_d(s, y));
+  return t0 + (num.hi + num.lo) / (den.hi + den.lo);
+}
+LF_HD double lf_atan2_cr(double y, double x) {
+  double t0; lf_dd s, c;
+  return lf_atan2_cr_sc(y, x, &t0, &s, &c);
+}
+/* Correctly rounded sin / cos of the double `theta`, where theta is either th (flipped = 0) or the rounded sum
+ * th + LF_PI (flipped = 1) and th itself lies within a few ulp of t0, whose double-double sine s0 / cosine c0 are
+ * known (lf_atan2_cr_sc): with D = theta - t0 - (flipped ? pi : 0) (|D| < 1e-15, formed exactly),
+ * sin(theta) = +-(s0 + c0 D), cos(theta) = +-(c0 - s0 D); the neglected D^2/2 is below 2^-102.      */
+LF_HD void lf_sincos_cr_near(double theta, int flipped, double th, double t0, lf_dd s0, lf_dd c0, double *s, double *c) {
+  lf_dd D = lf_dd_make(th - t0, 0.0);            /* exact: neighbours in the same binade (or across one) */
+  lf_dd sn, cn;
+  if (flipped) {
+    /* th + LF_PI = theta + err  and  LF_PI = pi - (PI_LO + PI_LO2):  theta = th + pi - (PI_LO + PI_LO2 + err) */
+    lf_dd sum = lf_two_sum(th, LF_PI);           /* sum.hi == theta */
+    lf_dd e = lf_two_sum(LF_PI_LO, sum.lo);
+    e = lf_dd_add(e, lf_dd_make(-2.9947698097183397e-33, 0.0));
+    D = lf_dd_add(D, lf_dd_neg(e));
+    (void)theta;
+  }
+  sn = lf_dd_add(s0, lf_dd_mul(c0, D));
+  cn = lf_dd_add(c0, lf_dd_neg(lf_dd_mul(s0, D)));
+  if (flipped) { sn = lf_dd_neg(sn); cn = lf_dd_neg(cn); }
+  *s = sn.hi + sn.lo;
+  *c = cn.hi + cn.lo;
+}
+
 /* -------------------------------------------------------------------- exp */
 LF_HD double lf_exp(double x) {
   const double LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10,

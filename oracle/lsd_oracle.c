@@ -34,6 +34,9 @@
 #define D_ATAN2(y, x) lf_atan2((y), (x))
 #define D_SIN(x) lf_sin(x)
 #define D_COS(x) lf_cos(x)
+/* region2rect / get_theta use the correctly rounded atan2 / sin / cos of lf_math.h (the one place where LSD
+ * depends on libm's last bit): get_theta keeps the double-double sine / cosine of its Newton start value and
+ * region2rect derives sin / cos of the final theta from them (lf_sincos_cr_near), exactly as the kernel does. */
 #define D_EXP(x) lf_exp(x)
 #define D_LOG10(x) lf_log10(x)
 #define D_POW(x, y) lf_pow((x), (y))
@@ -41,6 +44,7 @@
 #define D_ATAN2(y, x) atan2((y), (x))
 #define D_SIN(x) sin(x)
 #define D_COS(x) cos(x)
+
 #define D_EXP(x) exp(x)
 #define D_LOG10(x) log10(x)
 #define D_POW(x, y) pow((x), (y))
@@ -344,8 +348,13 @@ static double o_rect_nfa(octx *c, const orect *r, double logNT) {
 }
 
 /* lsd.cpp:1474-1512 get_theta */
+#ifdef ORACLE_LFMATH
+typedef struct { double th, t0; int flipped; lf_dd s0, c0; } o_theta_aux;
+#else
+typedef struct { int unused; } o_theta_aux;
+#endif
 static double o_get_theta(const octx *c, int reg_size, double x, double y, double reg_angle,
-                          double prec) {
+                          double prec, o_theta_aux *aux) {
   double lambda, theta, weight, Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
   int i;
   for (i = 0; i < reg_size; i++) {
@@ -357,8 +366,16 @@ static double o_get_theta(const octx *c, int reg_size, double x, double y, doubl
   /* the reference aborts on a null inertia matrix (:1496-1497); cannot occur
      for regions of >= 2 pixels with positive weights                        */
   lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-  theta = fabs(Ixx) > fabs(Iyy) ? D_ATAN2(lambda - Ixx, Ixy) : D_ATAN2(Ixy, lambda - Iyy);
+#ifdef ORACLE_LFMATH
+  theta = fabs(Ixx) > fabs(Iyy) ? lf_atan2_cr_sc(lambda - Ixx, Ixy, &aux->t0, &aux->s0, &aux->c0)
+                                : lf_atan2_cr_sc(Ixy, lambda - Iyy, &aux->t0, &aux->s0, &aux->c0);
+  aux->th = theta; aux->flipped = 0;
+  if (o_angle_diff(theta, reg_angle) > prec) { theta += O_PI; aux->flipped = 1; }
+#else
+  (void)aux;
+  theta = fabs(Ixx) > fabs(Iyy) ? atan2(lambda - Ixx, Ixy) : atan2(Ixy, lambda - Iyy);
   if (o_angle_diff(theta, reg_angle) > prec) theta += O_PI;
+#endif
   return theta;
 }
 
@@ -376,9 +393,14 @@ static void o_region2rect(const octx *c, int reg_size, double reg_angle, double 
   }
   x /= sum;
   y /= sum;
-  theta = o_get_theta(c, reg_size, x, y, reg_angle, prec);
-  dx = D_COS(theta);
-  dy = D_SIN(theta);
+  o_theta_aux aux;
+  theta = o_get_theta(c, reg_size, x, y, reg_angle, prec, &aux);
+#ifdef ORACLE_LFMATH
+  lf_sincos_cr_near(theta, aux.flipped, aux.th, aux.t0, aux.s0, aux.c0, &dy, &dx);
+#else
+  dx = cos(theta);
+  dy = sin(theta);
+#endif
   l_min = l_max = w_min = w_max = 0.0;
   for (i = 0; i < reg_size; i++) {
     l = ((double)c->regx[i] - x) * dx + ((double)c->regy[i] - y) * dy;

@@ -523,3 +523,14 @@ int oracle_relmotion_ransac(const lf_line_record *train, const lf_line_record *q
   return nprev;
 }
 double oracle_acos(double x) { return lf_acos(x); }
+void oracle_sincos_cr(double x, double *s, double *c) { lf_sincos_cr(x, s, c); }
+double oracle_atan2_cr(double y, double x) { return lf_atan2_cr(y, x); }
+/* sin / cos of theta = atan2_cr(y, x) (+ LF_PI if flip) through lf_sincos_cr_near; returns theta */
+double oracle_r2r_angle(double y, double x, int flip, double *s, double *c) {
+  double t0, th, theta;
+  lf_dd s0, c0;
+  th = lf_atan2_cr_sc(y, x, &t0, &s0, &c0);
+  theta = flip ? th + LF_PI : th;
+  lf_sincos_cr_near(theta, flip, th, t0, s0, c0, s, c);
+  return theta;
+}

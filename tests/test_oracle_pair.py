@@ -229,3 +229,27 @@ def test_lf_acos_matches_libm():
     ulp = np.abs(got - ref) / np.spacing(np.maximum(ref, 1e-300))
     assert ulp.max() <= 4, ulp.max()
     assert np.isnan(lib.oracle_acos(C.c_double(1.0000001)))
+
+
+def test_correctly_rounded_trig_of_region2rect():
+    """lf_atan2_cr / lf_sincos_cr (double-double): (almost) always equal to glibc; the single-evaluation path used by
+    region2rect (lf_sincos_cr_near) equals the direct evaluation bit for bit."""
+    import math
+    lib = O.oracle_lib("lf")
+    lib.oracle_atan2_cr.restype = C.c_double
+    lib.oracle_r2r_angle.restype = C.c_double
+    rng = np.random.default_rng(5)
+    s, c, s2, c2 = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    bad_sc = bad_at = 0
+    n = 20000
+    for _ in range(n):
+        y, x = rng.normal() * 10 ** rng.uniform(-3, 3), rng.normal() * 10 ** rng.uniform(-3, 3)
+        a = lib.oracle_atan2_cr(C.c_double(y), C.c_double(x))
+        bad_at += a != math.atan2(y, x)
+        for flip in (0, 1):
+            th = lib.oracle_r2r_angle(C.c_double(y), C.c_double(x), flip, C.byref(s), C.byref(c))
+            assert th == (a + math.pi if flip else a)
+            lib.oracle_sincos_cr(C.c_double(th), C.byref(s2), C.byref(c2))
+            assert s.value == s2.value and c.value == c2.value, (y, x, flip)
+        bad_sc += (s2.value != math.sin(th)) + (c2.value != math.cos(th))
+    assert bad_at <= n // 500 and bad_sc <= n // 100          # glibc itself misrounds ~0.1 % of sin / cos
