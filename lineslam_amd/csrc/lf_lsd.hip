@@ -359,27 +359,34 @@ __device__ int d_region_grow(const FV &f, int sx, int sy, double prec, double co
     int lastL = -1;
     bool need_exact = !fast;
     if (fast) {
+      // candidate lanes still to be decided, as a scalar mask; every lane keeps its own (cc, ss, ca)
+      u64 pendm = __ballot(cand);
+      double thr_hi = cp2 * S2 + 1e-12 * S2, thr_lo = cp2 * S2 - 1e-12 * S2;
       for (;;) {
-        bool pend = cand && lane > lastL;
         double dot = sumdx * cc + sumdy * ss;
-        double lhs = dot * dot, rhs = cp2 * S2, band = 1e-12 * S2;
-        bool yes = pend && dot > 0.0 && lhs > rhs + band;
-        bool no = !pend || !(dot > 0.0) || lhs < rhs - band;
-        if (__ballot(!yes && !no) != 0) { need_exact = true; break; }   // ambiguous lane: exact arithmetic below
-        u64 mask = __ballot(yes);
-        if (mask == 0) break;
+        double lhs = dot * dot;
+        const u64 posm = __builtin_amdgcn_ballot_w64(dot > 0.0) & pendm;
+        u64 ym = __builtin_amdgcn_ballot_w64(lhs > thr_hi) & posm;      // aligned for certain
+        u64 mm = __builtin_amdgcn_ballot_w64(!(lhs < thr_lo)) & posm;   // aligned or inside the 1e-12 band
+        if (mm != ym) { need_exact = true; break; }              // ambiguous lane: exact arithmetic below
+        if (ym == 0) break;
         if constexpr (FV::kMW) { if (size >= f.cap) { *f.overflow = 1; full = true; break; } }   // speculative list full: caller re-runs at the frontier
-        int L = __builtin_ctzll(mask);
+        int L = __builtin_ctzll(ym);
         double cL = rl64(cc, L), sL = rl64(ss, L);
-        if (ca == rl32(ca, L)) cand = false;   // the accepted pixel (also when reached through another parent)
+        // lanes up to L are decided; so is every lane that holds the accepted pixel (reached through another parent)
+        pendm &= ~((2ull << L) - 1ull) & ~__builtin_amdgcn_ballot_w64(ca == rl32(ca, L));
         cmask |= 1ull << L;
         size++;
         sumdx += cL;
         sumdy += sL;
+        asm volatile("" : "+v"(sumdx), "+v"(sumdy));   // keep the running sums in vector registers (no SGPR round trip)
         S2 = sumdx * sumdx + sumdy * sumdy;
+        thr_hi = cp2 * S2 + 1e-12 * S2;
+        thr_lo = cp2 * S2 - 1e-12 * S2;
         angle_valid = false;
         lastL = L;
       }
+      cand = cand && ((pendm >> lane) & 1ull);   // (for the exact path below: lanes already decided stay decided)
     }
     if (need_exact && !full) {   // the reference's own arithmetic for the rest of the window
       double a_exact = cand ? f.angles[ca] : LF_NOTDEF;
