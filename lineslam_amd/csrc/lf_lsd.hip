@@ -916,17 +916,27 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
 #endif
   int ls_count = 0;
   int s = 0;
+  // seeds are taken 64 at a time: the window's addresses are loaded once, only `used` is looked at again after
+  // every region (a region may have swallowed later seeds of the window)
+  int wbase = -64, wlast = 63;
+  uint32_t addr = 0u;
+  bool v = false;
   while (s < nseeds) {
     PROF(6);
-    int idx = s + lane;
-    bool v = idx < nseeds;
-    uint32_t addr = v ? seeds[idx] : 0u;
-    bool isfree = v && f.used[addr] == 0;      // angles != NOTDEF holds for every listed pixel
+    if (wlast >= 63) {            // next window
+      wbase += 64; wlast = -1;
+      s = wbase;
+      if (s >= nseeds) break;
+      int idx = s + lane;
+      v = idx < nseeds;
+      addr = v ? seeds[idx] : 0u;
+    }
+    bool isfree = v && lane > wlast && f.used[addr] == 0;      // angles != NOTDEF holds for every listed pixel
     u64 m = __ballot(isfree);
-    if (m == 0) { s += 64; continue; }
+    if (m == 0) { wlast = 63; continue; }
     int L = __builtin_ctzll(m);
     int sa = rl32((int)addr, L);
-    s += L + 1;
+    wlast = L;
     int sx = sa % c.N, sy = sa / c.N;
     double reg_angle;
     ++n_grow;
