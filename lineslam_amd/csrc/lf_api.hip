@@ -293,8 +293,7 @@ static int alloc_lsd(lf_ctx *c) {
   ALLOC(c, b.scaled, B * NM);
   ALLOC(c, b.angles, B * NM);
   ALLOC(c, b.modgrad, B * NM);
-  ALLOC(c, b.cosang, B * NM);
-  ALLOC(c, b.sinang, B * NM);
+  ALLOC(c, b.cossin, B * NM * 2);
   ALLOC(c, b.bins, B * NM);
   int nch = (lc.N - 1 + LF_SORT_CHUNK_COLS - 1) / LF_SORT_CHUNK_COLS;
   ALLOC(c, b.cnt, B * nch * 1024);

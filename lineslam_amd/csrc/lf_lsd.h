@@ -54,7 +54,7 @@ struct LsdBuffers {
   double *scaled;        // [B][M][N]
   double *angles;        // [B][M][N]
   double *modgrad;       // [B][M][N]
-  double *cosang, *sinang; // [B][M][N] cos / sin of the level-line angle (cos = 2 marks NOTDEF)
+  double *cossin;        // [B][M][N][2] (cos, sin) of the level-line angle, interleaved: one 16-byte gather per pixel (cos = 2 marks NOTDEF)
   uint16_t *bins;        // [B][M][N]
   uint32_t *cnt;         // [B][nchunks][n_bins]
   uint32_t *seeds;       // [B][M*N]   pixel address y*N+x in reference list order

@@ -30,6 +30,7 @@
 #include <float.h>
 
 typedef unsigned long long u64;
+typedef double lf_d2 __attribute__((ext_vector_type(2)));
 
 // ----------------------------------------------------------------------------------------------
 // small wave-level helpers (wave = 64 lanes on gfx950)
@@ -116,8 +117,7 @@ __global__ void __launch_bounds__(256) k_ll_angle(LsdConsts c, LsdBuffers b) {
   }
   b.angles[f * NM + adr] = ang;
   b.modgrad[f * NM + adr] = norm;
-  b.cosang[f * NM + adr] = ca;
-  b.sinang[f * NM + adr] = sa;
+  *(lf_d2 *)&b.cossin[2 * (f * NM + adr)] = (lf_d2){ca, sa};
   b.bins[f * NM + adr] = bin;
 }
 
@@ -234,7 +234,7 @@ template <bool MW_>
 struct FrameViewT {
   static constexpr bool kMW = MW_;
   int N, M, lane;
-  const double *angles, *modgrad, *lgam, *cosang, *sinang;
+  const double *angles, *modgrad, *lgam, *cossin;
   const double *nfa_tab;  // tabulated nfa() for small n (null: always evaluate)
   const LsdConsts *dc;
   uint8_t *used;          // committed `used` mask of the frame
@@ -321,7 +321,7 @@ __device__ int d_region_grow(const FV &f, int sx, int sy, double prec, double co
   const bool fast = (prec > 1e-6 && prec < 1.5);
   const double cp2 = cos_prec * cos_prec;
   double reg_angle = f.angles[seed];
-  double sumdx = f.cosang[seed], sumdy = f.sinang[seed];
+  double sumdx = f.cossin[2 * seed], sumdy = f.cossin[2 * seed + 1];
   double S2 = sumdx * sumdx + sumdy * sumdy;
   bool angle_valid = true;     // reg_angle == atan2(sumdy, sumdx) of the current sums
   if (lane == 0) { uint32_t pk = (uint32_t)sx | ((uint32_t)sy << 16); f.reg[0] = pk; ring[0] = pk; fv_mark(f, seed); }
@@ -342,7 +342,8 @@ __device__ int d_region_grow(const FV &f, int sx, int sy, double prec, double co
     bool inb = act && cx >= 0 && cy >= 0 && cx < N && cy < M;
     int ca = inb ? cy * N + cx : 0;
     bool u = fv_is_used(f, ca);            // the gathers are issued together
-    double cc = f.cosang[ca], ss = f.sinang[ca];
+    const lf_d2 csv = *(const lf_d2 *)&f.cossin[2 * ca];
+    double cc = csv.x, ss = csv.y;
     bool cand = inb && !u && (cc <= 1.5);   // cos == 2 marks NOTDEF
 #ifdef LF_SWEEP_PROFILE
     u64 tp0 = __builtin_amdgcn_s_memtime();
@@ -429,7 +430,6 @@ __device__ int d_region_grow(const FV &f, int sx, int sy, double prec, double co
 // j = 0 .. cnt-1, where lane j holds (a_j, b_j, c_j).  The lanes publish their operands in LDS and every lane adds
 // them one by one (broadcast reads, four pixels per trip with the loads issued first) -- 5 instructions per pixel
 // instead of 6 readlanes + 3 additions.
-typedef double lf_d2 __attribute__((ext_vector_type(2)));
 template <bool SUBC, class FV>
 __device__ __forceinline__ void d_ordered_sum3(const FV &f, double a, double b, double c, int cnt, double &sa, double &sb,
                                                double &sc) {
@@ -884,8 +884,7 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
   f.N = c.N; f.M = c.M; f.lane = lane;
   f.angles = b.angles + fidx * NM;
   f.modgrad = b.modgrad + fidx * NM;
-  f.cosang = b.cosang + fidx * NM;
-  f.sinang = b.sinang + fidx * NM;
+  f.cossin = b.cossin + 2 * fidx * NM;
   f.lgam = b.lgam;
   f.nfa_tab = b.nfa_tab;
   f.dc = dc;
@@ -1050,8 +1049,7 @@ __global__ void __launch_bounds__(W * 64) k_lsd_sweep_mw(LsdConsts c, const LsdC
   f.N = c.N; f.M = c.M; f.lane = lane;
   f.angles = b.angles + fidx * NM;
   f.modgrad = b.modgrad + fidx * NM;
-  f.cosang = b.cosang + fidx * NM;
-  f.sinang = b.sinang + fidx * NM;
+  f.cossin = b.cossin + 2 * fidx * NM;
   f.lgam = b.lgam;
   f.nfa_tab = b.nfa_tab;
   f.dc = dc;
