@@ -243,6 +243,7 @@ struct FrameViewT {
   int cap;
   uint32_t *ring;         // LDS ring of the most recent region pixels (per wavefront)
   double *sums;           // LDS, 64 x 4 doubles per wavefront: operands of the order-dependent sums
+  int *ring_ok;           // LDS flag: the ring holds the WHOLE current list (the last growth ended with <= LF_RING pixels)
   uint32_t *ever;         // multi-wave sweep: every pixel this region ever accepted (for validation)
   int ever_cap;
   int *n_ever, *overflow; // (wave-uniform values kept in memory visible to the helpers)
@@ -260,6 +261,14 @@ template <class FV> __device__ __forceinline__ bool fv_is_used(const FV &f, int 
 }
 template <class FV> __device__ __forceinline__ void fv_mark(const FV &f, int p) { if constexpr (FV::kMW) f.tag[p] = 1; else f.used[p] = 1; }
 template <class FV> __device__ __forceinline__ void fv_unmark(const FV &f, int p) { if constexpr (FV::kMW) f.tag[p] = 0; else f.used[p] = 0; }
+
+// Entry i of the current region list (n entries): the LDS ring holds the most recent LF_RING entries at [i mod LF_RING],
+// i.e. the WHOLE list whenever n <= LF_RING -- nearly always -- so the passes over the list do not go to memory.
+#define LF_RING 1024   // most recent region pixels kept in LDS (the growth front reads them back)
+template <class FV> __device__ __forceinline__ uint32_t fv_reg(const FV &f, int i, int n) {
+  (void)n;
+  return *f.ring_ok ? f.ring[i] : f.reg[i];
+}
 
 // lsd.cpp:147-165
 __device__ __forceinline__ bool d_double_equal(double a, double b) {
@@ -301,7 +310,6 @@ __device__ __forceinline__ double d_angle_diff(double a, double b) {          //
 // a final "no"; the first hit is committed (used, reg[], sums, reg_angle) and the slots behind it are
 // re-tested against the new sums, and so on until the window is exhausted -- exactly the sequential
 // semantics, with one memory round trip per 64 slots.
-#define LF_RING 1024   // most recent region pixels kept in LDS (the growth front reads them back)
 // Alignment test of region_grow without atan2 on the critical path.  The reference decides
 //   | atan2(sumdy, sumdx) - a | (wrapped, lsd.cpp:799-832) < prec.
 // For 0 < prec < pi/2 that is  cos(angle between (sumdx,sumdy) and (cos a, sin a)) > cos(prec), i.e.
@@ -423,6 +431,8 @@ __device__ int d_region_grow(const FV &f, int sx, int sy, double prec, double co
   }
   if (!angle_valid) reg_angle = lf_atan2(sumdy, sumdx);   // value after the last accepted pixel (lsd.cpp:1654)
   *reg_angle_io = reg_angle;
+  if (lane == 0) *f.ring_ok = (size <= LF_RING) ? 1 : 0;   // (a list that shrinks later stays complete: fills are mirrored)
+  wave_mem_order();
   return size;
 }
 
@@ -465,7 +475,7 @@ __device__ void d_region2rect(const FV &f, int n, double reg_angle, double prec,
   for (int base = 0; base < n; base += 64) {
     int i = base + lane;
     bool v = i < n;
-    uint32_t pk = v ? f.reg[i] : 0u;
+    uint32_t pk = v ? fv_reg(f, i, n) : 0u;
     int rx = (int)(pk & 0xffffu), ry = (int)(pk >> 16);
     double w = v ? f.modgrad[ry * N + rx] : 0.0;
     double xw = (double)rx * w, yw = (double)ry * w;
@@ -477,7 +487,7 @@ __device__ void d_region2rect(const FV &f, int n, double reg_angle, double prec,
   for (int base = 0; base < n; base += 64) {
     int i = base + lane;
     bool v = i < n;
-    uint32_t pk = v ? f.reg[i] : 0u;
+    uint32_t pk = v ? fv_reg(f, i, n) : 0u;
     int rx = (int)(pk & 0xffffu), ry = (int)(pk >> 16);
     double w = v ? f.modgrad[ry * N + rx] : 0.0;
     double ey = (double)ry - y, ex = (double)rx - x;
@@ -501,7 +511,7 @@ __device__ void d_region2rect(const FV &f, int n, double reg_angle, double prec,
   for (int base = 0; base < n; base += 64) {
     int i = base + lane;
     if (i < n) {
-      uint32_t pk = f.reg[i];
+      uint32_t pk = fv_reg(f, i, n);
       double ex = (double)(int)(pk & 0xffffu) - x, ey = (double)(int)(pk >> 16) - y;
       double l = ex * dx + ey * dy;
       double w = -ex * dy + ey * dx;
@@ -773,7 +783,7 @@ __device__ bool d_reduce_region_radius(const FV &f, int *reg_size, double reg_an
   int size = *reg_size;
   double density = (double)size / (d_dist(rec->x1, rec->y1, rec->x2, rec->y2) * rec->width);
   if (density >= density_th) return true;
-  uint32_t pk0 = f.reg[0];
+  uint32_t pk0 = fv_reg(f, 0, size);
   double xc = (double)(int)(pk0 & 0xffffu), yc = (double)(int)(pk0 >> 16);
   double rad1 = d_dist(xc, yc, rec->x1, rec->y1);
   double rad2 = d_dist(xc, yc, rec->x2, rec->y2);
@@ -784,7 +794,7 @@ __device__ bool d_reduce_region_radius(const FV &f, int *reg_size, double reg_an
     for (int base = 0; base < size; base += 64) {
       int i = base + lane;
       bool v = i < size;
-      uint32_t pk = v ? f.reg[i] : 0u;
+      uint32_t pk = v ? fv_reg(f, i, size) : 0u;
       bool keep = v && !(d_dist(xc, yc, (double)(int)(pk & 0xffffu), (double)(int)(pk >> 16)) > rad);
       nkeep += __popcll(__ballot(keep));
     }
@@ -792,7 +802,7 @@ __device__ bool d_reduce_region_radius(const FV &f, int *reg_size, double reg_an
     for (int base = 0; base < size; base += 64) {
       int i = base + lane;
       bool v = i < size;
-      uint32_t pk = v ? f.reg[i] : 0u;
+      uint32_t pk = v ? fv_reg(f, i, size) : 0u;
       int rx = (int)(pk & 0xffffu), ry = (int)(pk >> 16);
       bool far = v && (d_dist(xc, yc, (double)rx, (double)ry) > rad);
       if (far) fv_unmark(f, ry * N + rx);
@@ -808,7 +818,7 @@ __device__ bool d_reduce_region_radius(const FV &f, int *reg_size, double reg_an
     // hole j (ascending position) <- fillers from the end: filler k (ascending) sits at tmp[NM-1-k]
     for (int base = 0; base < nh; base += 64) {
       int j = base + lane;
-      if (j < nh) f.reg[f.tmp[j]] = f.tmp[NM - nf + j];
+      if (j < nh) { uint32_t at = f.tmp[j], fl = f.tmp[NM - nf + j]; f.reg[at] = fl; if (*f.ring_ok) f.ring[at] = fl; }
     }
     wave_mem_order();
     size = nkeep;
@@ -828,7 +838,7 @@ __device__ bool d_refine(const FV &f, int *reg_size, double reg_angle, double pr
   int size = *reg_size;
   double density = (double)size / (d_dist(rec->x1, rec->y1, rec->x2, rec->y2) * rec->width);
   if (density >= density_th) return true;
-  uint32_t pk0 = f.reg[0];
+  uint32_t pk0 = fv_reg(f, 0, size);
   int sx = (int)(pk0 & 0xffffu), sy = (int)(pk0 >> 16);
   double xc = (double)sx, yc = (double)sy;
   double ang_c = f.angles[sy * N + sx];
@@ -837,7 +847,7 @@ __device__ bool d_refine(const FV &f, int *reg_size, double reg_angle, double pr
   for (int base = 0; base < size; base += 64) {
     int i = base + lane;
     bool v = i < size;
-    uint32_t pk = v ? f.reg[i] : 0u;
+    uint32_t pk = v ? fv_reg(f, i, size) : 0u;
     int rx = (int)(pk & 0xffffu), ry = (int)(pk >> 16);
     if (v) fv_unmark(f, ry * N + rx);
     if constexpr (FV::kMW) { if (v && f.ever) { if (i < f.ever_cap) f.ever[i] = pk; } }   // first growth, kept for validation
@@ -890,7 +900,9 @@ __global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *
   f.dc = dc;
   __shared__ uint32_t ring1[LF_RING];
   __shared__ double sums1[64 * 4];
+  __shared__ int ring_ok1;
   f.sums = sums1;
+  f.ring_ok = &ring_ok1;
   f.used = b.used + fidx * NM;
   f.tag = nullptr;
   f.reg = b.reg + fidx * NM;
@@ -1036,6 +1048,7 @@ __global__ void __launch_bounds__(W * 64) k_lsd_sweep_mw(LsdConsts c, const LsdC
   __shared__ SweepCtl ctl;
   __shared__ uint32_t rings[W][LF_RING];
   __shared__ double sums_w[W][64 * 4];
+  __shared__ int ring_ok_w[W];
   __shared__ int s_never[W], s_over[W];
   const int fidx = blockIdx.x, lane = lane_id(), wave = (int)(threadIdx.x >> 6);
   const size_t NM = (size_t)c.N * c.M;
@@ -1059,6 +1072,7 @@ __global__ void __launch_bounds__(W * 64) k_lsd_sweep_mw(LsdConsts c, const LsdC
   uint32_t *tmp_small = reg_small + LF_MW_CAP;
   f.ring = rings[wave];
   f.sums = sums_w[wave];
+  f.ring_ok = &ring_ok_w[wave];
   f.ever = reg_small + 2 * LF_MW_CAP;
   f.ever_cap = 2 * LF_MW_CAP;
   f.n_ever = &s_never[wave];
