@@ -81,9 +81,10 @@ def cpu_baseline(gray, depth, P, n_frames):
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         recs = list(ex.map(front, range(n)))
-        list(ex.map(lambda k: pair(k, recs), range(1, n)))
+        poses_cpu = list(ex.map(lambda k: pair(k, recs), range(1, n)))
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+    cpu_baseline.pairs = [(bool(p[0]), np.asarray(p[1], np.float64)) for p in poses_cpu]   # (valid, T newer->older)
+    return {"value": n / dt, "unit": "frames/s", "cores": cores, "value_per_core": n / dt / cores, "kind": "port",
             "sample": "%d frames of the same sequence (LSD+3D lines+MSLD+MLE, match+pose vs predecessor), "
                       "oracle/*.c libm flavour, %d threads over frames, %.1f s wall" % (n, cores, dt)}
 
@@ -225,7 +226,7 @@ def main():
         algo = ALGO_BYTES_PER_FRAME * F
         achieved = algo / (sw * 1e-3) / 1e9
         out = {
-            "metric": "RGB-D frames/sec (detect+match+pose) at 640x480", "value": value, "unit": "frames/s",
+            "metric": "RGB-D frames/sec (detect+match+pose) at 640\u00d7480; ATE vs reference", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "TUM fr3/cabinet-length sequence (%d frames, 640x480), lines-only odometry: "
@@ -252,6 +253,13 @@ def main():
             ncpu = a.cpu_frames or max(16, min(F, 6 * (os.cpu_count() or 1)))
             out["cpu_baseline"] = cpu_baseline(gray, depth, P, ncpu)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            # ATE of the GPU odometry chain against the CPU path's chain over the sampled frames (the CPU side uses
+            # libm, the GPU lf_math.h: the poses agree to float rounding, not bit for bit)
+            cp = cpu_baseline.pairs
+            est_c = ate.chain_odometry([t for _, t in cp], [v for v, _ in cp])
+            est_g = ate.chain_odometry(Ts[:len(cp)], valid[:len(cp)])
+            out["quality"]["ate_rmse_m_vs_cpu_reference_port"] = ate.ate_rmse(est_g[:, :3, 3], est_c[:, :3, 3])
+            out["quality"]["pairs_with_identical_validity_vs_cpu"] = int(sum(bool(a) == b for a, (b, _) in zip(valid[:len(cp)], cp)))
     for c in ctxs:
         c.close()
     if dist_on:
