@@ -477,15 +477,19 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
 // Supporting points live in LDS (one or two per lane); residuals and Jacobian rows are evaluated
 // lane-parallel; J^T J / J^T e use one accumulator per lane walking the rows in levmar's order.
 #define MLE_N 104
-#define MLE_ROW_DOUBLES 19   // LDS doubles per support point: pos 3, DU 9, Jacobian row 6, e 1
+#define MLE_ROW_DOUBLES 20   // LDS doubles per support point: pos 3, DU 9, Jacobian row 6, e 1, scratch 1
+#define MLE_ACC_DOUBLES 28   // + per group: the 27 accumulators of J^T J / J^T e, published for the whole group
 struct MState {   // views into the group's LDS block, sized for the kernel variant's row capacity
   double *pos;    // [rows][3]
   double *DU;     // [rows][9]
   double *jac;    // [rows][6]
   double *e;      // [rows]
+  double *scr;    // [rows] operands of row-ordered sums (two-lines-per-wavefront variant)
+  double *accs;   // [MLE_ACC_DOUBLES]
 };
 __device__ __forceinline__ void f_mstate_bind(MState &S, double *lds, int rows) {
   S.pos = lds; S.DU = S.pos + rows * 3; S.jac = S.DU + rows * 9; S.e = S.jac + rows * 6;
+  S.scr = S.e + rows; S.accs = S.scr + rows;
 }
 
 // ---- lane groups.  A 3D line with n support points is handled by a GROUP of G lanes: G = 64 (one line per
@@ -547,14 +551,27 @@ __device__ __forceinline__ void f_mle_cost(const MState &S, const MleGroup &g, i
 }
 // sum of v[i]^2 over the rows i = 0..n-1 in that order (row i lives in group lane i % G, slot i / G)
 template <int G, int RW>
-__device__ __forceinline__ double f_ordered_sumsq(const double *v, const MleGroup &g, int n) {
+__device__ __forceinline__ double f_ordered_sumsq(const MState &S, const double *v, const MleGroup &g, int n) {
   double s = 0.0;
+  if constexpr (G == 64) {   // one line per wavefront: readlane with a scalar lane index
 #pragma unroll
-  for (int h = 0; h < MleCfgT<G, RW>::SLOTS; h++) {
-    double sq = v[h] * v[h];
-    int cnt = n - G * h;
-    if (cnt > G) cnt = G;
-    for (int l = 0; l < cnt; l++) s += g_get<G>(sq, g, l);
+    for (int h = 0; h < MleCfgT<G, RW>::SLOTS; h++) {
+      double sq = v[h] * v[h];
+      int cnt = n - G * h;
+      if (cnt > G) cnt = G;
+      for (int l = 0; l < cnt; l++) s += g_get<G>(sq, g, l);
+    }
+  } else {                   // several lines per wavefront: the squares are published in LDS, every lane adds them in row order
+#pragma unroll
+    for (int h = 0; h < MleCfgT<G, RW>::SLOTS; h++) { int i = g.glane + G * h; if (i < n) S.scr[i] = v[h] * v[h]; }
+    g_order<G>();
+    int l = 0;
+    for (; l + 4 <= n; l += 4) {
+      double q0 = S.scr[l], q1 = S.scr[l + 1], q2 = S.scr[l + 2], q3 = S.scr[l + 3];
+      s += q0; s += q1; s += q2; s += q3;
+    }
+    for (; l < n; l++) s += S.scr[l];
+    g_order<G>();
   }
   return s;
 }
@@ -597,7 +614,7 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
   f_mle_cost<G, RW>(S, g, n, e1, e2, ci1, ci2, p, hx);
 #pragma unroll
   for (int h = 0; h < SL; h++) { ev[h] = 0.0 - hx[h]; int i = lane + G * h; if (i < n) S.e[i] = ev[h]; }
-  p_eL2 = f_ordered_sumsq<G, RW>(ev, g, n);
+  p_eL2 = f_ordered_sumsq<G, RW>(S, ev, g, n);
   if (!(lf_fabs(p_eL2) <= DBL_MAX)) stop = 7;
   nu = 20;
   for (k = 0; k < itmax && !stop; ++k) {
@@ -647,16 +664,29 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
         }
       }
       MT(2);
+      if constexpr (G == 64) {
 #pragma unroll
-      for (int i = 0; i < 6; i++)
+        for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) {
-          const int a = i * (i + 1) / 2 + j;
-          double v = g_get<G>(acc[a / G], g, a % G);
-          jacTjac[i * m + j] = v; jacTjac[j * m + i] = v;
-        }
+          for (int j = 0; j <= i; j++) {
+            const int a = i * (i + 1) / 2 + j;
+            double v = g_get<G>(acc[a / G], g, a % G);
+            jacTjac[i * m + j] = v; jacTjac[j * m + i] = v;
+          }
 #pragma unroll
-      for (int i = 0; i < 6; i++) jacTe[i] = g_get<G>(acc[(21 + i) / G], g, (21 + i) % G);
+        for (int i = 0; i < 6; i++) jacTe[i] = g_get<G>(acc[(21 + i) / G], g, (21 + i) % G);
+      } else {   // the accumulator lanes publish their entries, every lane of the group reads all 27
+#pragma unroll
+        for (int q = 0; q < NACC; q++) { int a = lane + G * q; if (a < 27) S.accs[a] = acc[q]; }
+        g_order<G>();
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+          for (int j = 0; j <= i; j++) { double v = S.accs[i * (i + 1) / 2 + j]; jacTjac[i * m + j] = v; jacTjac[j * m + i] = v; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) jacTe[i] = S.accs[21 + i];
+        g_order<G>();
+      }
       p_L2 = jacTe_inf = 0.0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -698,7 +728,7 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
       MT(5);
 #pragma unroll
       for (int h = 0; h < SL; h++) wrk2[h] = 0.0 - wrk[h];
-      pDp_eL2 = f_ordered_sumsq<G, RW>(wrk2, g, n);
+      pDp_eL2 = f_ordered_sumsq<G, RW>(S, wrk2, g, n);
       MT(6);
       if (!(lf_fabs(pDp_eL2) <= DBL_MAX)) { stop = 7; break; }
       dF = p_eL2 - pDp_eL2;
@@ -761,7 +791,7 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
 template <int G, int RW, int WHICH>
 __global__ void __launch_bounds__(64, 2) k_mle(FrontConsts c, FrontBuffers b) {
   typedef MleCfgT<G, RW> Cfg;
-  __shared__ double lds_rows[Cfg::NG][Cfg::ROWS * MLE_ROW_DOUBLES];
+  __shared__ double lds_rows[Cfg::NG][Cfg::ROWS * MLE_ROW_DOUBLES + MLE_ACC_DOUBLES];
   const int f = blockIdx.y, wl = f_lane();
   MleGroup g;
   g.gbase = (wl / G) * G; g.glane = wl % G;
