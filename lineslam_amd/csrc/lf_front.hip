@@ -553,15 +553,8 @@ __device__ __forceinline__ void f_mle_cost(const MState &S, const MleGroup &g, i
 template <int G, int RW>
 __device__ __forceinline__ double f_ordered_sumsq(const MState &S, const double *v, const MleGroup &g, int n) {
   double s = 0.0;
-  if constexpr (G == 64) {   // one line per wavefront: readlane with a scalar lane index
-#pragma unroll
-    for (int h = 0; h < MleCfgT<G, RW>::SLOTS; h++) {
-      double sq = v[h] * v[h];
-      int cnt = n - G * h;
-      if (cnt > G) cnt = G;
-      for (int l = 0; l < cnt; l++) s += g_get<G>(sq, g, l);
-    }
-  } else {                   // several lines per wavefront: the squares are published in LDS, every lane adds them in row order
+  {                          // the squares are published in LDS, every lane adds them in row order (cheaper than
+                             // readlane / shuffle pairs also for one line per wavefront)
 #pragma unroll
     for (int h = 0; h < MleCfgT<G, RW>::SLOTS; h++) { int i = g.glane + G * h; if (i < n) S.scr[i] = v[h] * v[h]; }
     g_order<G>();
@@ -664,18 +657,7 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
         }
       }
       MT(2);
-      if constexpr (G == 64) {
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-          for (int j = 0; j <= i; j++) {
-            const int a = i * (i + 1) / 2 + j;
-            double v = g_get<G>(acc[a / G], g, a % G);
-            jacTjac[i * m + j] = v; jacTjac[j * m + i] = v;
-          }
-#pragma unroll
-        for (int i = 0; i < 6; i++) jacTe[i] = g_get<G>(acc[(21 + i) / G], g, (21 + i) % G);
-      } else {   // the accumulator lanes publish their entries, every lane of the group reads all 27
+      {   // the accumulator lanes publish their entries, every lane of the group reads all 27
 #pragma unroll
         for (int q = 0; q < NACC; q++) { int a = lane + G * q; if (a < 27) S.accs[a] = acc[q]; }
         g_order<G>();
