@@ -559,9 +559,12 @@ __device__ __forceinline__ double f_ordered_sumsq(const MState &S, const double 
     for (int h = 0; h < MleCfgT<G, RW>::SLOTS; h++) { int i = g.glane + G * h; if (i < n) S.scr[i] = v[h] * v[h]; }
     g_order<G>();
     int l = 0;
-    for (; l + 4 <= n; l += 4) {
-      double q0 = S.scr[l], q1 = S.scr[l + 1], q2 = S.scr[l + 2], q3 = S.scr[l + 3];
-      s += q0; s += q1; s += q2; s += q3;
+    for (; l + 8 <= n; l += 8) {   // eight loads in flight, the additions stay in row order
+      double q[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) q[k] = S.scr[l + k];
+#pragma unroll
+      for (int k = 0; k < 8; k++) s += q[k];
     }
     for (; l < n; l++) s += S.scr[l];
     g_order<G>();
@@ -641,13 +644,12 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
           const int strideB = (aj_ >= 0) ? m : 1;
           double s = 0.0;
           int l = n;
-          for (; l >= 4; l -= 4) {              // four rows per trip: loads first, additions in levmar's order
-            double a0 = S.jac[(l - 1) * m + ai_], a1 = S.jac[(l - 2) * m + ai_], a2 = S.jac[(l - 3) * m + ai_], a3 = S.jac[(l - 4) * m + ai_];
-            double b0 = colB[(l - 1) * strideB], b1 = colB[(l - 2) * strideB], b2 = colB[(l - 3) * strideB], b3 = colB[(l - 4) * strideB];
-            s += (aj_ >= 0) ? b0 * a0 : a0 * b0;
-            s += (aj_ >= 0) ? b1 * a1 : a1 * b1;
-            s += (aj_ >= 0) ? b2 * a2 : a2 * b2;
-            s += (aj_ >= 0) ? b3 * a3 : a3 * b3;
+          for (; l >= 8; l -= 8) {              // eight rows per trip: loads first, additions in levmar's order
+            double av[8], bv[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { av[k] = S.jac[(l - 1 - k) * m + ai_]; bv[k] = colB[(l - 1 - k) * strideB]; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) s += bv[k] * av[k];
           }
           for (; l-- > 0;) {
             double alpha = S.jac[l * m + ai_];
