@@ -27,7 +27,7 @@ if sw:
     js = {"frames": 1147, "kernel": k, "fetch_kb": tot["FETCH_SIZE"][k] / n, "write_kb": tot["WRITE_SIZE"].get(k, 0.0) / n,
           "hbm_bytes_per_launch": (tot["FETCH_SIZE"][k] + tot["WRITE_SIZE"].get(k, 0.0)) / n * 1024.0,
           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of one serial bench pass (--inflight 1), "
-                  "(FETCH+WRITE)*1024 per launch; the sweep's accesses are narrow 8-byte gathers, so the gfx950 x2 correction "
+                  "(FETCH+WRITE)*1024 per launch; the sweep's accesses are narrow 16-byte / 1-byte gathers, so the gfx950 x2 correction "
                   "for wide coalesced reads (MI355X_MICROARCH.md, HBM) is NOT applied (uncalibrated for this pattern)"}
     json.dump(js, open(os.path.join(d, tag + "_sweep_pmc.json"), "w"), indent=1)
 print(open(os.path.join(d, tag + "_pmc_fetch_write_by_kernel.csv")).read())
