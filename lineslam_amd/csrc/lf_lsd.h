@@ -55,7 +55,7 @@ struct LsdBuffers {
   double *angles;        // [B][M][N]
   double *modgrad;       // [B][M][N]
   double *cossin;        // [B][M][N][2] (cos, sin) of the level-line angle, interleaved: one 16-byte gather per pixel (cos = 2 marks NOTDEF)
-  uint16_t *bins;        // [B][M][N]
+  uint16_t *bins;        // [B][N][M]  gradient-magnitude bin of every pixel, TRANSPOSED (column-major walk of the seed sort)
   uint32_t *cnt;         // [B][nchunks][n_bins]
   uint32_t *seeds;       // [B][M*N]   pixel address y*N+x in reference list order
   int *nseeds;           // [B]

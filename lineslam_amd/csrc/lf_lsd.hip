@@ -91,34 +91,42 @@ __global__ void __launch_bounds__(256) k_gauss_y(LsdConsts c, LsdBuffers b) {
 }
 
 // ll_angle, gradient part (lsd.cpp:717-770).  One thread per pixel of the scaled image.
+// 32 x 8 pixel tile per block.  The magnitude bins are stored TRANSPOSED (bins[x][y]): the seed sort walks the image
+// column by column (x outer, y inner, lsd.cpp:723-724), so its reads become contiguous; the transpose goes through LDS.
 __global__ void __launch_bounds__(256) k_ll_angle(LsdConsts c, LsdBuffers b) {
-  int x = blockIdx.x * blockDim.x + threadIdx.x;
-  int y = blockIdx.y, f = blockIdx.z;
-  if (x >= c.N) return;
+  __shared__ uint16_t tile[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 8, f = blockIdx.z;
+  const int x = x0 + tx, y = y0 + ty;
   const size_t NM = (size_t)c.N * c.M;
-  const double *in = b.scaled + f * NM;
-  size_t adr = (size_t)y * c.N + x;
-  double ang = LF_NOTDEF, norm = 0.0, ca = 2.0, sa = 0.0;
   uint16_t bin = LF_BIN_NONE;
-  if (x < c.N - 1 && y < c.M - 1) {
-    double com1 = in[adr + c.N + 1] - in[adr];
-    double com2 = in[adr + 1] - in[adr + c.N];
-    double gx = com1 + com2;
-    double gy = com1 - com2;
-    double norm2 = gx * gx + gy * gy;
-    norm = lf_sqrt(norm2 / 4.0);
-    if (!(norm <= c.rho)) {
-      ang = lf_atan2(gx, -gy);
-      lf_sincos(ang, &sa, &ca);      // cos/sin of the stored angle, as region_grow evaluates them (lsd.cpp:1652-1653)
-      unsigned int i = (unsigned int)(norm * (double)c.n_bins / c.max_grad);
-      if (i >= (unsigned int)c.n_bins) i = (unsigned int)c.n_bins - 1;
-      bin = (uint16_t)i;
+  if (x < c.N && y < c.M) {
+    const double *in = b.scaled + f * NM;
+    size_t adr = (size_t)y * c.N + x;
+    double ang = LF_NOTDEF, norm = 0.0, ca = 2.0, sa = 0.0;
+    if (x < c.N - 1 && y < c.M - 1) {
+      double com1 = in[adr + c.N + 1] - in[adr];
+      double com2 = in[adr + 1] - in[adr + c.N];
+      double gx = com1 + com2;
+      double gy = com1 - com2;
+      double norm2 = gx * gx + gy * gy;
+      norm = lf_sqrt(norm2 / 4.0);
+      if (!(norm <= c.rho)) {
+        ang = lf_atan2(gx, -gy);
+        lf_sincos(ang, &sa, &ca);      // cos/sin of the stored angle, as region_grow evaluates them (lsd.cpp:1652-1653)
+        unsigned int i = (unsigned int)(norm * (double)c.n_bins / c.max_grad);
+        if (i >= (unsigned int)c.n_bins) i = (unsigned int)c.n_bins - 1;
+        bin = (uint16_t)i;
+      }
     }
+    b.angles[f * NM + adr] = ang;
+    b.modgrad[f * NM + adr] = norm;
+    *(lf_d2 *)&b.cossin[2 * (f * NM + adr)] = (lf_d2){ca, sa};
   }
-  b.angles[f * NM + adr] = ang;
-  b.modgrad[f * NM + adr] = norm;
-  *(lf_d2 *)&b.cossin[2 * (f * NM + adr)] = (lf_d2){ca, sa};
-  b.bins[f * NM + adr] = bin;
+  tile[ty][tx] = bin;
+  __syncthreads();
+  const int cx = threadIdx.x >> 3, ry = threadIdx.x & 7;     // 8 consecutive rows of one column per 8 threads
+  if (x0 + cx < c.N && y0 + ry < c.M) b.bins[f * NM + (size_t)(x0 + cx) * c.M + (y0 + ry)] = tile[ry][cx];
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -141,7 +149,7 @@ __global__ void __launch_bounds__(256) k_seed_hist(LsdConsts c, LsdBuffers b) {
   int rows = c.M - 1;
   for (int t = threadIdx.x; t < ncol * rows; t += blockDim.x) {
     int x = x0 + t / rows, y = t % rows;
-    unsigned int bn = bins[(size_t)y * c.N + x];
+    unsigned int bn = bins[(size_t)x * c.M + y];
     if (bn != LF_BIN_NONE) atomicAdd(&hist[bn], 1u);
   }
   __syncthreads();
@@ -205,7 +213,7 @@ __global__ void __launch_bounds__(64) k_seed_scatter(LsdConsts c, LsdBuffers b) 
     int t = t0 + lane;
     bool v = t < total;
     int x = x0 + (v ? t / rows : 0), y = v ? t % rows : 0;
-    unsigned int bn = v ? bins[(size_t)y * c.N + x] : LF_BIN_NONE;
+    unsigned int bn = v ? bins[(size_t)x * c.M + y] : LF_BIN_NONE;
     bool pending = v && bn != LF_BIN_NONE;
     unsigned int pos = 0xFFFFFFFFu;
     u64 m;
@@ -1203,7 +1211,7 @@ void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int B, hipStream_t s
   if (b.ev_pre) (void)hipEventRecord(b.ev_pre, st);
   hipLaunchKernelGGL(k_gauss_x, dim3((c.N + 255) / 256, c.H, B), blk, 0, st, c, b);
   hipLaunchKernelGGL(k_gauss_y, dim3((c.N + 255) / 256, c.M, B), blk, 0, st, c, b);
-  hipLaunchKernelGGL(k_ll_angle, dim3((c.N + 255) / 256, c.M, B), blk, 0, st, c, b);
+  hipLaunchKernelGGL(k_ll_angle, dim3((c.N + 31) / 32, (c.M + 7) / 8, B), blk, 0, st, c, b);
   int nch = (c.N - 1 + LF_SORT_CHUNK_COLS - 1) / LF_SORT_CHUNK_COLS;
   size_t lds = sizeof(unsigned int) * (size_t)c.n_bins;
   hipLaunchKernelGGL(k_seed_hist, dim3(nch, B), blk, lds, st, c, b);
