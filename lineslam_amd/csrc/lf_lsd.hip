@@ -655,9 +655,16 @@ __device__ __forceinline__ double pick4(int i, double a0, double a1, double a2, 
 // column y = ceil(ys).. while y <= ye.  Only in-image pixels are counted by the reference, so both
 // ranges are clipped to the image before any int conversion.  Lanes take (column, row-phase) pairs;
 // the two counters are integers, so their reduction order is irrelevant.
-template <class FV>
-__device__ double d_rect_nfa(const FV &f, const Rect &r, double logNT, u64 *n_px) {
+// The two counters are taken with ballots (every pass of the row loop tests one pixel per lane), so they live in
+// scalar registers and need no wavefront reduction.  NP = 1: the rectangle's own precision.  NP = 5: the five HALVED
+// precisions p/2 .. p/32 of the "finer precision" loops of rect_improve, which look at the same pixels: one pass
+// over the rectangle serves all five.
+template <int NP, class FV>
+__device__ void d_rect_count(const FV &f, const Rect &r, int *pts_out, int *alg_out) {
   const int N = f.N, M = f.M, lane = f.lane;
+  double precs[NP];
+  if constexpr (NP == 1) precs[0] = r.prec;
+  else { double pk = r.p; for (int k = 0; k < NP; k++) { pk /= 2.0; precs[k] = pk * LF_PI; } }   // r.p /= 2; r.prec = r.p * M_PI (lsd.cpp:1677-1678)
   double hw = r.width / 2.0;
   double rx0 = r.x1 - r.dy * hw, ry0 = r.y1 + r.dx * hw;
   double rx1 = r.x2 - r.dy * hw, ry1 = r.y2 + r.dx * hw;
@@ -672,7 +679,9 @@ __device__ double d_rect_nfa(const FV &f, const Rect &r, double logNT, u64 *n_px
   double vx1 = pick4(offset + 1, rx0, rx1, rx2, rx3), vy1 = pick4(offset + 1, ry0, ry1, ry2, ry3);
   double vx2 = pick4(offset + 2, rx0, rx1, rx2, rx3), vy2 = pick4(offset + 2, ry0, ry1, ry2, ry3);
   double vx3 = pick4(offset + 3, rx0, rx1, rx2, rx3), vy3 = pick4(offset + 3, ry0, ry1, ry2, ry3);
-  int pts = 0, alg = 0;
+  int pts = 0, alg[NP];
+#pragma unroll
+  for (int k = 0; k < NP; k++) alg[k] = 0;
   double xlo_d = __builtin_ceil(vx0), xhi_d = __builtin_floor(vx2);
   if (xlo_d < 0.0) xlo_d = 0.0;
   if (xhi_d > (double)(N - 1)) xhi_d = (double)(N - 1);
@@ -685,8 +694,8 @@ __device__ double d_rect_nfa(const FV &f, const Rect &r, double logNT, u64 *n_px
     int col = lane & (cpp - 1), phase = lane / cpp;
     for (int cb = 0; cb < ncols; cb += cpp) {
       int ci = cb + col;
+      int x = xlo + ci, y = 0, yhi = -1;
       if (ci < ncols) {
-        int x = xlo + ci;
         double xd = (double)x, ys, ye;
         if (xd < vx3) ys = d_inter_low(xd, vx0, vy0, vx3, vy3);
         else ys = d_inter_low(xd, vx3, vy3, vx2, vy2);
@@ -695,20 +704,56 @@ __device__ double d_rect_nfa(const FV &f, const Rect &r, double logNT, u64 *n_px
         double ylo_d = __builtin_ceil(ys), yhi_d = __builtin_floor(ye);
         if (ylo_d < 0.0) ylo_d = 0.0;
         if (yhi_d > (double)(M - 1)) yhi_d = (double)(M - 1);
-        if (ylo_d <= yhi_d) {
-          int yhi = (int)yhi_d;
-          for (int y = (int)ylo_d + phase; y <= yhi; y += lpc) {
-            ++pts;
-            if (d_isaligned(f.angles[y * N + x], r.theta, r.prec)) ++alg;
+        if (ylo_d <= yhi_d) { yhi = (int)yhi_d; y = (int)ylo_d + phase; }
+      }
+      for (;;) {   // one pixel per lane and trip
+        const bool v = y <= yhi;
+        const u64 vm = __builtin_amdgcn_ballot_w64(v);
+        if (vm == 0) break;
+        pts += __popcll(vm);
+        double th = 1e300;
+        if (v) {
+          double a = f.angles[y * N + x];
+          if (a != LF_NOTDEF) {   // isaligned (lsd.cpp:799-832): one wrapped difference, NP thresholds
+            th = r.theta - a;
+            if (th < 0.0) th = -th;
+            if (th > LF_M_3_2_PI) { th -= LF_M_2__PI; if (th < 0.0) th = -th; }
           }
         }
+#pragma unroll
+        for (int k = 0; k < NP; k++) alg[k] += __popcll(__builtin_amdgcn_ballot_w64(th < precs[k]));
+        y += lpc;
       }
     }
   }
-  pts = wave_sum_i32(pts);
-  alg = wave_sum_i32(alg);
+  *pts_out = pts;
+#pragma unroll
+  for (int k = 0; k < NP; k++) alg_out[k] = alg[k];
+}
+template <class FV>
+__device__ double d_rect_nfa(const FV &f, const Rect &r, double logNT, u64 *n_px) {
+  int pts, alg;
+  d_rect_count<1>(f, r, &pts, &alg);
   *n_px += (u64)pts;
   return d_nfa(f, pts, alg, r.p, r.plev, logNT);
+}
+// rect_nfa of the five rectangles r with p/2, p/4 .. p/32 (same geometry): one counting pass, the nfa values of small
+// rectangles looked up by five lanes at once
+template <class FV>
+__device__ void d_rect_nfa_finer5(const FV &f, const Rect &r, double logNT, u64 *n_px, double *out) {
+  int pts, alg[5];
+  d_rect_count<5>(f, r, &pts, alg);
+  *n_px += 5ull * (u64)pts;
+  if (pts < LF_NFA_TAB_N && f.nfa_tab && pts > 0) {
+    const int k = f.lane < 5 ? f.lane : 4;
+    int a = k == 0 ? alg[0] : (k == 1 ? alg[1] : (k == 2 ? alg[2] : (k == 3 ? alg[3] : alg[4])));
+    double v = (a == 0) ? -logNT : f.nfa_tab[(size_t)(r.plev + 1 + k) * LF_NFA_TAB_TRI + (size_t)(pts * (pts + 1) / 2 + a)];
+#pragma unroll
+    for (int q = 0; q < 5; q++) out[q] = rl64(v, q);
+  } else {
+    double pk = r.p;
+    for (int q = 0; q < 5; q++) { pk /= 2.0; out[q] = d_nfa(f, pts, alg[q], pk, r.plev + 1 + q, logNT); }
+  }
 }
 
 // rect_improve (lsd.cpp:1662-1768)
@@ -722,12 +767,16 @@ __device__ double d_rect_improve(const FV &f, Rect *rec, double logNT, double ep
   log_nfa = d_rect_nfa(f, *rec, logNT, n_px);
   if (log_nfa > eps) return log_nfa;
   r = *rec;
-  for (int n = 0; n < 5; n++) {   // finer precisions
-    r.p /= 2.0; r.plev++;
-    r.prec = r.p * LF_PI;
-    ++*n_nfa;
-    log_nfa_new = d_rect_nfa(f, r, logNT, n_px);
-    if (log_nfa_new > log_nfa) { log_nfa = log_nfa_new; *rec = r; }
+  {
+    double lv[5];
+    d_rect_nfa_finer5(f, r, logNT, n_px, lv);
+    for (int n = 0; n < 5; n++) {   // finer precisions
+      r.p /= 2.0; r.plev++;
+      r.prec = r.p * LF_PI;
+      ++*n_nfa;
+      log_nfa_new = lv[n];
+      if (log_nfa_new > log_nfa) { log_nfa = log_nfa_new; *rec = r; }
+    }
   }
   if (log_nfa > eps) return log_nfa;
   r = *rec;
@@ -769,12 +818,16 @@ __device__ double d_rect_improve(const FV &f, Rect *rec, double logNT, double ep
   }
   if (log_nfa > eps) return log_nfa;
   r = *rec;
-  for (int n = 0; n < 5; n++) {   // even finer precisions
-    r.p /= 2.0; r.plev++;
-    r.prec = r.p * LF_PI;
-    ++*n_nfa;
-    log_nfa_new = d_rect_nfa(f, r, logNT, n_px);
-    if (log_nfa_new > log_nfa) { log_nfa = log_nfa_new; *rec = r; }
+  {
+    double lv[5];
+    d_rect_nfa_finer5(f, r, logNT, n_px, lv);
+    for (int n = 0; n < 5; n++) {   // even finer precisions
+      r.p /= 2.0; r.plev++;
+      r.prec = r.p * LF_PI;
+      ++*n_nfa;
+      log_nfa_new = lv[n];
+      if (log_nfa_new > log_nfa) { log_nfa = log_nfa_new; *rec = r; }
+    }
   }
   return log_nfa;
 }
