@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--inflight", type=int, default=2, help="passes in flight (contexts / HIP streams); 1 = serial")
+    ap.add_argument("--points", action="store_true",
+                    help="BASELINE configs[2] instead of configs[1]: fused point + line odometry -- projectTo3D, Hamming "
+                         "feature matching and the hybrid RANSAC / LM solver on synthetic key points (the ORB extractor "
+                         "is outside the accelerated path); not the headline workload")
     ap.add_argument("--default-params", action="store_true",
                     help="ParameterServer defaults (lsd_angle_thres 22.5, min_matches 20) instead of the shipped "
                          "launch/lineslam.launch values (40, 10), which are what the reference actually runs with")
@@ -129,6 +133,20 @@ def main():
     kf = np.linspace(0, F - 1, a.keyframes).astype(np.int64) if dist_on else None
     rec_bytes, line_cap = 1040, 512
 
+    pts_state = None
+    if a.points:
+        NK = 640
+        kp, desc = synth.keypoints(depth, poses, n_own=NK // 2, seed=2 + rank)
+        d_kp, d_desc = torch.from_numpy(kp).cuda(), torch.from_numpy(desc).cuda()
+        d_nkp = torch.full((F,), NK, dtype=torch.int32, device="cuda")
+        pts_state = []
+        for _ in range(nfl):
+            pts_state.append(dict(
+                pts=torch.zeros((F, NK, 4), dtype=torch.float32, device="cuda"), npts=torch.zeros(F, dtype=torch.int32, device="cuda"),
+                kept=torch.zeros((F, NK), dtype=torch.int32, device="cuda"),
+                mq=torch.zeros((F, NK), dtype=torch.int32, device="cuda"), mt=torch.zeros((F, NK), dtype=torch.int32, device="cuda"),
+                md=torch.zeros((F, NK), dtype=torch.float32, device="cuda"), nm=torch.zeros(F, dtype=torch.int32, device="cuda")))
+
     n_lc = 64   # loop-closure queries per step on every rank (config 4 style: local frames vs all keyframes)
     sel = torch.from_numpy(kf).cuda() if dist_on else None      # (device-resident: nothing in a step blocks the host)
     lc_q = np.full(n_lc, F - 1, np.int32)
@@ -141,7 +159,19 @@ def main():
 
     def step_on(ctx):
         ctx.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), F, K, ids)
-        ctx.match_pairs_device(pq, pt)
+        if a.points:
+            st = pts_state[ctxs.index(ctx)]
+            ctx.project_keypoints_device(dd.data_ptr(), F, d_kp.data_ptr(), d_nkp.data_ptr(), NK, K, st["pts"].data_ptr(),
+                                         st["npts"].data_ptr(), st["kept"].data_ptr(), max_keypoints=600)
+            # descriptors follow the surviving key points (device gather, stream-ordered)
+            dsel = torch.gather(d_desc, 1, st["kept"].long().clamp_(0, NK - 1).unsqueeze(-1).expand(-1, -1, 32)).contiguous()
+            st["dsel"] = dsel
+            ctx.feature_match_pairs_device(dsel.data_ptr(), st["npts"].data_ptr(), NK, pq, pt, st["mq"].data_ptr(),
+                                           st["mt"].data_ptr(), st["md"].data_ptr(), st["nm"].data_ptr())
+            ctx.match_pairs_hybrid_device_pm(pq, pt, st["pts"].data_ptr(), NK, st["mq"].data_ptr(), st["mt"].data_ptr(),
+                                             st["nm"].data_ptr(), NK, K)
+        else:
+            ctx.match_pairs_device(pq, pt)
         if dist_on:
             recs_t, nl_t, ids_t = views[id(ctx)]
             mine_r = recs_t[sel].contiguous()                                   # [kf, line_cap*1040] u8
@@ -205,13 +235,16 @@ def main():
     if rank == 0:
         # result quality on this rank's sequence: odometry chain vs ground truth.  With the exchange enabled the
         # pair slots hold the loop-closure results of the last step: run the odometry pairs once more (untimed).
-        if dist_on:
+        if dist_on and not a.points:
             ctx.match_pairs_device(pq, pt)
         res = [ctx.pair_result(i) for i in range(F - 1)]
         valid = np.array([r.valid for r in res], bool)
         Ts = [np.array(list(r.T), np.float64).reshape(4, 4) for r in res]
         est = ate.chain_odometry(Ts, valid)
         gt = np.linalg.inv(poses[0])[None] @ poses
+        point_stats = {"point_matches_per_pair": float(np.mean([r.n_point_matches for r in res])),
+                       "point_inliers_per_pair": float(np.mean([r.n_point_inliers for r in res])),
+                       "line_inliers_per_pair": float(np.mean([r.n_inliers for r in res]))} if a.points else None
         sw = float(np.mean(sweep_ms))
         nlines = int(np.mean([len(ctx.frame_lines(k)) for k in range(0, F, max(1, F // 16))]))
         traffic = None
@@ -229,7 +262,10 @@ def main():
             "metric": "RGB-D frames/sec (detect+match+pose) at 640\u00d7480; ATE vs reference", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "TUM fr3/cabinet-length sequence (%d frames, 640x480), lines-only odometry: "
+            "config": {"workload": ("fused point + line odometry (BASELINE configs[2]) on a %d-frame 640x480 sequence: front end as "
+                                    "below + projectTo3D, Hamming feature matching, hybrid RANSAC / LM; synthetic key points" % F)
+                       if a.points else
+                                   "TUM fr3/cabinet-length sequence (%d frames, 640x480), lines-only odometry: "
                                    "LSD + 3D line fit + MSLD + MLE per frame, line matching + 3-line RANSAC + LM "
                                    "pose vs predecessor; synthetic seeded RGB-D (lineslam_amd/synth.py)" % F,
                        "frames_per_gpu": F, "params": "ParameterServer defaults" if a.default_params else "launch/lineslam.launch (lsd_angle_thres 40, min_matches 10)",
@@ -245,21 +281,22 @@ def main():
                                  "the timed region, where it shares the chip with the other pass in flight; see DESIGN.md section 4"},
             "stage_ms": {"lsd_data_parallel": float(np.mean(pre_ms)), "lsd_sweep": sw,
                          "lines3d_msld_mle": float(np.mean(front_ms)), "match_pose": float(np.mean(pair_ms))},
-            "serial": serial,
+            "serial": serial, "points": point_stats,
             "quality": {"valid_pairs": int(valid.sum()), "pairs": int(len(valid)),
                         "ate_rmse_m_vs_ground_truth": ate.ate_rmse(est[:, :3, 3], gt[:, :3, 3])},
         }
         if not a.no_cpu:
             ncpu = a.cpu_frames or max(16, min(F, 6 * (os.cpu_count() or 1)))
-            out["cpu_baseline"] = cpu_baseline(gray, depth, P, ncpu)
+            out["cpu_baseline"] = cpu_baseline(gray, depth, P, ncpu)   # (lines-only CPU path, also next to --points)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
             # ATE of the GPU odometry chain against the CPU path's chain over the sampled frames (the CPU side uses
             # libm, the GPU lf_math.h: the poses agree to float rounding, not bit for bit)
-            cp = cpu_baseline.pairs
+            cp = cpu_baseline.pairs if not a.points else []
             est_c = ate.chain_odometry([t for _, t in cp], [v for v, _ in cp])
             est_g = ate.chain_odometry(Ts[:len(cp)], valid[:len(cp)])
-            out["quality"]["ate_rmse_m_vs_cpu_reference_port"] = ate.ate_rmse(est_g[:, :3, 3], est_c[:, :3, 3])
-            out["quality"]["pairs_with_identical_validity_vs_cpu"] = int(sum(bool(a) == b for a, (b, _) in zip(valid[:len(cp)], cp)))
+            if cp:
+                out["quality"]["ate_rmse_m_vs_cpu_reference_port"] = ate.ate_rmse(est_g[:, :3, 3], est_c[:, :3, 3])
+                out["quality"]["pairs_with_identical_validity_vs_cpu"] = int(sum(bool(x) == b for x, (b, _) in zip(valid[:len(cp)], cp)))
     for c in ctxs:
         c.close()
     if dist_on:

@@ -176,3 +176,37 @@ def sequence(n_frames, seed=0, fps=30.0, w=640, h=480, n_unique=None):
         di[rng.random(d.shape) < 0.05] = np.nan
         gray[i], depth[i], poses[i] = gi, di, T
     return gray, depth, poses
+
+
+def keypoints(depth, poses, n_own=320, seed=0, K=K_TUM):
+    """Synthetic stand-in for the ORB side of BASELINE config 3 (the extractor itself is outside the accelerated path):
+    every frame k owns n_own scene points (pixels with depth, back-projected); its key-point list is
+    [its own points] + [the points of frame k-1 seen from frame k], so consecutive frames share n_own landmarks.
+    Returns kp [F, 2*n_own, 2] float32 pixel coordinates, desc [F, 2*n_own, 32] uint8 (256-bit descriptors: one random
+    code per landmark, ~6 % of the bits flipped per observation)."""
+    F, h, w = depth.shape
+    rng = np.random.default_rng(seed * 104729 + 17)
+    kp = np.zeros((F, 2 * n_own, 2), np.float32)
+    desc = np.zeros((F, 2 * n_own, 32), np.uint8)
+    prev_w = prev_d = None
+    for k in range(F):
+        u, v = rng.uniform(30, w - 30, n_own), rng.uniform(30, h - 30, n_own)
+        z = depth[k][np.rint(v).astype(int), np.rint(u).astype(int)].astype(np.float64)
+        z = np.where(np.isfinite(z), z, 2.0)
+        Pc = np.c_[(u - K[0, 2]) * z / K[0, 0], (v - K[1, 2]) * z / K[1, 1], z, np.ones(n_own)]
+        Pw = (poses[k] @ Pc.T).T
+        code = rng.integers(0, 256, (n_own, 32), dtype=np.uint8)
+        kp[k, :n_own, 0], kp[k, :n_own, 1] = u, v
+        desc[k, :n_own] = code
+        if prev_w is not None:
+            pc = (np.linalg.inv(poses[k]) @ prev_w.T).T
+            zc = np.where(np.abs(pc[:, 2]) > 1e-6, pc[:, 2], 1e-6)
+            uv = np.c_[K[0, 0] * pc[:, 0] / zc + K[0, 2], K[1, 1] * pc[:, 1] / zc + K[1, 2]] + rng.normal(0, 0.2, (n_own, 2))
+            kp[k, n_own:] = uv
+            flip = rng.integers(0, 256, (n_own, 32), dtype=np.uint8) & rng.integers(0, 256, (n_own, 32), dtype=np.uint8) & \
+                rng.integers(0, 256, (n_own, 32), dtype=np.uint8) & rng.integers(0, 256, (n_own, 32), dtype=np.uint8)
+            desc[k, n_own:] = prev_d ^ flip
+        else:
+            kp[k, n_own:] = -10.0       # outside the image: dropped by projectTo3D
+        prev_w, prev_d = Pw, code
+    return kp, desc
