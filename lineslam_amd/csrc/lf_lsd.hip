@@ -529,10 +529,14 @@ __device__ void d_region2rect(const FV &f, int n, double reg_angle, double prec,
       if (w < w_min) w_min = w;
     }
   }
-  l_max = wave_max_f64(l_max);
-  l_min = wave_min_f64(l_min);
-  w_max = wave_max_f64(w_max);
-  w_min = wave_min_f64(w_min);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {   // the four reductions step together: one shuffle round trip per step, not four
+    double a = __shfl_xor(l_max, o, 64), b2 = __shfl_xor(l_min, o, 64), c2 = __shfl_xor(w_max, o, 64), d2 = __shfl_xor(w_min, o, 64);
+    l_max = a > l_max ? a : l_max;
+    l_min = b2 < l_min ? b2 : l_min;
+    w_max = c2 > w_max ? c2 : w_max;
+    w_min = d2 < w_min ? d2 : w_min;
+  }
   rec->x1 = x + l_min * dx;
   rec->y1 = y + l_min * dy;
   rec->x2 = x + l_max * dx;
