@@ -318,8 +318,7 @@ static int alloc_lsd(lf_ctx *c) {
   memset(&fb, 0, sizeof fb);
   fc.W = c->W; fc.H = c->H;
   fc.cand_cap = 1024; fc.line_cap = 512; fc.seg_cap = lc.seg_cap;
-  ALLOC(c, fb.gx, B * (size_t)c->W * c->H);
-  ALLOC(c, fb.gy, B * (size_t)c->W * c->H);
+  ALLOC(c, fb.gxy, B * (size_t)c->W * c->H * 2);
   ALLOC(c, c->d_frame_ids, B);
   ALLOC(c, fb.cand_flag, B * fc.cand_cap);
   ALLOC(c, fb.cand_out, B * (size_t)fc.cand_cap * LF_CAND_STRIDE);

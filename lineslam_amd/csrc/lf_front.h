@@ -23,7 +23,7 @@ struct FrontConsts {
 struct FrontBuffers {
   const uint8_t *gray;  size_t gray_frame_stride;  int gray_row_stride;     // bytes
   const float *depth;   size_t depth_frame_stride; int depth_row_stride;    // elements
-  int16_t *gx, *gy;          // [B][H][W] Sobel ksize 5 (exact integers, |v| <= 24480)
+  int16_t *gxy;              // [B][H][W][2] Sobel ksize 5 (gx, gy) interleaved: one 32-bit load per pixel (exact integers, |v| <= 24480)
   const double *segs;        // [B][seg_cap][5]   from the LSD stage
   const int *nsegs;          // [B]
   const uint64_t *frame_ids; // [B]  keys of the counter-based generator

@@ -60,8 +60,7 @@ __global__ void __launch_bounds__(256) k_sobel5(FrontConsts c, FrontBuffers b) {
     sy += kd[j] * rs;
   }
   size_t o = ((size_t)f * c.H + y) * c.W + x;
-  b.gx[o] = (int16_t)sx;
-  b.gy[o] = (int16_t)sy;
+  *(uint32_t *)&b.gxy[2 * o] = (uint32_t)(uint16_t)(int16_t)sx | ((uint32_t)(uint16_t)(int16_t)sy << 16);
 }
 
 // ------------------------------------------------------------------------------ point helpers
@@ -918,7 +917,7 @@ __global__ void __launch_bounds__(64) k_describe(FrontConsts c, FrontBuffers b) 
   if (nl > c.line_cap) nl = c.line_cap;
   if (li >= nl) return;
   lf_line_record *R = b.recs + (size_t)f * c.line_cap + li;
-  const int16_t *gx = b.gx + (size_t)f * c.W * c.H, *gy = b.gy + (size_t)f * c.W * c.H;
+  const uint32_t *gxy = (const uint32_t *)(b.gxy + (size_t)f * c.W * c.H * 2);   // (gx | gy << 16) per pixel
   const int W = c.W, H = c.H;
   const double p0 = R->p[0], p1 = R->p[1], q0 = R->q[0], q1 = R->q[1];
   // ---- FrameLine::getGradient (lineslam.cpp:527-537): cv::LineIterator(img, p, q, 8).  Pixel i of
@@ -941,8 +940,9 @@ __global__ void __launch_bounds__(64) k_describe(FrontConsts c, FrontBuffers b) 
         int k = (num > 0 && major > 0) ? (int)((num + 2ll * major - 1) / (2ll * major)) : 0;
         int x = (int)x1 + (steep ? sgx * k : sgx * i);
         int y = (int)y1 + (steep ? sgy * i : sgy * k);
-        sxs += gx[y * W + x];
-        sys_ += gy[y * W + x];
+        const uint32_t gv = gxy[y * W + x];
+        sxs += (int16_t)(gv & 0xffffu);
+        sys_ += (int16_t)(gv >> 16);
       }
     }
 #pragma unroll
@@ -980,7 +980,8 @@ __global__ void __launch_bounds__(64) k_describe(FrontConsts c, FrontBuffers b) 
         double v1 = 0, v2 = 0, v3 = 0, v4 = 0;
         for (int y = (int)tl_y; y < tl_y + sd; ++y)
           for (int x = (int)tl_x; x < tl_x + sd; ++x) {
-            double xg = (double)gx[y * W + x], yg = (double)gy[y * W + x];
+            const uint32_t gv = gxy[y * W + x];
+            double xg = (double)(int16_t)(gv & 0xffffu), yg = (double)(int16_t)(gv >> 16);
             double tmp1 = xg * r0 + yg * r1;
             double tmp2 = xg * (-r1) + yg * r0;
             if (tmp1 >= 0) v1 = v1 + tmp1; else v2 = v2 - tmp1;
