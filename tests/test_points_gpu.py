@@ -127,3 +127,28 @@ def test_ingest_tum_on_device(built_lib):
     ctx.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), n, synth.K_TUM, np.arange(n, dtype=np.uint64))
     ctx.synchronize()
     ctx.close()
+
+
+def test_tum_folder_end_to_end(built_lib, tmp_path):
+    """tools/run_tum.py: raw TUM folder (PNG + syncidx.txt) -> device ingest -> odometry -> TUM trajectory -> ATE."""
+    import os
+    import sys
+    from lineslam_amd import tum
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import run_tum
+    n = 5
+    g, d, poses = synth.sequence(n, seed=31)
+    (tmp_path / "rgb").mkdir(); (tmp_path / "depth").mkdir()
+    ts = 1000.0 + np.arange(n) / 30.0
+    with open(tmp_path / "syncidx.txt", "w") as f:
+        for k in range(n):
+            tum.write_png(str(tmp_path / "rgb" / ("%d.png" % k)), np.repeat(g[k][..., None], 3, axis=2))    # grey as R = G = B
+            d16 = np.where(np.isfinite(d[k]), np.rint(d[k] * 5000.0), 0).astype(np.uint16)
+            tum.write_png(str(tmp_path / "depth" / ("%d.png" % k)), d16)
+            f.write("%.6f rgb/%d.png %.6f depth/%d.png\n" % (ts[k], k, ts[k] + 0.004, k))
+    gt = np.linalg.inv(poses[0])[None] @ poses
+    tum.write_poses(str(tmp_path / "groundtruth.txt"), ts + 0.002, gt)
+    est, have, lines, err = run_tum.run(str(tmp_path), str(tmp_path / "traj.txt"), str(tmp_path / "groundtruth.txt"))
+    assert have.all() and min(lines) > 50
+    assert err < 0.01                                             # metres, after rigid alignment
+    assert len(open(tmp_path / "traj.txt").read().strip().split("\n")) == n
