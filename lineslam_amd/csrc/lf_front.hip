@@ -836,36 +836,75 @@ __global__ void __launch_bounds__(64, 2) k_mle(FrontConsts c, FrontBuffers b) {
   }
   int stop = 0;
   int nit = f_levmar6<G, RW>(S, g, ns, e1, e2, ci1, ci2, para, P.line3d_mle_iter_num, &stop);
-  // ---- MleLine3dCov (utils.cpp:1138-1159): H = J^T J in point order, cov = H^-1
+  // ---- MleLine3dCov (utils.cpp:1138-1159): H = J^T J in point order, cov = H^-1.  Every lane forms the 3x6 Jacobian
+  // of its own rows, the rows are published in LDS (over pos / DU, which are dead by then), and 21 accumulator lanes
+  // walk them in the reference's order (point by point, residual row by row); H is symmetric term by term.
   double H[36], I6[36];
+  {
+    constexpr int SL = Cfg::SLOTS;
+    double J[SL][18];
 #pragma unroll
-  for (int i = 0; i < 36; i++) H[i] = 0;
-  for (int i = 0; i < ns; ++i) {
-    double J[18];
+    for (int h = 0; h < SL; h++) {
+      const int i = lane + G * h;
 #pragma unroll
-    for (int k = 0; k < 18; k++) J[k] = 0;
-    if (i == e1) {
+      for (int k = 0; k < 18; k++) J[h][k] = 0;
+      if (i < ns) {
+        if (i == e1) {
 #pragma unroll
-      for (int r = 0; r < 3; r++)
+          for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) J[r * 6 + k] = -S.DU[9 * i + 3 * r + k];
-    } else if (i == e2) {
+            for (int k = 0; k < 3; k++) J[h][r * 6 + k] = -S.DU[9 * i + 3 * r + k];
+        } else if (i == e2) {
 #pragma unroll
-      for (int r = 0; r < 3; r++)
+          for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) J[r * 6 + 3 + k] = -S.DU[9 * i + 3 * r + k];
-    } else
-      f_jac_line(&S.pos[3 * i], &S.DU[9 * i], para, J);
+            for (int k = 0; k < 3; k++) J[h][r * 6 + 3 + k] = -S.DU[9 * i + 3 * r + k];
+        } else
+          f_jac_line(&S.pos[3 * i], &S.DU[9 * i], para, J[h]);
+      }
+    }
+    g_order<G>();
+    double *Jl = S.pos;                       // [row][MLE_ROW_DOUBLES], 18 used
 #pragma unroll
-    for (int r = 0; r < 3; r++)
+    for (int h = 0; h < SL; h++) {
+      const int i = lane + G * h;
+      if (i < ns)
 #pragma unroll
-      for (int k = 0; k < 6; k++)
+        for (int k = 0; k < 18; k++) Jl[i * MLE_ROW_DOUBLES + k] = J[h][k];
+    }
+    g_order<G>();
+    constexpr int NA = (21 + G - 1) / G;      // lower-triangle entries per lane (1 for G >= 32)
 #pragma unroll
-        for (int l = 0; l < 6; l++) H[k * 6 + l] += J[r * 6 + k] * J[r * 6 + l];
+    for (int q = 0; q < NA; q++) {
+      const int a = lane + G * q;
+      if (a < 21) {
+        int hk = 0;
+        while ((hk + 1) * (hk + 2) / 2 <= a) hk++;
+        const int hl = a - hk * (hk + 1) / 2;
+        double acc = 0.0;
+        for (int i = 0; i < ns; ++i) {
+          const double *row = Jl + i * MLE_ROW_DOUBLES;
+          double a0 = row[hk], b0 = row[hl], a1 = row[6 + hk], b1 = row[6 + hl], a2 = row[12 + hk], b2 = row[12 + hl];
+          acc += a0 * b0;
+          acc += a1 * b1;
+          acc += a2 * b2;
+        }
+        S.accs[a] = acc;
+      }
+    }
+    g_order<G>();
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+#pragma unroll
+      for (int l = 0; l <= k; l++) { double v = S.accs[k * (k + 1) / 2 + l]; H[k * 6 + l] = v; H[l * 6 + k] = v; }
+    g_order<G>();
   }
 #pragma unroll
   for (int i = 0; i < 36; i++) I6[i] = (i % 7 == 0) ? 1.0 : 0.0;
-  if (!lf_solve6(H, I6, 6)) {
+  int inv_ok;
+  if constexpr (G == 64) inv_ok = lf_solve6_u(H, I6, 6);   // one line per wavefront: scalar pivot branches
+  else inv_ok = lf_solve6(H, I6, 6);
+  if (!inv_ok) {
 #pragma unroll
     for (int i = 0; i < 36; i++) I6[i] = lf_from_bits(0x7ff8000000000000ULL);
   }
