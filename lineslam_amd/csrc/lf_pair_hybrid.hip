@@ -227,7 +227,7 @@ __device__ void h_refine(const HCtx &pc, const int *pset, int np, const int *lse
         for (int i = 0; i < 36; i++) A[i] = S[i];
 #pragma unroll
         for (int i = 0; i < 6; i++) dp[i] = g[i];
-        ok2 = lf_solve6(A, dp, 1);
+        ok2 = lf_solve6_u(A, dp, 1);   // the pose system is the same in every lane: scalar pivot branches
       }
       tempChi = DBL_MAX;
       if (ok2) {
