@@ -557,15 +557,15 @@ __device__ __forceinline__ double f_ordered_sumsq(const MState &S, const double 
 #pragma unroll
     for (int h = 0; h < MleCfgT<G, RW>::SLOTS; h++) { int i = g.glane + G * h; if (i < n) S.scr[i] = v[h] * v[h]; }
     g_order<G>();
+    const int n8 = (n + 7) & ~7;   // rows n .. n8-1 of scr are zero (f_levmar6)
     int l = 0;
-    for (; l + 8 <= n; l += 8) {   // eight loads in flight, the additions stay in row order
+    for (; l + 8 <= n8; l += 8) {  // eight loads in flight, the additions stay in row order
       double q[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) q[k] = S.scr[l + k];
 #pragma unroll
       for (int k = 0; k < 8; k++) s += q[k];
     }
-    for (; l < n; l++) s += S.scr[l];
     g_order<G>();
   }
   return s;
@@ -606,6 +606,18 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
 #ifdef LF_MLE_PROFILE
   unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
+  // rows n .. n8-1 (n8 = n rounded up to 8) of jac / e / scr hold zeros: the row-ordered sums below then run in
+  // full groups of eight (adding +0.0 terms changes nothing)
+  const int n8 = (n + 7) & ~7;
+#pragma unroll
+  for (int h = 0; h < SL; h++) {
+    int i = lane + G * h;
+    if (i >= n && i < n8) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) S.jac[i * m + j] = 0.0;
+      S.e[i] = 0.0; S.scr[i] = 0.0;
+    }
+  }
   f_mle_cost<G, RW>(S, g, n, e1, e2, ci1, ci2, p, hx);
 #pragma unroll
   for (int h = 0; h < SL; h++) { ev[h] = 0.0 - hx[h]; int i = lane + G * h; if (i < n) S.e[i] = ev[h]; }
@@ -642,17 +654,13 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
           const double *colB = (aj_ >= 0) ? (S.jac + aj_) : S.e;   // second factor: J[l][aj] or e[l]
           const int strideB = (aj_ >= 0) ? m : 1;
           double s = 0.0;
-          int l = n;
+          int l = n8;                           // (the zero rows n .. n8-1 come first and leave s = 0)
           for (; l >= 8; l -= 8) {              // eight rows per trip: loads first, additions in levmar's order
             double av[8], bv[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) { av[k] = S.jac[(l - 1 - k) * m + ai_]; bv[k] = colB[(l - 1 - k) * strideB]; }
 #pragma unroll
             for (int k = 0; k < 8; k++) s += bv[k] * av[k];
-          }
-          for (; l-- > 0;) {
-            double alpha = S.jac[l * m + ai_];
-            s += (aj_ >= 0) ? S.jac[l * m + aj_] * alpha : alpha * S.e[l];
           }
           acc[q] = s;
         }
