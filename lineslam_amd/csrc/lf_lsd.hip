@@ -455,19 +455,16 @@ __device__ __forceinline__ void d_ordered_sum3(const FV &f, double a, double b, 
   *(lf_d2 *)&L[4 * f.lane] = (lf_d2){a, b};
   L[4 * f.lane + 2] = c;
   wave_mem_order();
-  int j = 0;
-  for (; j + 4 <= cnt; j += 4) {
-    lf_d2 p0 = *(const lf_d2 *)&L[4 * j], p1 = *(const lf_d2 *)&L[4 * j + 4], p2 = *(const lf_d2 *)&L[4 * j + 8], p3 = *(const lf_d2 *)&L[4 * j + 12];
-    double c0 = L[4 * j + 2], c1 = L[4 * j + 6], c2 = L[4 * j + 10], c3 = L[4 * j + 14];
-    sa += p0.x; sb += p0.y; sc = SUBC ? sc - c0 : sc + c0;
-    sa += p1.x; sb += p1.y; sc = SUBC ? sc - c1 : sc + c1;
-    sa += p2.x; sb += p2.y; sc = SUBC ? sc - c2 : sc + c2;
-    sa += p3.x; sb += p3.y; sc = SUBC ? sc - c3 : sc + c3;
-  }
-  for (; j < cnt; j++) {
-    lf_d2 p0 = *(const lf_d2 *)&L[4 * j];
-    double c0 = L[4 * j + 2];
-    sa += p0.x; sb += p0.y; sc = SUBC ? sc - c0 : sc + c0;
+  // lanes >= cnt published zeros (their pixel weight is 0), so the loop runs in full groups of eight: adding +0.0
+  // terms changes nothing and there is no tail
+  const int cnt8 = (cnt + 7) & ~7;
+  for (int j = 0; j < cnt8; j += 8) {
+    lf_d2 p[8];
+    double c8[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { p[k] = *(const lf_d2 *)&L[4 * (j + k)]; c8[k] = L[4 * (j + k) + 2]; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { sa += p[k].x; sb += p[k].y; sc = SUBC ? sc - c8[k] : sc + c8[k]; }
   }
   wave_mem_order();
 }
