@@ -126,15 +126,25 @@ __global__ void __launch_bounds__(256) k_match(PairConsts c, PairBuffers b) {
 }
 
 // ------------------------------------------------------------------------------ k_pose
+// ONE 256-THREAD WORKGROUP (four wavefronts) PER PAIR.  A match ("landmark" of the refinement graph) belongs to
+// thread i; sums over the matches are taken in list order from values published in LDS, so every thread holds
+// the same bits the sequential oracle computes.
+#define PT_N 256                   // threads per pair == LF_MAX_MATCHES
+#define PW_N (PT_N / 64)
 struct PoseShared {
   int idx[LF_MAX_MATCHES];
   unsigned char smp[LF_RANSAC_MAX_ITERS * 3];
   int set[LF_MAX_MATCHES];        // current inlier list (indices into the match list)
+  double red[2][LF_MAX_MATCHES + 8];   // per-match values of the ordered sums (zero padded to a multiple of 8)
+  double hb[42], sg[42];          // Hpp | bp of the current linearisation; S | g of the current damping
+  double tile[PW_N][10 * 108];    // per wavefront: the Jacobian columns (or W Vi) of the ten matches of a pass
+  double wred[PW_N];
+  int wcnt[PW_N], wit[PW_N], flag;
 };
 struct PoseCtx {
   const lf_line_record *train, *query;
   const int *mq, *mt;
-  double *wsB, *wsVi, *wsTU, *wsL, *wsLn;
+  double *wsB, *wsVi, *wsTU, *wsL, *wsLn, *wsJ;
   lf_params P;
 };
 
@@ -143,17 +153,43 @@ __device__ __forceinline__ void p_meas(const PoseCtx &pc, int k, lf_line_meas *m
   m->nA = q->A; m->nB = q->B; m->nMa = q->DUa; m->nMb = q->DUb;
   m->oA = t->A; m->oB = t->B; m->oMa = t->DUa; m->oMb = t->DUb;
 }
-// sum of per-landmark values in list order; v[h] belongs to list position lane + 64 h
-__device__ __forceinline__ double p_ordered_sum(const double *v, int n, double s) {
+// s + v_0 + v_1 + ... + v_{n-1} strictly in that order, v_i = the value thread i passes (threads >= n pass anything).
+// Eight LDS operands are in flight per trip; the padding rows are zero, and x + 0.0 == x.
+__device__ __forceinline__ void p_publish(double *red, double v, int n) {
+  const int tid = threadIdx.x;
+  red[tid] = (tid < n) ? v : 0.0;
+  if (tid < 8) red[PT_N + tid] = 0.0;
+}
+__device__ __forceinline__ double p_sum_published(const double *red, int n, double s) {
+  const int n8 = (n + 7) & ~7;
+  for (int l = 0; l < n8; l += 8) {
+    double q[8];
 #pragma unroll
-  for (int h = 0; h < NSLOT; h++) {
-    int cnt = n - 64 * h;
-    if (cnt > 64) cnt = 64;
-    for (int l = 0; l < cnt; l++) s += p_rl64(v[h], l);
+    for (int k = 0; k < 8; k++) q[k] = red[l + k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += q[k];
   }
   return s;
 }
-
+__device__ __forceinline__ double p_ordered_sum(PoseShared &S, double v, int n, double s) {
+  p_publish(S.red[0], v, n);
+  __syncthreads();
+  s = p_sum_published(S.red[0], n, s);
+  __syncthreads();
+  return s;
+}
+// maximum over the workgroup (order does not matter for a maximum)
+__device__ __forceinline__ double p_block_max(PoseShared &S, double mx) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(mx, o, 64); mx = t > mx ? t : mx; }
+  if (p_lane() == 0) S.wred[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = S.wred[0];
+#pragma unroll
+  for (int w = 1; w < PW_N; w++) { double t = S.wred[w]; mx = t > mx ? t : mx; }
+  __syncthreads();
+  return mx;
+}
 
 // acc (+/-)= base[k * stride] for k = 0..n-1, strictly in that order; the loads of 8 rows are issued together
 // (they do not depend on the running sum), the additions stay sequential.
@@ -171,124 +207,250 @@ __device__ __forceinline__ double p_walk(const double *base, size_t stride, int 
   return acc;
 }
 
+#ifdef LF_POSE_PROFILE   // LF_EXTRA_CFLAGS=-DLF_POSE_PROFILE: s_memtime per phase of pair 7, printed at the end of k_pose
+__device__ unsigned long long g_pprof[16], g_pprev;
+#define PT(k) do { __builtin_amdgcn_s_waitcnt(0); if (blockIdx.x == 7 && threadIdx.x == 0) { unsigned long long tn = __builtin_amdgcn_s_memtime(); g_pprof[k] += tn - g_pprev; g_pprev = tn; } } while (0)
+#else
+#define PT(k) do { } while (0)
+#endif
+// ---- the LM refinement works on TASKS (match i, component d): six neighbouring lanes own one match, ten matches per
+// wavefront, forty per pass of the workgroup.  The six lanes read the same workspace rows (one cache line serves
+// all of them, and a wavefront's working set stays inside the L1), exchange what they need through a per-wavefront
+// LDS tile, and each produces one column / row of the 6x6 blocks.  Every value is produced by the same expression
+// as in the sequential lf_match_blocks / lf_match_eliminate / lf_match_backsub (lf_pose.h).
+#define PG_N 10                    // matches per wavefront pass
+struct PoseTask { int i, d, g; bool act; };
+__device__ __forceinline__ PoseTask p_task(int base, int n) {
+  PoseTask t;
+  const int lane = p_lane();
+  t.g = lane / 6; t.d = lane - 6 * t.g;
+  if (t.g >= PG_N) { t.g = PG_N - 1; t.d = 0; }
+  t.i = base + (int)(threadIdx.x >> 6) * PG_N + t.g;
+  t.act = lane < 6 * PG_N && t.i < n;
+  return t;
+}
+__device__ __forceinline__ void p_wave_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+// value of component k of the calling lane's match (lanes 6 g .. 6 g + 5 hold components 0 .. 5)
+__device__ __forceinline__ double p_sib(double v, const PoseTask &t, int k) { return __shfl(v, 6 * t.g + k, 64); }
+
+// lf_match_blocks: lane (i, d) computes column d of Jn, Jo, Jp (central differences along landmark component d and
+// pose component d), publishes them in the tile, and then row d of V, W, Hpp and entry d of bl, bp.
+__device__ void p_blocks(PoseShared &S, const PoseCtx &pc, const int *set, int n, const lf_se3 &X, double wgt, double hd, int hub,
+                         double *mxl_io) {
+  const double delta = 1e-9, scalar = 1.0 / (2 * 1e-9);
+  double mxl = *mxl_io;
+  double *tile = S.tile[threadIdx.x >> 6];
+  for (int base = 0; base < n; base += PG_N * PW_N) {
+    const PoseTask t = p_task(base, n);
+    const int i = t.act ? t.i : 0, d = t.d;
+    lf_line_meas m;
+    double L[6], en[6], eo[6], cn[6], co[6], cp[6], c, r0n, r0o, wn, wo;
+    p_meas(pc, set[i], &m);
+    for (int k = 0; k < 6; k++) L[k] = pc.wsL[6 * i + k];
+    lf_match_errors(&X, L, &m, en, eo);
+    c = 0; for (int k = 0; k < 6; k++) c += en[k] * (wgt * en[k]);
+    lf_huber(c, hd, hub, &r0n, &wn);
+    c = 0; for (int k = 0; k < 6; k++) c += eo[k] * (wgt * eo[k]);
+    lf_huber(c, hd, hub, &r0o, &wo);
+    if (t.act && d == 0) S.red[0][i] = r0n + r0o;     // the match's chi2 term
+    wn = wn * wgt; wo = wo * wgt;
+    {
+      double Lp[6], ep[6], em[6], ep2[6], em2[6];
+      for (int k = 0; k < 6; k++) Lp[k] = (k == d) ? L[k] + delta : L[k];
+      lf_match_errors(&X, Lp, &m, ep, ep2);
+      for (int k = 0; k < 6; k++) Lp[k] = (k == d) ? L[k] - delta : L[k];
+      lf_match_errors(&X, Lp, &m, em, em2);
+      for (int k = 0; k < 6; k++) { cn[k] = scalar * (ep[k] - em[k]); co[k] = scalar * (ep2[k] - em2[k]); }
+    }
+    {
+      double v[6], PA[3], PB[3], ep[6], em[6];
+      lf_se3 Xp;
+      for (int k = 0; k < 6; k++) v[k] = (k == d) ? delta : 0.0;
+      lf_se3_oplus(&X, v, &Xp);
+      lf_se3_inv_apply(&Xp, L, PA); lf_se3_inv_apply(&Xp, L + 3, PB);
+      lf_line_edge_error(m.oMa, m.oMb, m.oA, m.oB, PA, PB, ep);
+      for (int k = 0; k < 6; k++) v[k] = (k == d) ? -delta : 0.0;
+      lf_se3_oplus(&X, v, &Xp);
+      lf_se3_inv_apply(&Xp, L, PA); lf_se3_inv_apply(&Xp, L + 3, PB);
+      lf_line_edge_error(m.oMa, m.oMb, m.oA, m.oB, PA, PB, em);
+      for (int k = 0; k < 6; k++) cp[k] = scalar * (ep[k] - em[k]);
+    }
+    double *J = tile + t.g * 108;          // Jn[36] Jo[36] Jp[36], row-major 6x6 each
+    if (t.act) for (int k = 0; k < 6; k++) { J[6 * k + d] = cn[k]; J[36 + 6 * k + d] = co[k]; J[72 + 6 * k + d] = cp[k]; }
+    p_wave_order();
+    if (t.act) {
+      const int q = d;
+      double *o = pc.wsB + (size_t)i * 120;
+      double sbl_n = 0, sbl_o = 0, sbp = 0;
+      for (int k = 0; k < 6; k++) {
+        double wen = wn * en[k], weo = wo * eo[k];
+        sbl_n += cn[k] * wen; sbl_o += co[k] * weo; sbp += cp[k] * weo;
+      }
+      o[72 + q] = -(sbl_n + sbl_o);
+      o[114 + q] = -sbp;
+      for (int j = 0; j < 6; j++) {
+        double vn = 0, vo = 0, hw = 0, hp = 0;
+        for (int k = 0; k < 6; k++) {
+          double jn = J[6 * k + j], jo = J[36 + 6 * k + j], jp = J[72 + 6 * k + j];
+          vn += cn[k] * (wn * jn);
+          vo += co[k] * (wo * jo);
+          hw += cp[k] * (wo * jo);
+          hp += cp[k] * (wo * jp);
+        }
+        double V = vn + vo;
+        o[6 * q + j] = V;
+        o[36 + 6 * q + j] = hw;
+        o[78 + 6 * q + j] = hp;
+        if (j == q) { double a = lf_fabs(V); if (a > mxl) mxl = a; }
+      }
+    }
+    p_wave_order();                         // the tile is free for the next pass
+  }
+  *mxl_io = mxl;
+}
+
+// lf_match_eliminate: lane (i, d) solves (V + lambda I) x = e_d (column d of Vi; the elimination of the matrix is
+// the same in the six lanes and the right-hand-side columns are independent), forms column d of W Vi, publishes it,
+// and then row d of T = W Vi W^T and entry d of u = W Vi bl.  Returns 1 if some match of this lane is singular.
+__device__ int p_eliminate(PoseShared &S, const PoseCtx &pc, int n, double lambda) {
+  int bad = 0;
+  double *tile = S.tile[threadIdx.x >> 6];
+  for (int base = 0; base < n; base += PG_N * PW_N) {
+    const PoseTask t = p_task(base, n);
+    const int i = t.act ? t.i : 0, d = t.d;
+    const double *o = pc.wsB + (size_t)i * 120;
+    double A[36], x[6], W[36], wvc[6];
+#pragma unroll
+    for (int k = 0; k < 36; k++) A[k] = o[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { A[7 * k] += lambda; x[k] = (k == d) ? 1.0 : 0.0; }
+    const int ok = lf_solve6(A, x, 1);
+    if (t.act && !ok) bad = 1;
+#pragma unroll
+    for (int k = 0; k < 36; k++) W[k] = o[36 + k];
+#pragma unroll
+    for (int r = 0; r < 6; r++) { double s = 0; for (int k = 0; k < 6; k++) s += W[6 * r + k] * x[k]; wvc[r] = s; }
+    double *WV = tile + t.g * 108;
+    if (t.act) {
+      double *vo = pc.wsVi + (size_t)i * 36;
+#pragma unroll
+      for (int k = 0; k < 6; k++) { vo[6 * k + d] = x[k]; WV[6 * k + d] = wvc[k]; }
+    }
+    p_wave_order();
+    if (t.act) {
+      double *to = pc.wsTU + (size_t)i * 42;
+      double wv[6], s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) wv[k] = WV[6 * d + k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += wv[k] * o[72 + k];
+      to[36 + d] = s;
+#pragma unroll
+      for (int j = 0; j < 6; j++) { double s2 = 0; for (int k = 0; k < 6; k++) s2 += wv[k] * W[6 * j + k]; to[6 * d + j] = s2; }
+    }
+    p_wave_order();
+  }
+  return bad;
+}
+
+// lf_match_backsub + the step's chi2: lane (i, a) computes component a of r = bl - W^T dp and of dl = Vi r; the six
+// lanes exchange r, the new landmark and the scale terms by lane shuffles.
+__device__ void p_backsub(PoseShared &S, const PoseCtx &pc, const int *set, int n, const lf_se3 &Xn, const double *dp, double lambda,
+                          double wgt, double hd, int hub) {
+  for (int base = 0; base < n; base += PG_N * PW_N) {
+    const PoseTask t = p_task(base, n);
+    const int i = t.act ? t.i : 0, a = t.d;
+    const double *o = pc.wsB + (size_t)i * 120, *Vi = pc.wsVi + (size_t)i * 36;
+    double tt = 0, rr[6], Ln[6], dl = 0, s = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) tt += o[36 + 6 * k + a] * dp[k];
+    const double bla = o[72 + a], ra = bla - tt;
+#pragma unroll
+    for (int k = 0; k < 6; k++) rr[k] = p_sib(ra, t, k);
+#pragma unroll
+    for (int k = 0; k < 6; k++) dl += Vi[6 * a + k] * rr[k];
+    const double La = pc.wsL[6 * i + a] + dl, term = dl * (lambda * dl + bla);
+    if (t.act) pc.wsLn[6 * i + a] = La;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { Ln[k] = p_sib(La, t, k); s += p_sib(term, t, k); }
+    lf_line_meas m;
+    p_meas(pc, set[i], &m);
+    const double tc = lf_match_chi2(&Xn, Ln, &m, wgt, hd, hub);
+    if (t.act && a == 0) { S.red[0][i] = s; S.red[1][i] = tc; }
+  }
+}
+// rows n .. n8-1 of both published columns hold 0.0 (the ordered sums run in trips of eight)
+__device__ __forceinline__ void p_pad_published(PoseShared &S, int n) {
+  const int tid = threadIdx.x;
+  if (tid < 8) { S.red[0][n + tid] = 0.0; S.red[1][n + tid] = 0.0; }
+}
+
 // getTransformFromHybridMatchesG2O (transformation_estimation.cpp:218-461), line edges only; the
 // sequential twin is oracle_refine_g2o.  set[0..n) = match indices (LDS).
-__device__ void p_refine(const PoseCtx &pc, const int *set, int n, float *tf, int iterations) {
-  const int lane = p_lane();
+__device__ void p_refine(PoseShared &S, const PoseCtx &pc, const int *set, int n, float *tf, int iterations) {
+  const int tid = threadIdx.x;
   const double wgt = pc.P.g2o_line_error_weight, hd = pc.P.g2o_BA_kernel_delta;
   const int hub = pc.P.g2o_BA_use_kernel;
   lf_se3 X, Xn;
   double lambda = 0, ni = 2, currentChi = 0;
   lf_tf_to_older_pose(tf, &X);
-  for (int h = 0; h < NSLOT; h++) {
-    int i = lane + 64 * h;
-    if (i < n) {
-      const lf_line_record *q = &pc.query[pc.mq[set[i]]];
-      for (int k = 0; k < 3; k++) { pc.wsL[6 * i + k] = q->A[k]; pc.wsL[6 * i + 3 + k] = q->B[k]; }
-    }
+  if (tid < n) {
+    const lf_line_record *q = &pc.query[pc.mq[set[tid]]];
+    for (int k = 0; k < 3; k++) { pc.wsL[6 * tid + k] = q->A[k]; pc.wsL[6 * tid + 3 + k] = q->B[k]; }
   }
+  p_pad_published(S, n);
   __syncthreads();
   for (int it = 0; it < iterations && n > 0; it++) {
-    double Hpp[36], bp[6], rho = 0, tempChi, cv[NSLOT];
+    double rho = 0, tempChi;
     int qmax = 0;
     double mxl = 0;
-    for (int h = 0; h < NSLOT; h++) {
-      int i = lane + 64 * h;
-      cv[h] = 0;
-      if (i < n) {
-        lf_line_meas m;
-        lf_line_blocks Bk;
-        double L[6];
-        p_meas(pc, set[i], &m);
-        for (int k = 0; k < 6; k++) L[k] = pc.wsL[6 * i + k];
-        cv[h] = lf_match_chi2(&X, L, &m, wgt, hd, hub);
-        lf_match_blocks(&X, L, &m, wgt, hd, hub, &Bk);
-        double *o = pc.wsB + (size_t)i * 120;
-        for (int k = 0; k < 36; k++) { o[k] = Bk.V[k]; o[36 + k] = Bk.W[k]; o[78 + k] = Bk.Hpp[k]; }
-        for (int k = 0; k < 6; k++) { o[72 + k] = Bk.bl[k]; o[114 + k] = Bk.bp[k]; double a = lf_fabs(Bk.V[7 * k]); if (a > mxl) mxl = a; }
-      }
-    }
-    currentChi = p_ordered_sum(cv, n, 0.0);
+    PT(0);
+    p_blocks(S, pc, set, n, X, wgt, hd, hub, &mxl);
     __syncthreads();
-    double accH = 0;   // Hpp | bp: accumulator lane a (< 42) walks the matches in order and keeps entry a
-    if (lane < 42) accH = p_walk<false>(pc.wsB + 78 + lane, 120, n, accH);
-#pragma unroll
-    for (int a = 0; a < 36; a++) Hpp[a] = p_rl64(accH, a);
-#pragma unroll
-    for (int a = 0; a < 6; a++) bp[a] = p_rl64(accH, 36 + a);
+    PT(5);
+    currentChi = p_sum_published(S.red[0], n, 0.0);
+    // Hpp | bp: accumulator lane a (< 42) walks the matches in order and keeps entry a
+    if (tid < 42) S.hb[tid] = p_walk<false>(pc.wsB + 78 + tid, 120, n, 0.0);
     if (it == 0) {   // computeLambdaInit: tau * max |diagonal entry|
-      double mx = mxl;
+      double mx = p_block_max(S, mxl);           // (barrier inside: hb visible)
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(mx, o, 64); mx = t > mx ? t : mx; }
-#pragma unroll
-      for (int i = 0; i < 6; i++) if (lf_fabs(Hpp[7 * i]) > mx) mx = lf_fabs(Hpp[7 * i]);
+      for (int i = 0; i < 6; i++) if (lf_fabs(S.hb[7 * i]) > mx) mx = lf_fabs(S.hb[7 * i]);
       lambda = 1e-5 * mx;
       ni = 2;
-    }
+    } else __syncthreads();
+    PT(6);
     do {
-      double S[36], g[6], dp[6], scale = 0;
-      bool okl = true;
-      for (int h = 0; h < NSLOT; h++) {
-        int i = lane + 64 * h;
-        if (i < n) {
-          lf_line_blocks Bk;
-          const double *o = pc.wsB + (size_t)i * 120;
-          for (int k = 0; k < 36; k++) { Bk.V[k] = o[k]; Bk.W[k] = o[36 + k]; }
-          for (int k = 0; k < 6; k++) Bk.bl[k] = o[72 + k];
-          double Vi[36], T[36], u[6];
-          if (!lf_match_eliminate(&Bk, lambda, Vi, T, u)) okl = false;
-          double *vo = pc.wsVi + (size_t)i * 36, *to = pc.wsTU + (size_t)i * 42;
-          for (int k = 0; k < 36; k++) { vo[k] = Vi[k]; to[k] = T[k]; }
-          for (int k = 0; k < 6; k++) to[36 + k] = u[k];
-        }
-      }
+      double dp[6], scale = 0;
       // the oracle stops eliminating at the first failing match; any failure rejects the step
-      int ok2 = (__ballot(!okl) == 0) ? 1 : 0;
-      __syncthreads();
-      {
-        double acc = accH;
-        if (lane < 36 && lane % 7 == 0) acc = accH + lambda;          // S = Hpp + lambda I ; g = bp
-        if (lane < 42) acc = p_walk<true>(pc.wsTU + lane, 42, n, acc);
-#pragma unroll
-        for (int a = 0; a < 36; a++) S[a] = p_rl64(acc, a);
-#pragma unroll
-        for (int a = 0; a < 6; a++) g[a] = p_rl64(acc, 36 + a);
+      int ok2 = __syncthreads_or(p_eliminate(S, pc, n, lambda)) ? 0 : 1;
+      PT(7);
+      if (tid < 42) {
+        double acc = S.hb[tid];
+        if (tid < 36 && tid % 7 == 0) acc = acc + lambda;             // S = Hpp + lambda I ; g = bp
+        S.sg[tid] = p_walk<true>(pc.wsTU + tid, 42, n, acc);
       }
+      __syncthreads();
+      PT(8);
       if (ok2) {
         double A[36];
 #pragma unroll
-        for (int i = 0; i < 36; i++) A[i] = S[i];
+        for (int i = 0; i < 36; i++) A[i] = S.sg[i];
 #pragma unroll
-        for (int i = 0; i < 6; i++) dp[i] = g[i];
-        ok2 = lf_solve6_u(A, dp, 1);   // the pose system is the same in every lane: scalar pivot branches
+        for (int i = 0; i < 6; i++) dp[i] = S.sg[36 + i];
+        ok2 = lf_solve6_u(A, dp, 1);   // the pose system is the same in every thread: scalar pivot branches
       }
+      PT(9);
       tempChi = DBL_MAX;
       if (ok2) {
         lf_se3_oplus(&X, dp, &Xn);
 #pragma unroll
-        for (int i = 0; i < 6; i++) scale += dp[i] * (lambda * dp[i] + bp[i]);
-        double sk[NSLOT], tc[NSLOT];
-        for (int h = 0; h < NSLOT; h++) {
-          int i = lane + 64 * h;
-          sk[h] = 0; tc[h] = 0;
-          if (i < n) {
-            lf_line_blocks Bk;
-            const double *o = pc.wsB + (size_t)i * 120;
-            for (int k = 0; k < 36; k++) Bk.W[k] = o[36 + k];
-            for (int k = 0; k < 6; k++) Bk.bl[k] = o[72 + k];
-            double Vi[36], dl[6], Ln[6], s = 0;
-            for (int k = 0; k < 36; k++) Vi[k] = pc.wsVi[(size_t)i * 36 + k];
-            lf_match_backsub(&Bk, Vi, dp, dl);
-            for (int k = 0; k < 6; k++) { Ln[k] = pc.wsL[6 * i + k] + dl[k]; pc.wsLn[6 * i + k] = Ln[k]; s += dl[k] * (lambda * dl[k] + Bk.bl[k]); }
-            sk[h] = s;
-            lf_line_meas m;
-            p_meas(pc, set[i], &m);
-            tc[h] = lf_match_chi2(&Xn, Ln, &m, wgt, hd, hub);
-          }
-        }
-        scale = p_ordered_sum(sk, n, scale);
-        tempChi = p_ordered_sum(tc, n, 0.0);
+        for (int i = 0; i < 6; i++) scale += dp[i] * (lambda * dp[i] + S.hb[36 + i]);
+        p_backsub(S, pc, set, n, Xn, dp, lambda, wgt, hd, hub);
+        __syncthreads();
+        scale = p_sum_published(S.red[0], n, scale);
+        tempChi = p_sum_published(S.red[1], n, 0.0);
       }
+      PT(10);
       rho = (currentChi - tempChi);
       scale += 1e-3;
       rho /= scale;
@@ -300,15 +462,13 @@ __device__ void p_refine(const PoseCtx &pc, const int *set, int n, float *tf, in
         ni = 2;
         currentChi = tempChi;
         X = Xn;
-        for (int h = 0; h < NSLOT; h++) {
-          int i = lane + 64 * h;
-          if (i < n) for (int k = 0; k < 6; k++) pc.wsL[6 * i + k] = pc.wsLn[6 * i + k];
-        }
+        for (int k = tid; k < 6 * n; k += PT_N) pc.wsL[k] = pc.wsLn[k];
       } else {
         lambda *= ni;
         ni *= 2;
       }
       __syncthreads();
+      PT(11);
       qmax++;
     } while (rho < 0 && qmax < 10);
     if (qmax == 10 || rho == 0) break;
@@ -318,31 +478,32 @@ __device__ void p_refine(const PoseCtx &pc, const int *set, int n, float *tf, in
 
 // inlier scan of all matches with tf; returns count, fills set[] (ascending) and the float sse the
 // reference accumulates (motion.cpp:688-699 / 795-812)
-__device__ int p_score(const PoseCtx &pc, int nLn, const float *tf, double thr, int *set, float *sse_out,
+__device__ int p_score(PoseShared &S, const PoseCtx &pc, int nLn, const float *tf, double thr, int *set, float *sse_out,
                        double *sse_d_out) {
-  const int lane = p_lane();
-  double add[NSLOT];
-  u64 msk[NSLOT];
-  int cnt = 0;
-#pragma unroll
-  for (int h = 0; h < NSLOT; h++) {
-    int i = lane + 64 * h;
-    bool in = false;
-    add[h] = 0;
-    if (i < nLn) {
-      const lf_line_record *q = &pc.query[pc.mq[i]], *t = &pc.train[pc.mt[i]];
-      in = lf_line_inlier(tf, q->A, q->B, t->A, t->B, t->DUa, t->DUb, thr, &add[h]);
-    }
-    msk[h] = __ballot(in);
-    if (in) set[cnt + __popcll(msk[h] & p_lt())] = i;
-    cnt += __popcll(msk[h]);
+  const int tid = threadIdx.x, w = tid >> 6;
+  bool in = false;
+  double add = 0;
+  if (tid < nLn) {
+    const lf_line_record *q = &pc.query[pc.mq[tid]], *t = &pc.train[pc.mt[tid]];
+    in = lf_line_inlier(tf, q->A, q->B, t->A, t->B, t->DUa, t->DUb, thr, &add);
   }
+  const u64 msk = __ballot(in);
+  if (p_lane() == 0) S.wcnt[w] = __popcll(msk);
+  p_publish(S.red[0], add, nLn);       // 0.0 for a non-inlier: adding it changes neither sum
+  __syncthreads();
+  int base = 0, cnt = 0;
+#pragma unroll
+  for (int k = 0; k < PW_N; k++) { int c = S.wcnt[k]; if (k < w) base += c; cnt += c; }
+  if (in) set[base + __popcll(msk & p_lt())] = tid;
   float sse = 0;      // `float sse` of the RANSAC loop (motion.cpp:666)
   double sse_d = 0;   // `double tmp_sse` of the re-scoring loop (motion.cpp:778)
+  const int n8 = (nLn + 7) & ~7;
+  for (int l = 0; l < n8; l += 8) {
+    double q[8];
 #pragma unroll
-  for (int h = 0; h < NSLOT; h++) {
-    u64 m = msk[h];
-    while (m) { int l = __builtin_ctzll(m); m &= m - 1; double a = p_rl64(add[h], l); sse += a; sse_d += a; }
+    for (int k = 0; k < 8; k++) q[k] = S.red[0][l + k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { sse += q[k]; sse_d += q[k]; }
   }
   *sse_out = sse;
   *sse_d_out = sse_d;
@@ -350,9 +511,9 @@ __device__ int p_score(const PoseCtx &pc, int nLn, const float *tf, double thr, 
   return cnt;
 }
 
-__global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
+__global__ void __launch_bounds__(PT_N, 2) k_pose(PairConsts c, PairBuffers b) {
   __shared__ PoseShared S;
-  const int pr = blockIdx.x, lane = p_lane();
+  const int pr = blockIdx.x, tid = threadIdx.x, lane = p_lane();
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];
   lf_pair_result *res = b.results + pr;
   PoseCtx pc;
@@ -362,7 +523,7 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
   pc.mt = b.match_t + (size_t)pr * c.match_cap;
   double *ws = b.ws + (size_t)pr * LF_PAIR_WS_DOUBLES;
   pc.wsB = ws; pc.wsVi = ws + LF_MAX_MATCHES * 120; pc.wsTU = pc.wsVi + LF_MAX_MATCHES * 36;
-  pc.wsL = pc.wsTU + LF_MAX_MATCHES * 42; pc.wsLn = pc.wsL + LF_MAX_MATCHES * 6;
+  pc.wsL = pc.wsTU + LF_MAX_MATCHES * 42; pc.wsLn = pc.wsL + LF_MAX_MATCHES * 6; pc.wsJ = pc.wsLn + LF_MAX_MATCHES * 6;
   pc.P = c.P;
   const lf_params &P = c.P;
   int nLn = b.nmatches[pr];
@@ -378,15 +539,18 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
   int min_inlier = P.min_feature_matches, lw = P.line_match_number_weight, maxIter = P.ransac_iters_line_motion;
   if (maxIter > LF_RANSAC_MAX_ITERS) maxIter = LF_RANSAC_MAX_ITERS;
   const double thr = P.max_mah_dist_for_inliers;
+#ifdef LF_POSE_PROFILE
+  if (blockIdx.x == 7 && tid == 0) g_pprev = __builtin_amdgcn_s_memtime();
+#endif
   bool go = !(0 + nLn * lw < min_inlier);                                                   // motion.cpp:621-624
   if (min_inlier > 0.7 * (0 + nLn * lw)) min_inlier = (int)(0.7 * (0 + nLn * lw));          // :626-628
   { long long d = id_t - id_q; if (d < 0) d = -d; if (d > 50) min_inlier = P.min_matches_loopclose; }   // :631-633
   if (nLn < 3) go = false;
   if (go) {
     // ---- sample sequence (serial; partial Fisher-Yates state carries over, :635-658)
-    for (int i = lane; i < nLn; i += 64) S.idx[i] = i;
+    for (int i = tid; i < nLn; i += PT_N) S.idx[i] = i;
     __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
       const uint64_t stream = LF_STREAM_PAIR((uint64_t)id_q, (uint64_t)id_t);
       uint64_t ctr = 0;
       for (int it = 0; it < maxIter; it++) {
@@ -400,9 +564,9 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
       }
     }
     __syncthreads();
-    // ---- one hypothesis per lane
+    // ---- one hypothesis per thread
     int my_cnt = -1, my_it = 1 << 30;
-    for (int it = lane; it < maxIter; it += 64) {
+    for (int it = tid; it < maxIter; it += PT_N) {
       double la[18], lb[18], R[9], t[3];
       float tf[16];
       for (int s = 0; s < 3; s++) {
@@ -419,13 +583,22 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
         const lf_line_record *q = &pc.query[pc.mq[i]], *tr = &pc.train[pc.mt[i]];
         nc += lf_line_inlier(tf, q->A, q->B, tr->A, tr->B, tr->DUa, tr->DUb, thr, &add);
       }
-      if (nc > my_cnt) { my_cnt = nc; my_it = it; }   // strictly greater: earliest iteration wins inside a lane
+      if (nc > my_cnt) { my_cnt = nc; my_it = it; }   // strictly greater: earliest iteration wins inside a thread
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {   // wavefront arg-max: count desc, iteration asc
+    for (int o = 32; o > 0; o >>= 1) {   // arg-max: count desc, iteration asc -- wavefront, then the four wavefronts
       int oc = __shfl_xor(my_cnt, o, 64), oi = __shfl_xor(my_it, o, 64);
       if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
     }
+    if (lane == 0) { S.wcnt[tid >> 6] = my_cnt; S.wit[tid >> 6] = my_it; }
+    __syncthreads();
+    my_cnt = S.wcnt[0]; my_it = S.wit[0];
+#pragma unroll
+    for (int w = 1; w < PW_N; w++) {
+      int oc = S.wcnt[w], oi = S.wit[w];
+      if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
+    }
+    __syncthreads();
     int nbest = my_cnt > 0 ? my_cnt : 0;
     best_iter = (my_cnt > 0) ? my_it : -1;
     if (0 + nbest >= 3) {                                                                    // :725-728
@@ -441,11 +614,12 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
       for (int i = 0; i < 3; i++) { for (int cc = 0; cc < 3; cc++) tf_best[4 * i + cc] = (float)R[3 * i + cc]; tf_best[4 * i + 3] = (float)t[i]; }
       tf_best[12] = tf_best[13] = tf_best[14] = 0.0f; tf_best[15] = 1.0f;
       double sse_unused;
-      int nb = p_score(pc, nLn, tf_best, thr, S.set, &sse_best, &sse_unused);
+      int nb = p_score(S, pc, nLn, tf_best, thr, S.set, &sse_best, &sse_unused);
       float refined_tf[16];
 #pragma unroll
       for (int i = 0; i < 16; i++) refined_tf[i] = tf_best[i];
-      p_refine(pc, S.set, nb, refined_tf, 25);                                               // :730
+      PT(12);
+      p_refine(S, pc, S.set, nb, refined_tf, 25);                                            // :730
       double refined_rmse = lf_sqrt(sse_best / (0 + nb));                                    // :731
       int nref = 0;
       for (int iter = 0; iter < 20; ++iter) {                                                // :775-839
@@ -454,13 +628,13 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
         int *inl = b.inliers + (size_t)pr * LF_MAX_MATCHES;
         // score into a scratch list first (kept only if it improves)
         __syncthreads();
-        int ncur = p_score(pc, nLn, refined_tf, thr, S.idx, &tmp_sse_f, &tmp_sse);
+        int ncur = p_score(S, pc, nLn, refined_tf, thr, S.idx, &tmp_sse_f, &tmp_sse);
         if (0 + ncur * lw > 0 + nref * lw) {
-          for (int i = lane; i < ncur; i += 64) { S.set[i] = S.idx[i]; inl[i] = S.idx[i]; }
+          for (int i = tid; i < ncur; i += PT_N) { S.set[i] = S.idx[i]; inl[i] = S.idx[i]; }
           __syncthreads();
           nref = ncur;
           refined_rmse = lf_sqrt(tmp_sse / (0 + ncur));
-          p_refine(pc, S.set, nref, refined_tf, 20);
+          p_refine(S, pc, S.set, nref, refined_tf, 20);
           rounds++;
         } else break;
       }
@@ -471,7 +645,15 @@ __global__ void __launch_bounds__(64) k_pose(PairConsts c, PairBuffers b) {
       valid = ((0 + lw * nref) >= min_inlier) ? 1 : 0;
     }
   }
-  if (lane == 0) {
+#ifdef LF_POSE_PROFILE
+  PT(13);
+  if (blockIdx.x == 7 && tid == 0) {
+    printf("k_pose prof (kticks) n=%d: pre-blocks %.1f stage0 %.1f A0 %.1f A1 %.1f A2 %.1f B %.1f walk+lambda %.1f elim %.1f walkTU %.1f solve %.1f backsub+chi %.1f accept %.1f | ransac %.1f rescoring/other %.1f\n", nLn,
+           g_pprof[0] / 1e3, g_pprof[1] / 1e3, g_pprof[2] / 1e3, g_pprof[3] / 1e3, g_pprof[4] / 1e3, g_pprof[5] / 1e3, g_pprof[6] / 1e3, g_pprof[7] / 1e3, g_pprof[8] / 1e3, g_pprof[9] / 1e3, g_pprof[10] / 1e3, g_pprof[11] / 1e3, g_pprof[12] / 1e3, g_pprof[13] / 1e3);
+    for (int i = 0; i < 16; i++) g_pprof[i] = 0;
+  }
+#endif
+  if (tid == 0) {
     for (int i = 0; i < 16; i++) res->T[i] = tf_out[i];
     res->rmse = rmse_out;
     res->valid = valid;
@@ -492,5 +674,5 @@ void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipS
   hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(256), 0, st, c, b);
   if (solver == LF_SOLVER_HYBRID) lf_pair_hybrid_launch(c, b, n_pairs, st);
   else if (solver == LF_SOLVER_RELMOTION) lf_pair_relmotion_launch(c, b, n_pairs, st);
-  else hipLaunchKernelGGL(k_pose, dim3(n_pairs), dim3(64), 0, st, c, b);
+  else hipLaunchKernelGGL(k_pose, dim3(n_pairs), dim3(PT_N), 0, st, c, b);
 }
