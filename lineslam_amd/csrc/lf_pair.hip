@@ -144,7 +144,7 @@ struct PoseShared {
 struct PoseCtx {
   const lf_line_record *train, *query;
   const int *mq, *mt;
-  double *wsB, *wsVi, *wsTU, *wsL, *wsLn, *wsJ;
+  double *wsB, *wsVi, *wsTU, *wsL, *wsLn, *wsE;
   lf_params P;
 };
 
@@ -233,10 +233,33 @@ __device__ __forceinline__ void p_wave_order() { __builtin_amdgcn_fence(__ATOMIC
 // value of component k of the calling lane's match (lanes 6 g .. 6 g + 5 hold components 0 .. 5)
 __device__ __forceinline__ double p_sib(double v, const PoseTask &t, int k) { return __shfl(v, 6 * t.g + k, 64); }
 
+// thread i < n: the edge errors of match i at (X, L = Lsrc + 6 i), their robust weights (times the edge weight) into
+// slot `slot` of the match's error record (en[6] eo[6] wn wo), and the match's chi2 term (lf_match_chi2) into red[i].
+// The record of an accepted trial step IS the base record of the next linearisation (same X, same L, same code).
+#define PE_STRIDE 28
+__device__ void p_errchi(const PoseCtx &pc, const int *set, int n, const lf_se3 &X, const double *Lsrc, int slot,
+                         double wgt, double hd, int hub, double *red) {
+  const int i = threadIdx.x;
+  if (i < n) {
+    lf_line_meas m;
+    double L[6], en[6], eo[6], c, r0n, r0o, wn, wo;
+    p_meas(pc, set[i], &m);
+    for (int k = 0; k < 6; k++) L[k] = Lsrc[6 * i + k];
+    lf_match_errors(&X, L, &m, en, eo);
+    c = 0; for (int k = 0; k < 6; k++) c += en[k] * (wgt * en[k]);
+    lf_huber(c, hd, hub, &r0n, &wn);
+    c = 0; for (int k = 0; k < 6; k++) c += eo[k] * (wgt * eo[k]);
+    lf_huber(c, hd, hub, &r0o, &wo);
+    double *E = pc.wsE + (size_t)i * PE_STRIDE + 14 * slot;
+    for (int k = 0; k < 6; k++) { E[k] = en[k]; E[6 + k] = eo[k]; }
+    E[12] = wn * wgt; E[13] = wo * wgt;
+    red[i] = r0n + r0o;
+  }
+}
+
 // lf_match_blocks: lane (i, d) computes column d of Jn, Jo, Jp (central differences along landmark component d and
 // pose component d), publishes them in the tile, and then row d of V, W, Hpp and entry d of bl, bp.
-__device__ void p_blocks(PoseShared &S, const PoseCtx &pc, const int *set, int n, const lf_se3 &X, double wgt, double hd, int hub,
-                         double *mxl_io) {
+__device__ void p_blocks(PoseShared &S, const PoseCtx &pc, const int *set, int n, const lf_se3 &X, int slot, double *mxl_io) {
   const double delta = 1e-9, scalar = 1.0 / (2 * 1e-9);
   double mxl = *mxl_io;
   double *tile = S.tile[threadIdx.x >> 6];
@@ -244,16 +267,12 @@ __device__ void p_blocks(PoseShared &S, const PoseCtx &pc, const int *set, int n
     const PoseTask t = p_task(base, n);
     const int i = t.act ? t.i : 0, d = t.d;
     lf_line_meas m;
-    double L[6], en[6], eo[6], cn[6], co[6], cp[6], c, r0n, r0o, wn, wo;
+    double L[6], en[6], eo[6], cn[6], co[6], cp[6];
     p_meas(pc, set[i], &m);
     for (int k = 0; k < 6; k++) L[k] = pc.wsL[6 * i + k];
-    lf_match_errors(&X, L, &m, en, eo);
-    c = 0; for (int k = 0; k < 6; k++) c += en[k] * (wgt * en[k]);
-    lf_huber(c, hd, hub, &r0n, &wn);
-    c = 0; for (int k = 0; k < 6; k++) c += eo[k] * (wgt * eo[k]);
-    lf_huber(c, hd, hub, &r0o, &wo);
-    if (t.act && d == 0) S.red[0][i] = r0n + r0o;     // the match's chi2 term
-    wn = wn * wgt; wo = wo * wgt;
+    const double *E = pc.wsE + (size_t)i * PE_STRIDE + 14 * slot;    // p_errchi: errors and weights at (X, L)
+    for (int k = 0; k < 6; k++) { en[k] = E[k]; eo[k] = E[6 + k]; }
+    const double wn = E[12], wo = E[13];
     {
       double Lp[6], ep[6], em[6], ep2[6], em2[6];
       for (int k = 0; k < 6; k++) Lp[k] = (k == d) ? L[k] + delta : L[k];
@@ -355,13 +374,12 @@ __device__ int p_eliminate(PoseShared &S, const PoseCtx &pc, int n, double lambd
 
 // lf_match_backsub + the step's chi2: lane (i, a) computes component a of r = bl - W^T dp and of dl = Vi r; the six
 // lanes exchange r, the new landmark and the scale terms by lane shuffles.
-__device__ void p_backsub(PoseShared &S, const PoseCtx &pc, const int *set, int n, const lf_se3 &Xn, const double *dp, double lambda,
-                          double wgt, double hd, int hub) {
+__device__ void p_backsub(PoseShared &S, const PoseCtx &pc, int n, const double *dp, double lambda) {
   for (int base = 0; base < n; base += PG_N * PW_N) {
     const PoseTask t = p_task(base, n);
     const int i = t.act ? t.i : 0, a = t.d;
     const double *o = pc.wsB + (size_t)i * 120, *Vi = pc.wsVi + (size_t)i * 36;
-    double tt = 0, rr[6], Ln[6], dl = 0, s = 0;
+    double tt = 0, rr[6], dl = 0, s = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++) tt += o[36 + 6 * k + a] * dp[k];
     const double bla = o[72 + a], ra = bla - tt;
@@ -372,11 +390,8 @@ __device__ void p_backsub(PoseShared &S, const PoseCtx &pc, const int *set, int 
     const double La = pc.wsL[6 * i + a] + dl, term = dl * (lambda * dl + bla);
     if (t.act) pc.wsLn[6 * i + a] = La;
 #pragma unroll
-    for (int k = 0; k < 6; k++) { Ln[k] = p_sib(La, t, k); s += p_sib(term, t, k); }
-    lf_line_meas m;
-    p_meas(pc, set[i], &m);
-    const double tc = lf_match_chi2(&Xn, Ln, &m, wgt, hd, hub);
-    if (t.act && a == 0) { S.red[0][i] = s; S.red[1][i] = tc; }
+    for (int k = 0; k < 6; k++) s += p_sib(term, t, k);
+    if (t.act && a == 0) S.red[0][i] = s;
   }
 }
 // rows n .. n8-1 of both published columns hold 0.0 (the ordered sums run in trips of eight)
@@ -400,15 +415,20 @@ __device__ void p_refine(PoseShared &S, const PoseCtx &pc, const int *set, int n
   }
   p_pad_published(S, n);
   __syncthreads();
+  int slot = 0;                                // error record of the current (X, L); the other one takes the trial step
+  if (n > 0 && iterations > 0) {
+    p_errchi(pc, set, n, X, pc.wsL, slot, wgt, hd, hub, S.red[0]);
+    __syncthreads();
+    currentChi = p_sum_published(S.red[0], n, 0.0);
+  }
   for (int it = 0; it < iterations && n > 0; it++) {
     double rho = 0, tempChi;
     int qmax = 0;
     double mxl = 0;
     PT(0);
-    p_blocks(S, pc, set, n, X, wgt, hd, hub, &mxl);
+    p_blocks(S, pc, set, n, X, slot, &mxl);
     __syncthreads();
     PT(5);
-    currentChi = p_sum_published(S.red[0], n, 0.0);
     // Hpp | bp: accumulator lane a (< 42) walks the matches in order and keeps entry a
     if (tid < 42) S.hb[tid] = p_walk<false>(pc.wsB + 78 + tid, 120, n, 0.0);
     if (it == 0) {   // computeLambdaInit: tau * max |diagonal entry|
@@ -445,7 +465,9 @@ __device__ void p_refine(PoseShared &S, const PoseCtx &pc, const int *set, int n
         lf_se3_oplus(&X, dp, &Xn);
 #pragma unroll
         for (int i = 0; i < 6; i++) scale += dp[i] * (lambda * dp[i] + S.hb[36 + i]);
-        p_backsub(S, pc, set, n, Xn, dp, lambda, wgt, hd, hub);
+        p_backsub(S, pc, n, dp, lambda);
+        __syncthreads();                       // the new landmarks are in wsLn
+        p_errchi(pc, set, n, Xn, pc.wsLn, slot ^ 1, wgt, hd, hub, S.red[1]);
         __syncthreads();
         scale = p_sum_published(S.red[0], n, scale);
         tempChi = p_sum_published(S.red[1], n, 0.0);
@@ -462,6 +484,7 @@ __device__ void p_refine(PoseShared &S, const PoseCtx &pc, const int *set, int n
         ni = 2;
         currentChi = tempChi;
         X = Xn;
+        slot ^= 1;
         for (int k = tid; k < 6 * n; k += PT_N) pc.wsL[k] = pc.wsLn[k];
       } else {
         lambda *= ni;
@@ -523,7 +546,7 @@ __global__ void __launch_bounds__(PT_N, 2) k_pose(PairConsts c, PairBuffers b) {
   pc.mt = b.match_t + (size_t)pr * c.match_cap;
   double *ws = b.ws + (size_t)pr * LF_PAIR_WS_DOUBLES;
   pc.wsB = ws; pc.wsVi = ws + LF_MAX_MATCHES * 120; pc.wsTU = pc.wsVi + LF_MAX_MATCHES * 36;
-  pc.wsL = pc.wsTU + LF_MAX_MATCHES * 42; pc.wsLn = pc.wsL + LF_MAX_MATCHES * 6; pc.wsJ = pc.wsLn + LF_MAX_MATCHES * 6;
+  pc.wsL = pc.wsTU + LF_MAX_MATCHES * 42; pc.wsLn = pc.wsL + LF_MAX_MATCHES * 6; pc.wsE = pc.wsLn + LF_MAX_MATCHES * 6;
   pc.P = c.P;
   const lf_params &P = c.P;
   int nLn = b.nmatches[pr];
