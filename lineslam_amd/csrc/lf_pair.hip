@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) k_match(PairConsts c, PairBuffers b) {
 // ONE 256-THREAD WORKGROUP (four wavefronts) PER PAIR.  A match ("landmark" of the refinement graph) belongs to
 // thread i; sums over the matches are taken in list order from values published in LDS, so every thread holds
 // the same bits the sequential oracle computes.
-#define PT_N 256                   // threads per pair == LF_MAX_MATCHES
+#define PT_N 256                   // threads per pair (>= LF_MAX_MATCHES)
 #define PW_N (PT_N / 64)
 struct PoseShared {
   int idx[LF_MAX_MATCHES];
@@ -157,8 +157,8 @@ __device__ __forceinline__ void p_meas(const PoseCtx &pc, int k, lf_line_meas *m
 // Eight LDS operands are in flight per trip; the padding rows are zero, and x + 0.0 == x.
 __device__ __forceinline__ void p_publish(double *red, double v, int n) {
   const int tid = threadIdx.x;
-  red[tid] = (tid < n) ? v : 0.0;
-  if (tid < 8) red[PT_N + tid] = 0.0;
+  if (tid < LF_MAX_MATCHES) red[tid] = (tid < n) ? v : 0.0;
+  if (tid < 8) red[LF_MAX_MATCHES + tid] = 0.0;
 }
 __device__ __forceinline__ double p_sum_published(const double *red, int n, double s) {
   const int n8 = (n + 7) & ~7;
@@ -196,6 +196,13 @@ __device__ __forceinline__ double p_block_max(PoseShared &S, double mx) {
 template <bool SUB>
 __device__ __forceinline__ double p_walk(const double *base, size_t stride, int n, double acc) {
   int k = 0;
+  for (; k + 32 <= n; k += 32) {     // (the rows come from HBM / L2 when the chip is full: keep many loads in flight)
+    double v[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) v[j] = base[(size_t)(k + j) * stride];
+#pragma unroll
+    for (int j = 0; j < 32; j++) acc = SUB ? acc - v[j] : acc + v[j];
+  }
   for (; k + 8 <= n; k += 8) {
     double v[8];
 #pragma unroll
