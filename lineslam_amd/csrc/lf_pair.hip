@@ -3,15 +3,15 @@
 //   k_match   Node::lineMatching (src/node.cpp:1619-1694): all-pairs gated descriptor distances
 //             (one 256-thread block per pair; N1 x N2 x 72 fp64, VALU -- no MFMA: N ~ 10^2),
 //             mutual nearest neighbour + ratio tests, ordered emission.
-//   k_pose    ONE WAVEFRONT PER PAIR:
+//   k_pose    ONE 256-THREAD WORKGROUP PER PAIR:
 //             getTransform_PtsLines_ransac (src/line/motion.cpp:605-849) with line matches: the sample
 //             sequence is generated serially (partial Fisher-Yates state carries over, :635-658), the
-//             500 hypotheses are solved and scored ONE PER LANE, the winner is the arg-max of the
+//             500 hypotheses are solved and scored ONE PER THREAD, the winner is the arg-max of the
 //             inlier count with the lowest iteration on ties (the sequential "strictly greater" rule,
-//             :714-720), found with wavefront shuffles;
-//             getTransformFromHybridMatchesG2O (src/transformation_estimation.cpp:218-461): LM with
-//             one landmark per lane, 6x6 Schur elimination per lane, pose system accumulated in match
-//             order by one accumulator lane per matrix entry (bit-identical to the sequential oracle).
+//             :714-720), found with wavefront shuffles + LDS;
+//             getTransformFromHybridMatchesG2O (src/transformation_estimation.cpp:218-461): LM with six
+//             lanes per match (columns / rows of the 6x6 blocks), pose system accumulated in match
+//             order by one accumulator thread per matrix entry (bit-identical to the sequential oracle).
 #include "lf_pair.h"
 #include "lf_pose.h"
 #include <float.h>
