@@ -67,16 +67,42 @@ __device__ __forceinline__ void wave_mem_order() { __builtin_amdgcn_fence(__ATOM
 // gaussian_sampler (lsd.cpp:529-646).  Taps kx/ky and boundary-folded source indices jx/jy are
 // host tables (gaussian_kernel :461-487 uses exp(); the symmetric boundary :597-600 is integer).
 // Summation order i = 0..n-1 starting from 0.0, exactly as :590-603 / :622-635.
+#define LF_GX_ROWS 8     // image rows per thread of k_gauss_x (the column's taps and source indices stay in registers)
+#define LF_GX_TAPS 7     // 1 + 2 ceil(sigma sqrt(2 * 3 ln 10)) for scale 0.8 (sigma = 0.75); other widths take the generic loop
 __global__ void __launch_bounds__(256) k_gauss_x(LsdConsts c, LsdBuffers b) {
   int x = blockIdx.x * blockDim.x + threadIdx.x;
-  int y = blockIdx.y, f = blockIdx.z;
+  int y0 = blockIdx.y * LF_GX_ROWS, f = blockIdx.z;
   if (x >= c.N) return;
-  const uint8_t *row = b.gray + (size_t)f * b.gray_frame_stride + (size_t)y * b.gray_row_stride;
+  const uint8_t *img = b.gray + (size_t)f * b.gray_frame_stride;
   const double *k = b.kx + (size_t)x * c.ntaps;
   const int *j = b.jx + (size_t)x * c.ntaps;
-  double sum = 0.0;
-  for (int i = 0; i < c.ntaps; i++) sum += (double)row[j[i]] * k[i];   // u8 -> double: utils.cpp:124-129
-  b.aux[((size_t)f * c.H + y) * c.N + x] = sum;
+  double *out = b.aux + ((size_t)f * c.H) * c.N + x;
+  if (c.ntaps == LF_GX_TAPS) {
+    double kk[LF_GX_TAPS];
+    int jj[LF_GX_TAPS];
+#pragma unroll
+    for (int i = 0; i < LF_GX_TAPS; i++) { kk[i] = k[i]; jj[i] = j[i]; }
+#pragma unroll
+    for (int r = 0; r < LF_GX_ROWS; r++) {
+      const int y = y0 + r;
+      if (y < c.H) {
+        const uint8_t *row = img + (size_t)y * b.gray_row_stride;
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < LF_GX_TAPS; i++) sum += (double)row[jj[i]] * kk[i];   // u8 -> double: utils.cpp:124-129
+        out[(size_t)y * c.N] = sum;
+      }
+    }
+    return;
+  }
+  for (int r = 0; r < LF_GX_ROWS; r++) {
+    const int y = y0 + r;
+    if (y >= c.H) break;
+    const uint8_t *row = img + (size_t)y * b.gray_row_stride;
+    double sum = 0.0;
+    for (int i = 0; i < c.ntaps; i++) sum += (double)row[j[i]] * k[i];
+    out[(size_t)y * c.N] = sum;
+  }
 }
 __global__ void __launch_bounds__(256) k_gauss_y(LsdConsts c, LsdBuffers b) {
   int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1263,7 +1289,7 @@ void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int B, hipStream_t s
   const size_t NM = (size_t)c.N * c.M;
   dim3 blk(256);
   if (b.ev_pre) (void)hipEventRecord(b.ev_pre, st);
-  hipLaunchKernelGGL(k_gauss_x, dim3((c.N + 255) / 256, c.H, B), blk, 0, st, c, b);
+  hipLaunchKernelGGL(k_gauss_x, dim3((c.N + 255) / 256, (c.H + LF_GX_ROWS - 1) / LF_GX_ROWS, B), blk, 0, st, c, b);
   hipLaunchKernelGGL(k_gauss_y, dim3((c.N + 255) / 256, c.M, B), blk, 0, st, c, b);
   hipLaunchKernelGGL(k_ll_angle, dim3((c.N + 31) / 32, (c.M + 7) / 8, B), blk, 0, st, c, b);
   int nch = (c.N - 1 + LF_SORT_CHUNK_COLS - 1) / LF_SORT_CHUNK_COLS;
