@@ -139,6 +139,7 @@ struct PoseShared {
   double hb[42], sg[42];          // Hpp | bp of the current linearisation; S | g of the current damping
   double tile[PW_N][10 * 108];    // per wavefront: the Jacobian columns (or W Vi) of the ten matches of a pass
   double wred[PW_N];
+  lf_se3 xp[12];                  // X (+) (+-delta e_d): the perturbed poses of the current linearisation
   int wcnt[PW_N], wit[PW_N], flag;
 };
 struct PoseCtx {
@@ -264,6 +265,21 @@ __device__ void p_errchi(const PoseCtx &pc, const int *set, int n, const lf_se3 
   }
 }
 
+// the twelve perturbed poses X (+) (+-1e-9 e_d) of the numeric pose Jacobians are the same for every match: twelve
+// threads compute them once per linearisation (lf_se3_oplus, as lf_match_blocks does per match) into S.xp[2 d + sign]
+__device__ __forceinline__ void p_perturbed_poses(PoseShared &S, const lf_se3 &X) {
+  const int tid = threadIdx.x;
+  if (tid < 12) {
+    const int d = tid >> 1;
+    const double dl = (tid & 1) ? -1e-9 : 1e-9;
+    double v[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = (k == d) ? dl : 0.0;
+    lf_se3 Xp;
+    lf_se3_oplus(&X, v, &Xp);
+    S.xp[tid] = Xp;
+  }
+}
 // lf_match_blocks: lane (i, d) computes column d of Jn, Jo, Jp (central differences along landmark component d and
 // pose component d), publishes them in the tile, and then row d of V, W, Hpp and entry d of bl, bp.
 __device__ void p_blocks(PoseShared &S, const PoseCtx &pc, const int *set, int n, const lf_se3 &X, int slot, double *mxl_io) {
@@ -289,14 +305,11 @@ __device__ void p_blocks(PoseShared &S, const PoseCtx &pc, const int *set, int n
       for (int k = 0; k < 6; k++) { cn[k] = scalar * (ep[k] - em[k]); co[k] = scalar * (ep2[k] - em2[k]); }
     }
     {
-      double v[6], PA[3], PB[3], ep[6], em[6];
-      lf_se3 Xp;
-      for (int k = 0; k < 6; k++) v[k] = (k == d) ? delta : 0.0;
-      lf_se3_oplus(&X, v, &Xp);
+      double PA[3], PB[3], ep[6], em[6];
+      lf_se3 Xp = S.xp[2 * d];                 // X (+) (+delta e_d), p_perturbed_poses
       lf_se3_inv_apply(&Xp, L, PA); lf_se3_inv_apply(&Xp, L + 3, PB);
       lf_line_edge_error(m.oMa, m.oMb, m.oA, m.oB, PA, PB, ep);
-      for (int k = 0; k < 6; k++) v[k] = (k == d) ? -delta : 0.0;
-      lf_se3_oplus(&X, v, &Xp);
+      Xp = S.xp[2 * d + 1];                    // X (+) (-delta e_d)
       lf_se3_inv_apply(&Xp, L, PA); lf_se3_inv_apply(&Xp, L + 3, PB);
       lf_line_edge_error(m.oMa, m.oMb, m.oA, m.oB, PA, PB, em);
       for (int k = 0; k < 6; k++) cp[k] = scalar * (ep[k] - em[k]);
@@ -433,6 +446,8 @@ __device__ void p_refine(PoseShared &S, const PoseCtx &pc, const int *set, int n
     int qmax = 0;
     double mxl = 0;
     PT(0);
+    p_perturbed_poses(S, X);
+    __syncthreads();
     p_blocks(S, pc, set, n, X, slot, &mxl);
     __syncthreads();
     PT(5);
