@@ -32,6 +32,7 @@ struct HShared {
   unsigned short smp[LF_RANSAC_MAX_ITERS * 3];
   int pset[LF_MAX_PT_MATCHES], lset[LF_MAX_MATCHES];     // current inlier lists
   int pcur[LF_MAX_PT_MATCHES], lcur[LF_MAX_MATCHES];     // scratch lists of the re-scoring loop
+  lf_se3 xp[12];                                         // X (+) (+-1e-9 e_d) of the current linearisation (lf_perturbed_poses)
 };
 struct HCtx {
   const lf_line_record *train, *query;
@@ -90,7 +91,7 @@ __device__ __forceinline__ double h_walk(const double *base, size_t stride, int 
 }
 
 // getTransformFromHybridMatchesG2O with point and line edges; sequential twin: oracle_refine_hybrid.
-__device__ void h_refine(const HCtx &pc, const int *pset, int np, const int *lset, int nl, float *tf, int iterations) {
+__device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, const int *lset, int nl, float *tf, int iterations) {
   const int lane = h_lane();
   const double wgt = pc.P.g2o_line_error_weight, hd = pc.P.g2o_BA_kernel_delta;
   const int hub = pc.P.g2o_BA_use_kernel;
@@ -121,6 +122,14 @@ __device__ void h_refine(const HCtx &pc, const int *pset, int np, const int *lse
     double Hpp[36], bp[6], rho = 0, tempChi, cvp[HP_SLOT], cvl[HL_SLOT];
     int qmax = 0;
     double mxl = 0;
+    if (lane < 12) {   // the perturbed poses of the numeric pose Jacobians do not depend on the landmark
+      double v[6];
+      for (int k = 0; k < 6; k++) v[k] = (k == (lane >> 1)) ? ((lane & 1) ? -1e-9 : 1e-9) : 0.0;
+      lf_se3 Xp;
+      lf_se3_oplus(&X, v, &Xp);
+      S.xp[lane] = Xp;
+    }
+    __syncthreads();
     for (int h = 0; h < HP_SLOT; h++) {
       int i = lane + 64 * h;
       cvp[h] = 0;
@@ -130,7 +139,7 @@ __device__ void h_refine(const HCtx &pc, const int *pset, int np, const int *lse
         lf_point_blocks Bk;
         double p[3] = {ws[WP_L + 3 * i], ws[WP_L + 3 * i + 1], ws[WP_L + 3 * i + 2]};
         cvp[h] = lf_ptmatch_chi2(&X, p, &pmm, hd, hub);
-        lf_ptmatch_blocks(&X, p, &pmm, hd, hub, &Bk);
+        lf_ptmatch_blocks_xp(&X, S.xp, p, &pmm, hd, hub, &Bk);
         double *o = ws + WP_B + (size_t)i * 72;
         for (int k = 0; k < 9; k++) o[k] = Bk.V[k];
         for (int k = 0; k < 18; k++) o[9 + k] = Bk.W[k];
@@ -149,7 +158,7 @@ __device__ void h_refine(const HCtx &pc, const int *pset, int np, const int *lse
         h_lmeas(pc, lset[i], &m);
         for (int k = 0; k < 6; k++) L[k] = ws[WL_L + 6 * i + k];
         cvl[h] = lf_match_chi2(&X, L, &m, wgt, hd, hub);
-        lf_match_blocks(&X, L, &m, wgt, hd, hub, &Bk);
+        lf_match_blocks_xp(&X, S.xp, L, &m, wgt, hd, hub, &Bk);
         double *o = ws + WL_B + (size_t)i * 120;
         for (int k = 0; k < 36; k++) { o[k] = Bk.V[k]; o[36 + k] = Bk.W[k]; o[78 + k] = Bk.Hpp[k]; }
         for (int k = 0; k < 6; k++) { o[72 + k] = Bk.bl[k]; o[114 + k] = Bk.bp[k]; double a = lf_fabs(Bk.V[7 * k]); if (a > mxl) mxl = a; }
@@ -481,7 +490,7 @@ __global__ void __launch_bounds__(64) k_pose_hybrid(PairConsts c, PairBuffers b)
         float refined_tf[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) refined_tf[i] = tf_best[i];
-        h_refine(pc, S.pset, nbp, S.lset, nbl, refined_tf, 25);                              // :730
+        h_refine(S, pc, S.pset, nbp, S.lset, nbl, refined_tf, 25);                              // :730
         double refined_rmse = lf_sqrt(sse_best / (nbp + nbl));                               // :731
         int nrp = 0, nrl = 0;
         int *pin = b.pt_inliers + (size_t)pr * LF_MAX_PT_MATCHES, *lin = b.inliers + (size_t)pr * LF_MAX_MATCHES;
@@ -496,7 +505,7 @@ __global__ void __launch_bounds__(64) k_pose_hybrid(PairConsts c, PairBuffers b)
             __syncthreads();
             nrp = ncp; nrl = ncl;
             refined_rmse = lf_sqrt(tmp_sse / (ncp + ncl));
-            h_refine(pc, S.pset, nrp, S.lset, nrl, refined_tf, 20);
+            h_refine(S, pc, S.pset, nrp, S.lset, nrl, refined_tf, 20);
             rounds++;
           } else break;
         }

@@ -255,8 +255,19 @@ LF_HD double lf_match_chi2(const lf_se3 *X, const double *L, const lf_line_meas 
   lf_huber(c, hdelta, huber, &r0, &r1);
   return s + r0;
 }
-LF_HD void lf_match_blocks(const lf_se3 *X, const double *L, const lf_line_meas *m, double wgt, double hdelta,
-                           int huber, lf_line_blocks *B) {
+/* XP: optional table of the twelve perturbed poses X (+) (+-1e-9 e_d) at [2 d + (minus ? 1 : 0)] -- they do not
+ * depend on the match, so a caller with many matches computes them once (lf_perturbed_poses); NULL: computed here. */
+LF_HD void lf_perturbed_poses(const lf_se3 *X, lf_se3 *XP) {
+  int d, i;
+  for (d = 0; d < 6; d++) {
+    double v[6];
+    for (i = 0; i < 6; i++) v[i] = 0;
+    v[d] = 1e-9; lf_se3_oplus(X, v, &XP[2 * d]);
+    v[d] = -1e-9; lf_se3_oplus(X, v, &XP[2 * d + 1]);
+  }
+}
+LF_HD void lf_match_blocks_xp(const lf_se3 *X, const lf_se3 *XP, const double *L, const lf_line_meas *m, double wgt, double hdelta,
+                              int huber, lf_line_blocks *B) {
   const double delta = 1e-9, scalar = 1.0 / (2 * 1e-9);
   double en[6], eo[6], Jn[36], Jo[36], Jp[36];   /* d e_n/dL, d e_o/dL, d e_o/dX  (row-major 6x6) */
   double c, r0, wn, wo;
@@ -276,11 +287,11 @@ LF_HD void lf_match_blocks(const lf_se3 *X, const double *L, const lf_line_meas 
     lf_se3 Xp;
     for (i = 0; i < 6; i++) v[i] = 0;
     v[d] = delta;
-    lf_se3_oplus(X, v, &Xp);
+    if (XP) Xp = XP[2 * d]; else lf_se3_oplus(X, v, &Xp);
     lf_se3_inv_apply(&Xp, L, PA); lf_se3_inv_apply(&Xp, L + 3, PB);
     lf_line_edge_error(m->oMa, m->oMb, m->oA, m->oB, PA, PB, ep);
     v[d] = -delta;
-    lf_se3_oplus(X, v, &Xp);
+    if (XP) Xp = XP[2 * d + 1]; else lf_se3_oplus(X, v, &Xp);
     lf_se3_inv_apply(&Xp, L, PA); lf_se3_inv_apply(&Xp, L + 3, PB);
     lf_line_edge_error(m->oMa, m->oMb, m->oA, m->oB, PA, PB, em);
     for (i = 0; i < 6; i++) Jp[6 * i + d] = scalar * (ep[i] - em[i]);
@@ -308,6 +319,10 @@ LF_HD void lf_match_blocks(const lf_se3 *X, const double *L, const lf_line_meas 
       B->Hpp[6 * i + j] = hp;
     }
   }
+}
+LF_HD void lf_match_blocks(const lf_se3 *X, const double *L, const lf_line_meas *m, double wgt, double hdelta,
+                           int huber, lf_line_blocks *B) {
+  lf_match_blocks_xp(X, 0, L, m, wgt, hdelta, huber, B);
 }
 /* Elimination of one landmark at damping lambda: Vi = (V + lambda I)^-1;  T = W Vi W^T (6x6),
  * u = W Vi bl (6).  Vi is kept for the back-substitution dl = Vi (bl - W^T dp).                  */
@@ -561,8 +576,8 @@ LF_HD double lf_ptmatch_chi2(const lf_se3 *X, const double *p, const lf_point_me
   lf_huber(lf_quad3(eo, m->Io), hdelta, huber, &r0, &r1);
   return s + r0;
 }
-LF_HD void lf_ptmatch_blocks(const lf_se3 *X, const double *p, const lf_point_meas *m, double hdelta, int huber,
-                             lf_point_blocks *B) {
+LF_HD void lf_ptmatch_blocks_xp(const lf_se3 *X, const lf_se3 *XP, const double *p, const lf_point_meas *m, double hdelta, int huber,
+                                lf_point_blocks *B) {
   const double delta = 1e-9, scalar = 1.0 / (2 * 1e-9);
   double en[3], eo[3], Jn[9], Jo[9], Jp[18], wn, wo, r0, On[9], Oo[9], One[3], Ooe[3];
   int d, i, j, k;
@@ -578,8 +593,10 @@ LF_HD void lf_ptmatch_blocks(const lf_se3 *X, const double *p, const lf_point_me
     double v[6], q[3], a[3], b[3];
     lf_se3 Xp;
     for (i = 0; i < 6; i++) v[i] = 0;
-    v[d] = delta; lf_se3_oplus(X, v, &Xp); lf_se3_inv_apply(&Xp, p, q); for (i = 0; i < 3; i++) a[i] = q[i] - m->mo[i];
-    v[d] = -delta; lf_se3_oplus(X, v, &Xp); lf_se3_inv_apply(&Xp, p, q); for (i = 0; i < 3; i++) b[i] = q[i] - m->mo[i];
+    v[d] = delta; if (XP) Xp = XP[2 * d]; else lf_se3_oplus(X, v, &Xp);
+    lf_se3_inv_apply(&Xp, p, q); for (i = 0; i < 3; i++) a[i] = q[i] - m->mo[i];
+    v[d] = -delta; if (XP) Xp = XP[2 * d + 1]; else lf_se3_oplus(X, v, &Xp);
+    lf_se3_inv_apply(&Xp, p, q); for (i = 0; i < 3; i++) b[i] = q[i] - m->mo[i];
     for (i = 0; i < 3; i++) Jp[6 * i + d] = scalar * (a[i] - b[i]);
   }
   lf_huber(lf_quad3(en, m->In), hdelta, huber, &r0, &wn);
@@ -616,6 +633,10 @@ LF_HD void lf_ptmatch_blocks(const lf_se3 *X, const double *p, const lf_point_me
       for (j = 0; j < 6; j++) { double a = 0; for (k = 0; k < 3; k++) a += Jp[6 * k + i] * OJp[6 * k + j]; B->Hpp[6 * i + j] = a; }
     }
   }
+}
+LF_HD void lf_ptmatch_blocks(const lf_se3 *X, const double *p, const lf_point_meas *m, double hdelta, int huber,
+                             lf_point_blocks *B) {
+  lf_ptmatch_blocks_xp(X, 0, p, m, hdelta, huber, B);
 }
 LF_HD int lf_ptmatch_eliminate(const lf_point_blocks *B, double lambda, double *Vi, double *T, double *u) {
   double A[9], WV[18];
