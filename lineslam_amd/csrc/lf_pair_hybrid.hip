@@ -1,5 +1,5 @@
 // lf_pair_hybrid.hip -- getTransform_PtsLines_ransac (src/line/motion.cpp:605-849) with BOTH point and
-// line matches (BASELINE.json config 3), one wavefront per node pair.  Launched instead of k_pose when the
+// line matches (BASELINE.json config 3), ONE 256-THREAD WORKGROUP PER NODE PAIR.  Launched instead of k_pose when the
 // caller supplies 3D points + point matches (Node::feature_locations_3d_ / MatchingResult::all_matches;
 // ORB extraction and descriptor matching themselves are SURVEY 8f "next" and stay on the caller's side).
 //
@@ -7,34 +7,26 @@
 //   point scoring         : errorFunction2 (src/misc.cpp:699-786)
 //   point edges           : EdgeSE3PointXYZ (src/line/edge_se3_ptxyz.cpp:84-90), information =
 //                           inverse compPt3dCov (transformation_estimation.cpp:267,283)
-// Same mapping as k_pose: samples generated serially, one hypothesis per lane, arg-max by shuffles, LM with
-// one landmark per lane and per-lane Schur elimination; every sum in the oracle's order (points first, then
-// lines -- the order in which the reference adds vertices and edges).
+// Same mapping as k_pose (lf_pose_wg.h): samples generated serially, one hypothesis per thread, arg-max by shuffles +
+// LDS; LM with six lanes per LINE landmark and one thread per POINT landmark (its 3x3 blocks are small); every sum
+// in the oracle's order (points first, then lines -- the order in which the reference adds vertices and edges).
 #include "lf_pair.h"
 #include "lf_pose.h"
 #include <float.h>
+#include "lf_pose_wg.h"
 
-typedef unsigned long long u64;
-#define HP_SLOT (LF_MAX_PT_MATCHES / 64)
-#define HL_SLOT (LF_MAX_MATCHES / 64)
-
-__device__ __forceinline__ int h_lane() { return (int)(threadIdx.x & 63u); }
-__device__ __forceinline__ u64 h_lt() { return (1ull << h_lane()) - 1ull; }
-__device__ __forceinline__ double h_rl64(double v, int l) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, l);
-  hi = __builtin_amdgcn_readlane(hi, l);
-  return __hiloint2double(hi, lo);
-}
+#define HP_SLOT (LF_MAX_PT_MATCHES / PT_N)   // point landmarks per thread
 
 struct HShared {
   int idx[LF_MAX_PT_MATCHES + LF_MAX_MATCHES];
   unsigned short smp[LF_RANSAC_MAX_ITERS * 3];
   int pset[LF_MAX_PT_MATCHES], lset[LF_MAX_MATCHES];     // current inlier lists
   int pcur[LF_MAX_PT_MATCHES], lcur[LF_MAX_MATCHES];     // scratch lists of the re-scoring loop
-  lf_se3 xp[12];                                         // X (+) (+-1e-9 e_d) of the current linearisation (lf_perturbed_poses)
+  int scnt[HP_SLOT + 1][PW_N];                           // inlier counts per (slot, wavefront) of h_score
+  LmShared lm;
 };
 struct HCtx {
+  PoseCtx lc;                          // line side: records, matches, line workspace (lf_pose_wg.h)
   const lf_line_record *train, *query;
   const float *tpts, *qpts;            // float4 per point
   const int *mq, *mt, *pq, *pt;        // line / point matches (indices into records / point arrays)
@@ -55,44 +47,19 @@ struct HCtx {
 #define WL_TU (WL_VI + LF_MAX_MATCHES * 36)
 #define WL_L (WL_TU + LF_MAX_MATCHES * 42)
 #define WL_LN (WL_L + LF_MAX_MATCHES * 6)
-#define W_TOTAL (WL_LN + LF_MAX_MATCHES * 6)
+#define WL_E (WL_LN + LF_MAX_MATCHES * 6)               /* [256][PE_STRIDE] error records of the line matches */
+#define W_TOTAL (WL_E + LF_MAX_MATCHES * PE_STRIDE)
 
-__device__ __forceinline__ void h_lmeas(const HCtx &pc, int k, lf_line_meas *m) {
-  const lf_line_record *q = &pc.query[pc.mq[k]], *t = &pc.train[pc.mt[k]];
-  m->nA = q->A; m->nB = q->B; m->nMa = q->DUa; m->nMb = q->DUb;
-  m->oA = t->A; m->oB = t->B; m->oMa = t->DUa; m->oMb = t->DUb;
-}
-template <int NS>
-__device__ __forceinline__ double h_ordered_sum(const double *v, int n, double s) {
-#pragma unroll
-  for (int h = 0; h < NS; h++) {
-    int cnt = n - 64 * h;
-    if (cnt > 64) cnt = 64;
-    for (int l = 0; l < cnt; l++) s += h_rl64(v[h], l);
-  }
-  return s;
-}
-
-
-// acc (+/-)= base[k * stride] for k = 0..n-1, strictly in that order; the loads of 8 rows are issued together
-// (they do not depend on the running sum), the additions stay sequential.
-template <bool SUB>
-__device__ __forceinline__ double h_walk(const double *base, size_t stride, int n, double acc) {
-  int k = 0;
-  for (; k + 8 <= n; k += 8) {
-    double v[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = base[(size_t)(k + j) * stride];
-#pragma unroll
-    for (int j = 0; j < 8; j++) acc = SUB ? acc - v[j] : acc + v[j];
-  }
-  for (; k < n; k++) acc = SUB ? acc - base[(size_t)k * stride] : acc + base[(size_t)k * stride];
-  return acc;
+__device__ __forceinline__ void h_pmeas(const double *ws, int i, lf_point_meas *pmm) {
+  const double *m = ws + WP_M + 24 * (size_t)i;
+  pmm->mn = m; pmm->mo = m + 3; pmm->In = m + 6; pmm->Io = m + 15;
 }
 
 // getTransformFromHybridMatchesG2O with point and line edges; sequential twin: oracle_refine_hybrid.
 __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, const int *lset, int nl, float *tf, int iterations) {
-  const int lane = h_lane();
+  LmShared &M = S.lm;
+  const PoseCtx &lc = pc.lc;
+  const int tid = threadIdx.x, ntot = np + nl;
   const double wgt = pc.P.g2o_line_error_weight, hd = pc.P.g2o_BA_kernel_delta;
   const int hub = pc.P.g2o_BA_use_kernel;
   double *ws = pc.ws;
@@ -100,7 +67,7 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
   double lambda = 0, ni = 2, currentChi = 0;
   lf_tf_to_older_pose(tf, &X);
   for (int h = 0; h < HP_SLOT; h++) {
-    int i = lane + 64 * h;
+    int i = tid + PT_N * h;
     if (i < np) {
       int k = pset[i];
       const float *qn = pc.qpts + 4 * (size_t)pc.pq[k], *qo = pc.tpts + 4 * (size_t)pc.pt[k];
@@ -110,36 +77,39 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
       lf_point_information(qo, pc.focal, pc.P.stdev_sample_pt_imgline, pc.P.depth_stdev_coeff_c1, pc.P.depth_stdev_coeff_c2 + 0.0 * 0.5, pc.P.depth_stdev_coeff_c3, m + 15);
     }
   }
-  for (int h = 0; h < HL_SLOT; h++) {
-    int i = lane + 64 * h;
-    if (i < nl) {
-      const lf_line_record *q = &pc.query[pc.mq[lset[i]]];
-      for (int k = 0; k < 3; k++) { ws[WL_L + 6 * i + k] = q->A[k]; ws[WL_L + 6 * i + 3 + k] = q->B[k]; }
-    }
+  if (tid < nl) {
+    const lf_line_record *q = &pc.query[pc.mq[lset[tid]]];
+    for (int k = 0; k < 3; k++) { lc.wsL[6 * tid + k] = q->A[k]; lc.wsL[6 * tid + 3 + k] = q->B[k]; }
   }
+  if (tid < 8) { M.red[0][ntot + tid] = 0.0; M.red[1][ntot + tid] = 0.0; }   // zero padding of the ordered sums
   __syncthreads();
-  for (int it = 0; it < iterations && (np + nl) > 0; it++) {
-    double Hpp[36], bp[6], rho = 0, tempChi, cvp[HP_SLOT], cvl[HL_SLOT];
+  int slot = 0;                                // error record of the line matches at the current (X, L)
+  if (ntot > 0 && iterations > 0) {
+    for (int h = 0; h < HP_SLOT; h++) {
+      int i = tid + PT_N * h;
+      if (i < np) {
+        lf_point_meas pmm; h_pmeas(ws, i, &pmm);
+        double p[3] = {ws[WP_L + 3 * i], ws[WP_L + 3 * i + 1], ws[WP_L + 3 * i + 2]};
+        M.red[0][i] = lf_ptmatch_chi2(&X, p, &pmm, hd, hub);
+      }
+    }
+    p_errchi(lc, lset, nl, X, lc.wsL, slot, wgt, hd, hub, M.red[0] + np);
+    __syncthreads();
+    currentChi = p_sum_published(M.red[0], ntot, 0.0);
+  }
+  for (int it = 0; it < iterations && ntot > 0; it++) {
+    double rho = 0, tempChi;
     int qmax = 0;
     double mxl = 0;
-    if (lane < 12) {   // the perturbed poses of the numeric pose Jacobians do not depend on the landmark
-      double v[6];
-      for (int k = 0; k < 6; k++) v[k] = (k == (lane >> 1)) ? ((lane & 1) ? -1e-9 : 1e-9) : 0.0;
-      lf_se3 Xp;
-      lf_se3_oplus(&X, v, &Xp);
-      S.xp[lane] = Xp;
-    }
+    p_perturbed_poses(M, X);
     __syncthreads();
-    for (int h = 0; h < HP_SLOT; h++) {
-      int i = lane + 64 * h;
-      cvp[h] = 0;
+    for (int h = 0; h < HP_SLOT; h++) {        // point landmarks: one thread each
+      int i = tid + PT_N * h;
       if (i < np) {
-        const double *m = ws + WP_M + 24 * (size_t)i;
-        lf_point_meas pmm; pmm.mn = m; pmm.mo = m + 3; pmm.In = m + 6; pmm.Io = m + 15;
+        lf_point_meas pmm; h_pmeas(ws, i, &pmm);
         lf_point_blocks Bk;
         double p[3] = {ws[WP_L + 3 * i], ws[WP_L + 3 * i + 1], ws[WP_L + 3 * i + 2]};
-        cvp[h] = lf_ptmatch_chi2(&X, p, &pmm, hd, hub);
-        lf_ptmatch_blocks_xp(&X, S.xp, p, &pmm, hd, hub, &Bk);
+        lf_ptmatch_blocks_xp(&X, M.xp, p, &pmm, hd, hub, &Bk);
         double *o = ws + WP_B + (size_t)i * 72;
         for (int k = 0; k < 9; k++) o[k] = Bk.V[k];
         for (int k = 0; k < 18; k++) o[9 + k] = Bk.W[k];
@@ -148,48 +118,24 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
         for (int k = 0; k < 6; k++) o[66 + k] = Bk.bp[k];
       }
     }
-    for (int h = 0; h < HL_SLOT; h++) {
-      int i = lane + 64 * h;
-      cvl[h] = 0;
-      if (i < nl) {
-        lf_line_meas m;
-        lf_line_blocks Bk;
-        double L[6];
-        h_lmeas(pc, lset[i], &m);
-        for (int k = 0; k < 6; k++) L[k] = ws[WL_L + 6 * i + k];
-        cvl[h] = lf_match_chi2(&X, L, &m, wgt, hd, hub);
-        lf_match_blocks_xp(&X, S.xp, L, &m, wgt, hd, hub, &Bk);
-        double *o = ws + WL_B + (size_t)i * 120;
-        for (int k = 0; k < 36; k++) { o[k] = Bk.V[k]; o[36 + k] = Bk.W[k]; o[78 + k] = Bk.Hpp[k]; }
-        for (int k = 0; k < 6; k++) { o[72 + k] = Bk.bl[k]; o[114 + k] = Bk.bp[k]; double a = lf_fabs(Bk.V[7 * k]); if (a > mxl) mxl = a; }
-      }
-    }
-    currentChi = h_ordered_sum<HP_SLOT>(cvp, np, 0.0);
-    currentChi = h_ordered_sum<HL_SLOT>(cvl, nl, currentChi);
+    p_blocks(M, lc, lset, nl, X, slot, &mxl);  // line landmarks: six lanes each
     __syncthreads();
-    double accH = 0;   // Hpp | bp: accumulator lane a (< 42): points first, then lines
-    if (lane < 42) {
-      accH = h_walk<false>(ws + WP_B + 30 + lane, 72, np, accH);
-      accH = h_walk<false>(ws + WL_B + 78 + lane, 120, nl, accH);
+    if (tid < 42) {   // Hpp | bp: accumulator thread a walks the landmarks in order, points first, then lines
+      double acc = p_walk<false>(ws + WP_B + 30 + tid, 72, np, 0.0);
+      M.hb[tid] = p_walk<false>(lc.wsB + 78 + tid, 120, nl, acc);
     }
-#pragma unroll
-    for (int a = 0; a < 36; a++) Hpp[a] = h_rl64(accH, a);
-#pragma unroll
-    for (int a = 0; a < 6; a++) bp[a] = h_rl64(accH, 36 + a);
     if (it == 0) {
-      double mx = mxl;
+      double mx = p_block_max(M, mxl);
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(mx, o, 64); mx = t > mx ? t : mx; }
-#pragma unroll
-      for (int i = 0; i < 6; i++) if (lf_fabs(Hpp[7 * i]) > mx) mx = lf_fabs(Hpp[7 * i]);
+      for (int i = 0; i < 6; i++) if (lf_fabs(M.hb[7 * i]) > mx) mx = lf_fabs(M.hb[7 * i]);
       lambda = 1e-5 * mx;
       ni = 2;
-    }
+    } else __syncthreads();
     do {
-      double S[36], g[6], dp[6], scale = 0;
-      bool okl = true;
+      double dp[6], scale = 0;
+      int bad = 0;
       for (int h = 0; h < HP_SLOT; h++) {
-        int i = lane + 64 * h;
+        int i = tid + PT_N * h;
         if (i < np) {
           lf_point_blocks Bk;
           const double *o = ws + WP_B + (size_t)i * 72;
@@ -197,56 +143,36 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
           for (int k = 0; k < 18; k++) Bk.W[k] = o[9 + k];
           for (int k = 0; k < 3; k++) Bk.bl[k] = o[27 + k];
           double Vi[9], T[36], u[6];
-          if (!lf_ptmatch_eliminate(&Bk, lambda, Vi, T, u)) okl = false;
+          if (!lf_ptmatch_eliminate(&Bk, lambda, Vi, T, u)) bad = 1;
           for (int k = 0; k < 9; k++) ws[WP_VI + (size_t)i * 9 + k] = Vi[k];
           for (int k = 0; k < 36; k++) ws[WP_TU + (size_t)i * 42 + k] = T[k];
           for (int k = 0; k < 6; k++) ws[WP_TU + (size_t)i * 42 + 36 + k] = u[k];
         }
       }
-      for (int h = 0; h < HL_SLOT; h++) {
-        int i = lane + 64 * h;
-        if (i < nl) {
-          lf_line_blocks Bk;
-          const double *o = ws + WL_B + (size_t)i * 120;
-          for (int k = 0; k < 36; k++) { Bk.V[k] = o[k]; Bk.W[k] = o[36 + k]; }
-          for (int k = 0; k < 6; k++) Bk.bl[k] = o[72 + k];
-          double Vi[36], T[36], u[6];
-          if (!lf_match_eliminate(&Bk, lambda, Vi, T, u)) okl = false;
-          for (int k = 0; k < 36; k++) { ws[WL_VI + (size_t)i * 36 + k] = Vi[k]; ws[WL_TU + (size_t)i * 42 + k] = T[k]; }
-          for (int k = 0; k < 6; k++) ws[WL_TU + (size_t)i * 42 + 36 + k] = u[k];
-        }
+      bad |= p_eliminate(M, lc, nl, lambda);
+      int ok2 = __syncthreads_or(bad) ? 0 : 1;
+      if (tid < 42) {
+        double acc = M.hb[tid];
+        if (tid < 36 && tid % 7 == 0) acc = acc + lambda;
+        acc = p_walk<true>(ws + WP_TU + tid, 42, np, acc);
+        M.sg[tid] = p_walk<true>(lc.wsTU + tid, 42, nl, acc);
       }
-      int ok2 = (__ballot(!okl) == 0) ? 1 : 0;
       __syncthreads();
-      {
-        double acc = accH;
-        if (lane < 36 && lane % 7 == 0) acc = accH + lambda;
-        if (lane < 42) {
-          acc = h_walk<true>(ws + WP_TU + lane, 42, np, acc);
-          acc = h_walk<true>(ws + WL_TU + lane, 42, nl, acc);
-        }
-#pragma unroll
-        for (int a = 0; a < 36; a++) S[a] = h_rl64(acc, a);
-#pragma unroll
-        for (int a = 0; a < 6; a++) g[a] = h_rl64(acc, 36 + a);
-      }
       if (ok2) {
         double A[36];
 #pragma unroll
-        for (int i = 0; i < 36; i++) A[i] = S[i];
+        for (int i = 0; i < 36; i++) A[i] = M.sg[i];
 #pragma unroll
-        for (int i = 0; i < 6; i++) dp[i] = g[i];
-        ok2 = lf_solve6_u(A, dp, 1);   // the pose system is the same in every lane: scalar pivot branches
+        for (int i = 0; i < 6; i++) dp[i] = M.sg[36 + i];
+        ok2 = lf_solve6_u(A, dp, 1);   // the pose system is the same in every thread: scalar pivot branches
       }
       tempChi = DBL_MAX;
       if (ok2) {
         lf_se3_oplus(&X, dp, &Xn);
 #pragma unroll
-        for (int i = 0; i < 6; i++) scale += dp[i] * (lambda * dp[i] + bp[i]);
-        double skp[HP_SLOT], tcp[HP_SLOT], skl[HL_SLOT], tcl[HL_SLOT];
+        for (int i = 0; i < 6; i++) scale += dp[i] * (lambda * dp[i] + M.hb[36 + i]);
         for (int h = 0; h < HP_SLOT; h++) {
-          int i = lane + 64 * h;
-          skp[h] = 0; tcp[h] = 0;
+          int i = tid + PT_N * h;
           if (i < np) {
             lf_point_blocks Bk;
             const double *o = ws + WP_B + (size_t)i * 72;
@@ -256,34 +182,17 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
             for (int k = 0; k < 9; k++) Vi[k] = ws[WP_VI + (size_t)i * 9 + k];
             lf_ptmatch_backsub(&Bk, Vi, dp, dl);
             for (int k = 0; k < 3; k++) { pn[k] = ws[WP_L + 3 * i + k] + dl[k]; ws[WP_LN + 3 * i + k] = pn[k]; s += dl[k] * (lambda * dl[k] + Bk.bl[k]); }
-            skp[h] = s;
-            const double *m = ws + WP_M + 24 * (size_t)i;
-            lf_point_meas pmm; pmm.mn = m; pmm.mo = m + 3; pmm.In = m + 6; pmm.Io = m + 15;
-            tcp[h] = lf_ptmatch_chi2(&Xn, pn, &pmm, hd, hub);
+            lf_point_meas pmm; h_pmeas(ws, i, &pmm);
+            M.red[0][i] = s;
+            M.red[1][i] = lf_ptmatch_chi2(&Xn, pn, &pmm, hd, hub);
           }
         }
-        for (int h = 0; h < HL_SLOT; h++) {
-          int i = lane + 64 * h;
-          skl[h] = 0; tcl[h] = 0;
-          if (i < nl) {
-            lf_line_blocks Bk;
-            const double *o = ws + WL_B + (size_t)i * 120;
-            for (int k = 0; k < 36; k++) Bk.W[k] = o[36 + k];
-            for (int k = 0; k < 6; k++) Bk.bl[k] = o[72 + k];
-            double Vi[36], dl[6], Ln[6], s = 0;
-            for (int k = 0; k < 36; k++) Vi[k] = ws[WL_VI + (size_t)i * 36 + k];
-            lf_match_backsub(&Bk, Vi, dp, dl);
-            for (int k = 0; k < 6; k++) { Ln[k] = ws[WL_L + 6 * i + k] + dl[k]; ws[WL_LN + 6 * i + k] = Ln[k]; s += dl[k] * (lambda * dl[k] + Bk.bl[k]); }
-            skl[h] = s;
-            lf_line_meas m;
-            h_lmeas(pc, lset[i], &m);
-            tcl[h] = lf_match_chi2(&Xn, Ln, &m, wgt, hd, hub);
-          }
-        }
-        scale = h_ordered_sum<HP_SLOT>(skp, np, scale);
-        scale = h_ordered_sum<HL_SLOT>(skl, nl, scale);
-        tempChi = h_ordered_sum<HP_SLOT>(tcp, np, 0.0);
-        tempChi = h_ordered_sum<HL_SLOT>(tcl, nl, tempChi);
+        p_backsub(lc, nl, dp, lambda, M.red[0] + np);
+        __syncthreads();                       // the new line landmarks are in wsLn
+        p_errchi(lc, lset, nl, Xn, lc.wsLn, slot ^ 1, wgt, hd, hub, M.red[1] + np);
+        __syncthreads();
+        scale = p_sum_published(M.red[0], ntot, scale);
+        tempChi = p_sum_published(M.red[1], ntot, 0.0);
       }
       rho = (currentChi - tempChi);
       scale += 1e-3;
@@ -296,8 +205,9 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
         ni = 2;
         currentChi = tempChi;
         X = Xn;
-        for (int h = 0; h < HP_SLOT; h++) { int i = lane + 64 * h; if (i < np) for (int k = 0; k < 3; k++) ws[WP_L + 3 * i + k] = ws[WP_LN + 3 * i + k]; }
-        for (int h = 0; h < HL_SLOT; h++) { int i = lane + 64 * h; if (i < nl) for (int k = 0; k < 6; k++) ws[WL_L + 6 * i + k] = ws[WL_LN + 6 * i + k]; }
+        slot ^= 1;
+        for (int k = tid; k < 3 * np; k += PT_N) ws[WP_L + k] = ws[WP_LN + k];
+        for (int k = tid; k < 6 * nl; k += PT_N) lc.wsL[k] = lc.wsLn[k];
       } else {
         lambda *= ni;
         ni *= 2;
@@ -310,44 +220,62 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
   lf_older_pose_to_tf(&X, tf);
 }
 
-// inlier scan of ALL point and line matches with tf (motion.cpp:680-699 / 783-812)
-__device__ void h_score(const HCtx &pc, int nPt, int nLn, const float *tf, double thr, int *pset, int *npin, int *lset,
+// inlier scan of ALL point and line matches with tf (motion.cpp:680-699 / 783-812): lists ascending, sums in list
+// order (points, then lines); a non-inlier contributes 0.0, which changes neither sum
+__device__ void h_score(HShared &S, const HCtx &pc, int nPt, int nLn, const float *tf, double thr, int *pset, int *npin, int *lset,
                         int *nlin, float *sse_f_out, double *sse_d_out) {
-  const int lane = h_lane();
-  double addp[HP_SLOT], addl[HL_SLOT];
-  u64 mp[HP_SLOT], ml[HL_SLOT];
+  LmShared &M = S.lm;
+  const int tid = threadIdx.x, w = tid >> 6, lane = p_lane(), ntot = nPt + nLn;
+  bool inp[HP_SLOT], inl = false;
+  u64 mp[HP_SLOT], ml;
+#pragma unroll
+  for (int h = 0; h < HP_SLOT; h++) {
+    int i = tid + PT_N * h;
+    double add = 0;
+    inp[h] = false;
+    if (i < nPt) {
+      double m = lf_error_function2(pc.qpts + 4 * (size_t)pc.pq[i], pc.tpts + 4 * (size_t)pc.pt[i], tf, &pc.pm);
+      if (m < thr * thr) { inp[h] = true; add = m; }
+      M.red[0][i] = add;
+    }
+    mp[h] = __ballot(inp[h]);
+    if (lane == 0) S.scnt[h][w] = __popcll(mp[h]);
+  }
+  {
+    double add = 0;
+    if (tid < nLn) {
+      const lf_line_record *q = &pc.query[pc.mq[tid]], *t = &pc.train[pc.mt[tid]];
+      inl = lf_line_inlier(tf, q->A, q->B, t->A, t->B, t->DUa, t->DUb, thr, &add);
+      M.red[0][nPt + tid] = add;
+    }
+    ml = __ballot(inl);
+    if (lane == 0) S.scnt[HP_SLOT][w] = __popcll(ml);
+  }
+  if (tid < 8) M.red[0][ntot + tid] = 0.0;
+  __syncthreads();
   int np = 0, nl = 0;
 #pragma unroll
   for (int h = 0; h < HP_SLOT; h++) {
-    int i = lane + 64 * h;
-    bool in = false;
-    addp[h] = 0;
-    if (i < nPt) {
-      double m = lf_error_function2(pc.qpts + 4 * (size_t)pc.pq[i], pc.tpts + 4 * (size_t)pc.pt[i], tf, &pc.pm);
-      if (m < thr * thr) { in = true; addp[h] = m; }
-    }
-    mp[h] = __ballot(in);
-    if (in) pset[np + __popcll(mp[h] & h_lt())] = i;
-    np += __popcll(mp[h]);
-  }
+    int before = np;
 #pragma unroll
-  for (int h = 0; h < HL_SLOT; h++) {
-    int i = lane + 64 * h;
-    bool in = false;
-    addl[h] = 0;
-    if (i < nLn) {
-      const lf_line_record *q = &pc.query[pc.mq[i]], *t = &pc.train[pc.mt[i]];
-      in = lf_line_inlier(tf, q->A, q->B, t->A, t->B, t->DUa, t->DUb, thr, &addl[h]);
-    }
-    ml[h] = __ballot(in);
-    if (in) lset[nl + __popcll(ml[h] & h_lt())] = i;
-    nl += __popcll(ml[h]);
+    for (int k = 0; k < PW_N; k++) { int c = S.scnt[h][k]; if (k < w) before += c; np += c; }
+    if (inp[h]) pset[before + __popcll(mp[h] & p_lt())] = tid + PT_N * h;
+  }
+  {
+    int before = 0;
+#pragma unroll
+    for (int k = 0; k < PW_N; k++) { int c = S.scnt[HP_SLOT][k]; if (k < w) before += c; nl += c; }
+    if (inl) lset[before + __popcll(ml & p_lt())] = tid;
   }
   float sf = 0; double sd = 0;
+  const int n8 = (ntot + 7) & ~7;
+  for (int l = 0; l < n8; l += 8) {
+    double q[8];
 #pragma unroll
-  for (int h = 0; h < HP_SLOT; h++) { u64 m = mp[h]; while (m) { int l = __builtin_ctzll(m); m &= m - 1; double a = h_rl64(addp[h], l); sf += a; sd += a; } }
+    for (int k = 0; k < 8; k++) q[k] = M.red[0][l + k];
 #pragma unroll
-  for (int h = 0; h < HL_SLOT; h++) { u64 m = ml[h]; while (m) { int l = __builtin_ctzll(m); m &= m - 1; double a = h_rl64(addl[h], l); sf += a; sd += a; } }
+    for (int k = 0; k < 8; k++) { sf += q[k]; sd += q[k]; }
+  }
   *npin = np; *nlin = nl; *sse_f_out = sf; *sse_d_out = sd;
   __syncthreads();
 }
@@ -402,9 +330,9 @@ __device__ bool h_model(const HCtx &pc, const unsigned short *smp, int it, int n
   return true;
 }
 
-__global__ void __launch_bounds__(64) k_pose_hybrid(PairConsts c, PairBuffers b) {
+__global__ void __launch_bounds__(PT_N, 2) k_pose_hybrid(PairConsts c, PairBuffers b) {
   __shared__ HShared S;
-  const int pr = blockIdx.x, lane = h_lane();
+  const int pr = blockIdx.x, tid = threadIdx.x, lane = p_lane();
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];
   lf_pair_result *res = b.results + pr;
   HCtx pc;
@@ -420,6 +348,9 @@ __global__ void __launch_bounds__(64) k_pose_hybrid(PairConsts c, PairBuffers b)
   pc.P = c.P;
   pc.pm = c.pm;
   pc.focal = c.focal;
+  pc.lc.train = pc.train; pc.lc.query = pc.query; pc.lc.mq = pc.mq; pc.lc.mt = pc.mt; pc.lc.P = c.P;
+  pc.lc.wsB = pc.ws + WL_B; pc.lc.wsVi = pc.ws + WL_VI; pc.lc.wsTU = pc.ws + WL_TU;
+  pc.lc.wsL = pc.ws + WL_L; pc.lc.wsLn = pc.ws + WL_LN; pc.lc.wsE = pc.ws + WL_E;
   const lf_params &P = c.P;
   int nLn = b.nmatches[pr], nPt = b.npm[pr];
   const int n_all = nLn, np_all = nPt;
@@ -442,9 +373,9 @@ __global__ void __launch_bounds__(64) k_pose_hybrid(PairConsts c, PairBuffers b)
   { long long d = id_t - id_q; if (d < 0) d = -d; if (d > 50) min_inlier = P.min_matches_loopclose; }   // :631-633
   if (nTot < 3) go = false;
   if (go) {
-    for (int i = lane; i < nTot; i += 64) S.idx[i] = i;
+    for (int i = tid; i < nTot; i += PT_N) S.idx[i] = i;
     __syncthreads();
-    if (lane == 0) {   // sample sequence, serial (partial Fisher-Yates state carries over, :635-658)
+    if (tid == 0) {   // sample sequence, serial (partial Fisher-Yates state carries over, :635-658)
       uint64_t ctr = 0;
       for (int it = 0; it < maxIter; it++) {
         int bpos = 0, left = nTot;
@@ -458,7 +389,7 @@ __global__ void __launch_bounds__(64) k_pose_hybrid(PairConsts c, PairBuffers b)
     }
     __syncthreads();
     int my_cnt = -1, my_it = 1 << 30;
-    for (int it = lane; it < maxIter; it += 64) {   // one hypothesis per lane
+    for (int it = tid; it < maxIter; it += PT_N) {   // one hypothesis per thread
       float tf[16];
       if (!h_model(pc, S.smp, it, nPt, stream, tf)) continue;
       int ncp = 0, ncl = 0;
@@ -475,17 +406,26 @@ __global__ void __launch_bounds__(64) k_pose_hybrid(PairConsts c, PairBuffers b)
       if (score > my_cnt) { my_cnt = score; my_it = it; }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 32; o > 0; o >>= 1) {   // arg-max: score desc, iteration asc -- wavefront, then the four wavefronts
       int oc = __shfl_xor(my_cnt, o, 64), oi = __shfl_xor(my_it, o, 64);
       if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
     }
+    if (lane == 0) { S.lm.wcnt[tid >> 6] = my_cnt; S.lm.wit[tid >> 6] = my_it; }
+    __syncthreads();
+    my_cnt = S.lm.wcnt[0]; my_it = S.lm.wit[0];
+#pragma unroll
+    for (int w = 1; w < PW_N; w++) {
+      int oc = S.lm.wcnt[w], oi = S.lm.wit[w];
+      if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
+    }
+    __syncthreads();
     best_iter = (my_cnt > 0) ? my_it : -1;
     if (best_iter >= 0) {
       float tf_best[16], sse_best = 0;
       double sse_unused;
       h_model(pc, S.smp, best_iter, nPt, stream, tf_best);
       int nbp, nbl;
-      h_score(pc, nPt, nLn, tf_best, thr, S.pset, &nbp, S.lset, &nbl, &sse_best, &sse_unused);
+      h_score(S, pc, nPt, nLn, tf_best, thr, S.pset, &nbp, S.lset, &nbl, &sse_best, &sse_unused);
       if (nbp + nbl >= 3) {                                                                  // :725-728
         float refined_tf[16];
 #pragma unroll
@@ -498,10 +438,10 @@ __global__ void __launch_bounds__(64) k_pose_hybrid(PairConsts c, PairBuffers b)
           float tmp_f; double tmp_sse;
           int ncp, ncl;
           __syncthreads();
-          h_score(pc, nPt, nLn, refined_tf, thr, S.pcur, &ncp, S.lcur, &ncl, &tmp_f, &tmp_sse);
+          h_score(S, pc, nPt, nLn, refined_tf, thr, S.pcur, &ncp, S.lcur, &ncl, &tmp_f, &tmp_sse);
           if (ncp + ncl * lw > nrp + nrl * lw) {
-            for (int i = lane; i < ncp; i += 64) { S.pset[i] = S.pcur[i]; pin[i] = S.pcur[i]; }
-            for (int i = lane; i < ncl; i += 64) { S.lset[i] = S.lcur[i]; lin[i] = S.lcur[i]; }
+            for (int i = tid; i < ncp; i += PT_N) { S.pset[i] = S.pcur[i]; pin[i] = S.pcur[i]; }
+            for (int i = tid; i < ncl; i += PT_N) { S.lset[i] = S.lcur[i]; lin[i] = S.lcur[i]; }
             __syncthreads();
             nrp = ncp; nrl = ncl;
             refined_rmse = lf_sqrt(tmp_sse / (ncp + ncl));
@@ -517,7 +457,7 @@ __global__ void __launch_bounds__(64) k_pose_hybrid(PairConsts c, PairBuffers b)
       }
     }
   }
-  if (lane == 0) {
+  if (tid == 0) {
     for (int i = 0; i < 16; i++) res->T[i] = tf_out[i];
     res->rmse = rmse_out;
     res->valid = valid;
@@ -536,5 +476,5 @@ __global__ void __launch_bounds__(64) k_pose_hybrid(PairConsts c, PairBuffers b)
 
 size_t lf_pair_hybrid_ws_doubles() { return (size_t)W_TOTAL; }
 void lf_pair_hybrid_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t st) {
-  hipLaunchKernelGGL(k_pose_hybrid, dim3(n_pairs), dim3(64), 0, st, c, b);
+  hipLaunchKernelGGL(k_pose_hybrid, dim3(n_pairs), dim3(PT_N), 0, st, c, b);
 }
