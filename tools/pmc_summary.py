@@ -1,4 +1,4 @@
-"""python tools/pmc_summary.py <dir> <tag>: per-kernel FETCH_SIZE / WRITE_SIZE (KB, summed over the dispatches of ONE pass)
+"""python tools/pmc_summary.py <dir> <tag>: per-kernel FETCH_SIZE / WRITE_SIZE (KB per dispatch, averaged over the dispatches of the run)
 from the two rocprofv3 counter_collection CSVs under <dir>/pmc_*, plus the sweep's HBM bytes per launch as JSON."""
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -17,9 +17,9 @@ for c in tot:
                 cnt[k] += 1
 rows = sorted(tot["FETCH_SIZE"], key=lambda k: -(tot["FETCH_SIZE"][k] + tot["WRITE_SIZE"].get(k, 0)))
 with open(os.path.join(d, tag + "_pmc_fetch_write_by_kernel.csv"), "w") as f:
-    f.write("Kernel,Dispatches,FETCH_SIZE_KB_total,WRITE_SIZE_KB_total\n")
+    f.write("Kernel,Dispatches,FETCH_SIZE_KB_per_dispatch,WRITE_SIZE_KB_per_dispatch\n")
     for k in rows:
-        f.write("%s,%d,%.1f,%.1f\n" % (k, cnt[k], tot["FETCH_SIZE"][k], tot["WRITE_SIZE"].get(k, 0.0)))
+        f.write("%s,%d,%.1f,%.1f\n" % (k, cnt[k], tot["FETCH_SIZE"][k] / max(cnt[k], 1), tot["WRITE_SIZE"].get(k, 0.0) / max(cnt[k], 1)))
 sw = [k for k in rows if k.startswith("k_lsd_sweep")]
 if sw:
     k = sw[0]
