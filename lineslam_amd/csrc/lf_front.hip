@@ -958,7 +958,7 @@ __device__ bool f_clipline(int w, int h, long long *px1, long long *py1, long lo
 
 #define MSLD_TILE 64
 __global__ void __launch_bounds__(64) k_describe(FrontConsts c, FrontBuffers b) {
-  __shared__ double G[MSLD_TILE * 36];
+  __shared__ double G[(MSLD_TILE / 2) * 36];   // half a tile of sample columns at a time: 9 KB per wavefront keeps 4 waves per SIMD resident
   const int li = blockIdx.x, f = blockIdx.y, lane = f_lane();
   int nl = b.nlines[f];
   if (nl > c.line_cap) nl = c.line_cap;
@@ -1038,23 +1038,30 @@ __global__ void __launch_bounds__(64) k_describe(FrontConsts c, FrontBuffers b) 
       }
     }
     u64 mv = __ballot(ok);
-    if (ok) {
-      int slot = __popcll(mv & f_lt());
+    const int slot = __popcll(mv & f_lt()), cnt = __popcll(mv);
+    // the valid samples' columns pass through LDS in two halves (slots 0..31, then 32..63); accumulator lane c adds
+    // component c of the samples in slot order
 #pragma unroll
-      for (int k = 0; k < 36; k++) G[slot * 36 + k] = col[k];
-    }
-    f_sync();
-    int cnt = __popcll(mv);
-    if (lane < 36) {
-      double gw = gauss[lane / 4];
-      for (int j = 0; j < cnt; j++) {
-        double v = G[j * 36 + lane] * gw;
-        sum += v;
-        sum2 += v * v;
+    for (int half = 0; half < 2; half++) {
+      const int s0 = half * (MSLD_TILE / 2);
+      if (s0 >= cnt) break;
+      if (ok && slot >= s0 && slot < s0 + MSLD_TILE / 2) {
+#pragma unroll
+        for (int k = 0; k < 36; k++) G[(slot - s0) * 36 + k] = col[k];
       }
+      f_sync();
+      const int m = min(cnt - s0, MSLD_TILE / 2);
+      if (lane < 36) {
+        double gw = gauss[lane / 4];
+        for (int j = 0; j < m; j++) {
+          double v = G[j * 36 + lane] * gw;
+          sum += v;
+          sum2 += v * v;
+        }
+      }
+      f_sync();
     }
     nvalid += cnt;
-    f_sync();
   }
   double *des = R->des;
   if (nvalid == 0) {
