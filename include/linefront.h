@@ -60,7 +60,7 @@ typedef struct lf_params {
   double line_segment_len_thresh; /* 10 px   line_2d_len_thres */
   double line3d_length_thresh;    /* 0.02 m  line_3d_len_thres_m */
   double ratio_of_collinear_pts;  /* 0.6     collin_pts_ratio */
-  int    line_sample_max_num;     /* 100 */
+  int    line_sample_max_num;     /* 100  (at most 103: larger values return LF_ERR_UNSUPPORTED) */
   int    line_sample_min_num;     /* 10  */
   double line_sample_interval;    /* 1   */
   int    line3d_mle_iter_num;     /* 100 */

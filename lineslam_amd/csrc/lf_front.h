@@ -5,7 +5,7 @@
 #include <stdint.h>
 #include "../../include/linefront.h"
 
-#define LF_MAX_SAMPLES 128      // numSmp <= line_sample_max_num (100) -> at most 101 samples
+#define LF_MAX_SAMPLES 104      // numSmp <= line_sample_max_num (100) -> at most 101 samples; 104 keeps the LDS of k_line3d at 10.4 KB (15 wavefronts per CU)
 #define LF_CAND_STRIDE 32       // doubles per candidate in cand_out
 // cand_out layout: [0..2] A  [3..5] B  [6..14] covA  [15..23] covB  [24] numSmp  [25] #valid samples
 //                  [26] #RANSAC inliers  [27] levmar iterations  [28] levmar stop reason
