@@ -39,8 +39,11 @@ struct lf_ctx {
   // pinned staging for the small host arrays of the batched entry points (frame ids, pair lists): the calls
   // stay asynchronous, so that several contexts on different streams can be driven from one host thread
   uint8_t *h_stage = nullptr;
-  hipEvent_t ev_stage_ids = nullptr, ev_stage_pairs = nullptr;
-  bool stage_ids_pending = false, stage_pairs_pending = false;
+#define LF_PAIR_STAGE_SLOTS 4   // pinned staging slots of the pair lists: several pair launches per pass (odometry + loop
+                                // closures, feature matching + hybrid solve) must not make the host wait for the pass
+  hipEvent_t ev_stage_ids = nullptr, ev_stage_pairs[LF_PAIR_STAGE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  bool stage_ids_pending = false, stage_pairs_pending[LF_PAIR_STAGE_SLOTS] = {false, false, false, false};
+  unsigned stage_pairs_next = 0;
   bool hybrid_ready = false;         // hybrid (points + lines) buffers are allocated on first use
   int *d_pm_q = nullptr, *d_pm_t = nullptr, *d_npm = nullptr;
   float *d_pts_stage = nullptr;      // lf_match_node_pair_hybrid staging: 2 x LF_NODE_PT_CAP float4
@@ -375,9 +378,10 @@ int lf_ctx_create(lf_ctx **out, int device, void *hip_stream, int width, int hei
     }
     for (int i = 0; i < 8; i++) if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) { r = fail_hip(c, e, "hipEventCreate"); break; }
     if (r != LF_OK) break;
-    if ((e = hipEventCreateWithFlags(&c->ev_stage_ids, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_stage_pairs, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipHostMalloc((void **)&c->h_stage, (size_t)c->maxB * 16, hipHostMallocDefault)) != hipSuccess) {
+    e = hipEventCreateWithFlags(&c->ev_stage_ids, hipEventDisableTiming);
+    for (int i = 0; i < LF_PAIR_STAGE_SLOTS && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->ev_stage_pairs[i], hipEventDisableTiming);
+    if (e != hipSuccess ||
+        (e = hipHostMalloc((void **)&c->h_stage, (size_t)c->maxB * 8 * (1 + LF_PAIR_STAGE_SLOTS), hipHostMallocDefault)) != hipSuccess) {
       r = fail_hip(c, e, "staging buffers");
       break;
     }
@@ -398,7 +402,7 @@ void lf_ctx_destroy(lf_ctx *c) {
   for (void *p : c->allocs) (void)hipFree(p);
   for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->ev_stage_ids) (void)hipEventDestroy(c->ev_stage_ids);
-  if (c->ev_stage_pairs) (void)hipEventDestroy(c->ev_stage_pairs);
+  for (int i = 0; i < LF_PAIR_STAGE_SLOTS; i++) if (c->ev_stage_pairs[i]) (void)hipEventDestroy(c->ev_stage_pairs[i]);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -663,14 +667,15 @@ static int match_pairs_impl(lf_ctx *c, const int32_t *query_frames, const int32_
       return LF_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   {   // pair lists through the pinned staging area (the caller's arrays may be temporaries)
-    if (c->stage_pairs_pending) HIPCHK(c, hipEventSynchronize(c->ev_stage_pairs));
-    int *hq = (int *)(c->h_stage + (size_t)c->maxB * 8), *ht = hq + c->maxB;
+    const unsigned sl = c->stage_pairs_next++ % LF_PAIR_STAGE_SLOTS;
+    if (c->stage_pairs_pending[sl]) HIPCHK(c, hipEventSynchronize(c->ev_stage_pairs[sl]));
+    int *hq = (int *)(c->h_stage + (size_t)c->maxB * 8 * (1 + sl)), *ht = hq + c->maxB;
     memcpy(hq, query_frames, sizeof(int) * (size_t)n_pairs);
     memcpy(ht, train_frames, sizeof(int) * (size_t)n_pairs);
     HIPCHK(c, hipMemcpyAsync(c->d_pair_q, hq, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_pair_t, ht, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev_stage_pairs, c->stream));
-    c->stage_pairs_pending = true;
+    HIPCHK(c, hipEventRecord(c->ev_stage_pairs[sl], c->stream));
+    c->stage_pairs_pending[sl] = true;
   }
   c->pcn.P = c->params;
   PairBuffers pb = c->pb;
@@ -756,14 +761,15 @@ int lf_feature_match_pairs_device(lf_ctx *c, const uint8_t *d_desc, const int32_
       return LF_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   {   // pair lists through the pinned staging area
-    if (c->stage_pairs_pending) HIPCHK(c, hipEventSynchronize(c->ev_stage_pairs));
-    int *hq = (int *)(c->h_stage + (size_t)c->maxB * 8), *ht = hq + c->maxB;
+    const unsigned sl = c->stage_pairs_next++ % LF_PAIR_STAGE_SLOTS;
+    if (c->stage_pairs_pending[sl]) HIPCHK(c, hipEventSynchronize(c->ev_stage_pairs[sl]));
+    int *hq = (int *)(c->h_stage + (size_t)c->maxB * 8 * (1 + sl)), *ht = hq + c->maxB;
     memcpy(hq, query_frames, sizeof(int) * (size_t)n_pairs);
     memcpy(ht, train_frames, sizeof(int) * (size_t)n_pairs);
     HIPCHK(c, hipMemcpyAsync(c->d_pair_q, hq, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_pair_t, ht, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev_stage_pairs, c->stream));
-    c->stage_pairs_pending = true;
+    HIPCHK(c, hipEventRecord(c->ev_stage_pairs[sl], c->stream));
+    c->stage_pairs_pending[sl] = true;
   }
   PointConsts pc;
   memset(&pc, 0, sizeof pc);
