@@ -11,9 +11,10 @@
  *
  * Execution model: a context owns (or is given) ONE HIP stream.  The *_device entry points only enqueue
  * work on it and return (their small host arrays -- node ids, pair lists -- are copied through pinned
- * staging buffers); the getters (lf_frame_get_*, lf_pair_get_*, lf_get_stage_ms) and the host-pointer
+ * staging buffers; up to four pair-list calls may be pending per context before a call waits for the
+ * oldest one's copy); the getters (lf_frame_get_*, lf_pair_get_*, lf_get_stage_ms) and the host-pointer
  * convenience calls synchronise that stream.  Several contexts on different streams can therefore be
- * driven from one host thread and overlap on the device (bench.py keeps two passes in flight that way).
+ * driven from one host thread and overlap on the device (bench.py keeps four passes in flight that way).
  * A context is not thread-safe; use one per thread.
  */
 #ifndef LINEFRONT_H
