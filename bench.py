@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1147, help="frames per sequence (TUM fr3/cabinet: 1147)")
     ap.add_argument("--unique", type=int, default=16, help="ray-cast poses per sequence (rest: fresh noise)")
