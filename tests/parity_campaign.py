@@ -1,4 +1,7 @@
 import sys, os
+"""python tests/parity_campaign.py  (on the GPU box, from the repo root): randomized whole-chain parity campaign -- six
+seeds x two parameter sets, every frame's LSD output and line records and every pair's pose against the oracle, bit for
+bit.  Test infrastructure (it uses the oracle); not collected by pytest."""
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch
 import _oracle as O
