@@ -498,6 +498,23 @@ __device__ __forceinline__ void d_ordered_sum3(const FV &f, double a, double b, 
 // region2rect + get_theta (lsd.cpp:1517-1604, 1474-1512).  The three weighted sums and the three
 // inertia sums are accumulated in the reference's pixel order: lanes prepare the 64 next operands,
 // a uniform loop adds them one by one.
+// Rectangle angle and axis of region2rect (lsd.cpp:1517-1545): correctly rounded atan2 / sin / cos -- the rectangle's end
+// pixel lies exactly on its end edge, so this is the one place where LSD's output depends on the last bit of libm
+// (DESIGN.md section 3).  Kept OUT OF LINE: its double-double temporaries would otherwise set the register
+// allocation of the whole sweep kernel; it runs once per rectangle.
+__device__ __noinline__ void d_rect_theta(double Ixx, double Iyy, double Ixy, double lambda, double reg_angle, double prec,
+                                          double *theta_out, double *dx_out, double *dy_out) {
+  double t0;
+  lf_dd s0, c0;
+  const bool xx = lf_fabs(Ixx) > lf_fabs(Iyy);
+  const double th = lf_atan2_cr_sc(xx ? lambda - Ixx : Ixy, xx ? Ixy : lambda - Iyy, &t0, &s0, &c0);
+  double theta = th;
+  int flipped = 0;
+  if (d_angle_diff(theta, reg_angle) > prec) { theta += LF_PI; flipped = 1; }
+  double dy, dx;
+  lf_sincos_cr_near(theta, flipped, th, t0, s0, c0, &dy, &dx);   // one double-double sin/cos evaluation serves both
+  *theta_out = theta; *dx_out = dx; *dy_out = dy;
+}
 template <class FV>
 __device__ void d_region2rect(const FV &f, int n, double reg_angle, double prec, double p,
                               int plev, Rect *rec) {
@@ -526,17 +543,8 @@ __device__ void d_region2rect(const FV &f, int n, double reg_angle, double prec,
     d_ordered_sum3<true>(f, txx, tyy, txy, min(64, n - base), Ixx, Iyy, Ixy);
   }
   double lambda = 0.5 * (Ixx + Iyy - lf_sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-  // correctly rounded atan2 / sin / cos here: the rectangle's end pixel lies exactly on its end edge, so this is
-  // the one place where LSD's output depends on the last bit of libm
-  double t0;
-  lf_dd s0, c0;
-  const bool xx = lf_fabs(Ixx) > lf_fabs(Iyy);
-  const double th = lf_atan2_cr_sc(xx ? lambda - Ixx : Ixy, xx ? Ixy : lambda - Iyy, &t0, &s0, &c0);
-  double theta = th;
-  int flipped = 0;
-  if (d_angle_diff(theta, reg_angle) > prec) { theta += LF_PI; flipped = 1; }
-  double dy, dx;
-  lf_sincos_cr_near(theta, flipped, th, t0, s0, c0, &dy, &dx);   // one double-double sin/cos evaluation serves both
+  double theta, dy, dx;
+  d_rect_theta(Ixx, Iyy, Ixy, lambda, reg_angle, prec, &theta, &dx, &dy);
   // extents: max/min over the region including 0 (lsd.cpp:1571-1580); order independent
   double l_min = 0.0, l_max = 0.0, w_min = 0.0, w_max = 0.0;
   for (int base = 0; base < n; base += 64) {
@@ -975,7 +983,7 @@ __device__ bool d_refine(const FV &f, int *reg_size, double reg_angle, double pr
 }
 
 // LineSegmentDetection main loop (lsd.cpp:1996-2053): one wavefront per frame.
-__global__ void __launch_bounds__(64) k_lsd_sweep(LsdConsts c, const LsdConsts *dc, LsdBuffers b) {
+__global__ void __launch_bounds__(64, 3) k_lsd_sweep(LsdConsts c, const LsdConsts *dc, LsdBuffers b) {
   const int fidx = blockIdx.x, lane = lane_id();
   const size_t NM = (size_t)c.N * c.M;
   FrameView f;
