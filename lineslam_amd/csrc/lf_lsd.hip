@@ -240,20 +240,21 @@ __global__ void __launch_bounds__(64) k_seed_scatter(LsdConsts c, LsdBuffers b) 
     bool v = t < total;
     int x = x0 + (v ? t / rows : 0), y = v ? t % rows : 0;
     unsigned int bn = v ? bins[(size_t)x * c.M + y] : LF_BIN_NONE;
-    bool pending = v && bn != LF_BIN_NONE;
-    unsigned int pos = 0xFFFFFFFFu;
-    u64 m;
-    while ((m = __ballot(pending)) != 0) {
-      int leader = __builtin_ctzll(m);
-      unsigned int lb = (unsigned int)rl32((int)bn, leader);
-      bool mine = pending && bn == lb;
-      u64 same = __ballot(mine);
-      unsigned int base = ctr[lb];
-      if (mine) { pos = (base == 0xFFFFFFFFu) ? base : base + (unsigned int)__popcll(same & lanemask_lt()); pending = false; }
-      __syncthreads();   // single wave: orders the LDS read above against the update below
-      if (lane == leader && base != 0xFFFFFFFFu) ctr[lb] = base + (unsigned int)__popcll(same);
-      __syncthreads();
+    const bool has = v && bn != LF_BIN_NONE;
+    // lanes of the same bin, found with one ballot per bin bit (n_bins <= 1024): a lane's position is its bin's
+    // running counter plus its rank among the lanes of that bin in this group of 64 (list order = lane order)
+    u64 same = __ballot(has);
+#pragma unroll
+    for (int bit = 0; bit < 10; bit++) {
+      const u64 bm = __ballot((bn >> bit) & 1u);
+      same &= ((bn >> bit) & 1u) ? bm : ~bm;
     }
+    unsigned int pos = 0xFFFFFFFFu;
+    unsigned int base = has ? ctr[bn] : 0xFFFFFFFFu;
+    if (has && base != 0xFFFFFFFFu) pos = base + (unsigned int)__popcll(same & lanemask_lt());
+    __syncthreads();   // single wave: every lane has read its counter before the bins' first lanes advance them
+    if (has && base != 0xFFFFFFFFu && (same & lanemask_lt()) == 0ull) ctr[bn] = base + (unsigned int)__popcll(same);
+    __syncthreads();
     if (pos != 0xFFFFFFFFu) seeds[pos] = (uint32_t)(y * c.N + x);
   }
 }
