@@ -40,27 +40,39 @@ __device__ __forceinline__ int f_reflect101(int i, int n) {
   if (i >= n) i = 2 * (n - 1) - i;
   return i;
 }
+#define SOBEL_ROWS 4   // output rows per thread: the horizontal passes of an input row serve all the output rows it touches
 __global__ void __launch_bounds__(256) k_sobel5(FrontConsts c, FrontBuffers b) {
-  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y0 = blockIdx.y * SOBEL_ROWS, f = blockIdx.z;
   if (x >= c.W) return;
   const uint8_t *g = b.gray + (size_t)f * b.gray_frame_stride;
   const int kd[5] = {-1, -2, 0, 2, 1}, ks[5] = {1, 4, 6, 4, 1};
-  int sx = 0, sy = 0;
+  int xi[5];
 #pragma unroll
-  for (int j = 0; j < 5; j++) {
-    const uint8_t *row = g + (size_t)f_reflect101(y + j - 2, c.H) * b.gray_row_stride;
-    int rd = 0, rs = 0;
+  for (int i = 0; i < 5; i++) xi[i] = f_reflect101(x + i - 2, c.W);
+  int rd[SOBEL_ROWS + 4], rs[SOBEL_ROWS + 4];      // horizontal derivative / smoothing of input rows y0-2 .. y0+SOBEL_ROWS+1
+#pragma unroll
+  for (int j = 0; j < SOBEL_ROWS + 4; j++) {
+    const uint8_t *row = g + (size_t)f_reflect101(y0 + j - 2, c.H) * b.gray_row_stride;
+    int d = 0, sm = 0;
 #pragma unroll
     for (int i = 0; i < 5; i++) {
-      int v = row[f_reflect101(x + i - 2, c.W)];
-      rd += kd[i] * v;
-      rs += ks[i] * v;
+      int v = row[xi[i]];
+      d += kd[i] * v;
+      sm += ks[i] * v;
     }
-    sx += ks[j] * rd;
-    sy += kd[j] * rs;
+    rd[j] = d; rs[j] = sm;
   }
-  size_t o = ((size_t)f * c.H + y) * c.W + x;
-  *(uint32_t *)&b.gxy[2 * o] = (uint32_t)(uint16_t)(int16_t)sx | ((uint32_t)(uint16_t)(int16_t)sy << 16);
+#pragma unroll
+  for (int r = 0; r < SOBEL_ROWS; r++) {
+    const int y = y0 + r;
+    if (y < c.H) {
+      int sx = 0, sy = 0;
+#pragma unroll
+      for (int j = 0; j < 5; j++) { sx += ks[j] * rd[r + j]; sy += kd[j] * rs[r + j]; }
+      size_t o = ((size_t)f * c.H + y) * c.W + x;
+      *(uint32_t *)&b.gxy[2 * o] = (uint32_t)(uint16_t)(int16_t)sx | ((uint32_t)(uint16_t)(int16_t)sy << 16);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------ point helpers
@@ -1091,7 +1103,7 @@ __global__ void __launch_bounds__(64) k_describe(FrontConsts c, FrontBuffers b) 
 
 // ----------------------------------------------------------------------------------------------
 void lf_front_launch(const FrontConsts &c, const FrontBuffers &b, int B, hipStream_t st) {
-  hipLaunchKernelGGL(k_sobel5, dim3((c.W + 255) / 256, c.H, B), dim3(256), 0, st, c, b);
+  hipLaunchKernelGGL(k_sobel5, dim3((c.W + 255) / 256, (c.H + SOBEL_ROWS - 1) / SOBEL_ROWS, B), dim3(256), 0, st, c, b);
   hipLaunchKernelGGL(k_line3d, dim3(c.cand_cap, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_records, dim3(B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL((k_mle<32, 32, 1>), dim3((c.line_cap + 1) / 2, B), dim3(64), 0, st, c, b);   // 2 lines per wavefront
