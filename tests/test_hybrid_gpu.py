@@ -136,3 +136,41 @@ def test_hybrid_capacity_and_index_errors(built_lib, seq):
     bad = np.full((1, 4), NP, np.int32)
     with pytest.raises(capi.LinefrontError):
         ctx.match_pairs_hybrid_device(q, t, dpts.data_ptr(), NP, bad, bad, np.array([4], np.int32), synth.K_TUM)
+
+
+@pytest.mark.parametrize("npm,nlines", [(255, 41), (256, 0), (257, 80), (400, 3), (511, 41), (512, 200)])
+def test_hybrid_over_point_match_counts(built_lib, seq, npm, nlines):
+    """Point-match counts around the pose kernel's thread slots (256 threads, two point landmarks per thread, 512 at
+    most) with a few, many or no line matches next to them."""
+    ctx, recs, poses, P, ids, pts, dpts = seq
+    from lineslam_amd import capi
+    rng = np.random.default_rng(100 + npm)
+    NB = 700
+    Pw = np.c_[rng.uniform(-1.2, 1.2, NB), rng.uniform(-0.9, 0.9, NB), rng.uniform(1.0, 3.5, NB), np.ones(NB)]
+    Pw = (poses[0] @ Pw.T).T
+    fp = []
+    for f in (0, 1):
+        pc = (np.linalg.inv(poses[f]) @ Pw.T).T
+        pc[:, :3] += rng.normal(0, 0.003, (NB, 3)) * pc[:, 2:3] ** 2 / 4
+        pc = pc.astype(np.float32); pc[:, 3] = 1.0
+        pc[rng.choice(NB, 20, replace=False), 2] = np.nan
+        fp.append(pc)
+    a = rng.choice(NB, npm, replace=False).astype(np.int32)
+    b = a.copy()
+    bad = rng.choice(npm, npm // 6, replace=False)
+    b[bad] = np.roll(b[bad], 1)
+    newer, older = recs[1][:nlines], recs[0][:nlines]
+    ctx2 = capi.Context(640, 480, max_batch=2, params=P)
+    r = ctx2.match_node_pair_hybrid(newer, 21, fp[1], older, 20, fp[0], a, b, synth.K_TUM)
+    if nlines:
+        mq, mt, md, D = O.match_oracle(newer, older, True)
+    else:
+        mq = mt = np.zeros(0, np.int32)
+    stream = (21 << 32) ^ 20 ^ 0x2000000000000000
+    ok, tf, rmse, pinl, linl, dbg = O.pose_hybrid_oracle(older, newer, fp[0], fp[1], a, b, mq, mt, 20, 21, P, stream,
+                                                         focal=synth.K_TUM[0, 0])
+    assert r.n_point_matches == npm and r.n_matches == len(mq)
+    assert bool(r.valid) == ok and np.array_equal(np.array(list(r.T), np.float32).reshape(4, 4), tf)
+    assert np.array_equal(ctx2.pair_point_inliers(0), pinl) and np.array_equal(ctx2.pair_inliers(0), linl)
+    assert np.float32(r.rmse) == np.float32(rmse)
+    ctx2.close()
