@@ -17,15 +17,6 @@
 #include <float.h>
 #include "lf_pose_wg.h"
 
-#define NSLOT (LF_MAX_MATCHES / 64)
-
-__device__ __forceinline__ double p_rl64(double v, int l) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, l);
-  hi = __builtin_amdgcn_readlane(hi, l);
-  return __hiloint2double(hi, lo);
-}
-
 // ------------------------------------------------------------------------------ k_match
 __device__ __forceinline__ double m_pt_line2d(const double *p, const double *l) {   // utils.cpp:1250-1264
   return lf_fabs((l[0] * p[0] + l[1] * p[1] + l[2])) / lf_sqrt(l[0] * l[0] + l[1] * l[1]);

@@ -17,7 +17,7 @@ struct LmShared {                  // LDS state of the LM refinement (per workgr
   double tile[PW_N][10 * 108];    // per wavefront: the Jacobian columns (or W Vi) of the ten matches of a pass
   double wred[PW_N];
   lf_se3 xp[12];                  // X (+) (+-delta e_d): the perturbed poses of the current linearisation
-  int wcnt[PW_N], wit[PW_N], flag;
+  int wcnt[PW_N], wit[PW_N];
 };
 struct PoseCtx {
   const lf_line_record *train, *query;
@@ -47,13 +47,6 @@ __device__ __forceinline__ double p_sum_published(const double *red, int n, doub
 #pragma unroll
     for (int k = 0; k < 8; k++) s += q[k];
   }
-  return s;
-}
-__device__ __forceinline__ double p_ordered_sum(LmShared &S, double v, int n, double s) {
-  p_publish(S.red[0], v, n);
-  __syncthreads();
-  s = p_sum_published(S.red[0], n, s);
-  __syncthreads();
   return s;
 }
 // maximum over the workgroup (order does not matter for a maximum)
