@@ -9,7 +9,7 @@ from lineslam_amd import capi, synth, build
 build.build()
 NF = 10
 bad = 0
-for seed in range(200, 206):
+for seed in range(int(os.environ.get("LF_CAMPAIGN_FIRST", "200")), int(os.environ.get("LF_CAMPAIGN_FIRST", "200")) + int(os.environ.get("LF_CAMPAIGN_SEEDS", "6"))):
     for launch in (False, True):
         g, d, poses = synth.sequence(NF, seed=seed, n_unique=NF)
         if seed % 2: d = d.copy(); d[:, ::3, ::5] = np.nan            # more holes
