@@ -791,21 +791,14 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
 #undef MT
 
 
-template <int G, int RW, int WHICH>
-__global__ void __launch_bounds__(64, 2) k_mle(FrontConsts c, FrontBuffers b) {
+// One 3D line (record lid of frame f) from its RANSAC support points to the refined end points and their covariances:
+// the body of k_mle for a lane group of G lanes with RW row slots (RW / G rows per lane).
+template <int G, int RW>
+__device__ __forceinline__ void f_mle_line(const FrontConsts &c, const FrontBuffers &b, int f, int lid, double *lds, const MleGroup &g) {
   typedef MleCfgT<G, RW> Cfg;
-  __shared__ double lds_rows[Cfg::NG][Cfg::ROWS * MLE_ROW_DOUBLES + MLE_ACC_DOUBLES];
-  const int f = blockIdx.y, wl = f_lane();
-  MleGroup g;
-  g.gbase = (wl / G) * G; g.glane = wl % G;
   const int lane = g.glane;
-  // work lists of k_records: [0] unused, [1] lines with <= 32 support points (two per wavefront), [2] more (one)
-  const int which = WHICH;
-  const int item = blockIdx.x * Cfg::NG + wl / G;
-  if (item >= b.mle_cnt[3 * f + which]) return;
-  const int lid = b.mle_list[((size_t)f * 3 + which) * c.line_cap + item];
   MState S;
-  f_mstate_bind(S, lds_rows[wl / G], Cfg::ROWS);
+  f_mstate_bind(S, lds, Cfg::ROWS);
   const lf_params &P = c.P;
   lf_line_record *R = b.recs + (size_t)f * c.line_cap + lid;
   const int seg = R->seg;
@@ -945,6 +938,27 @@ __global__ void __launch_bounds__(64, 2) k_mle(FrontConsts c, FrontBuffers b) {
     out[27] = (double)nit;
     out[28] = (double)stop;
   }
+}
+
+template <int G, int RW, int WHICH>
+__global__ void __launch_bounds__(64, 2) k_mle(FrontConsts c, FrontBuffers b) {
+  typedef MleCfgT<G, RW> Cfg;
+  __shared__ double lds_rows[Cfg::NG][Cfg::ROWS * MLE_ROW_DOUBLES + MLE_ACC_DOUBLES];
+  const int f = blockIdx.y, wl = f_lane();
+  MleGroup g;
+  g.gbase = (wl / G) * G; g.glane = wl % G;
+  // work lists of k_records: [0] unused, [1] lines with <= 32 support points (two per wavefront), [2] more (one)
+  const int which = WHICH;
+  const int item = blockIdx.x * Cfg::NG + wl / G;
+  if (item >= b.mle_cnt[3 * f + which]) return;
+  const int lid = b.mle_list[((size_t)f * 3 + which) * c.line_cap + item];
+  if constexpr (G == 64 && RW > 64) {
+    // most lines of this list have at most 64 support points: one row per lane, none of the second slot's instructions
+    const int seg = b.recs[(size_t)f * c.line_cap + lid].seg;
+    const int ns = (int)b.cand_out[((size_t)f * c.cand_cap + seg) * LF_CAND_STRIDE + 26];
+    if (ns <= 64) { f_mle_line<64, 64>(c, b, f, lid, lds_rows[0], g); return; }
+  }
+  f_mle_line<G, RW>(c, b, f, lid, lds_rows[wl / G], g);
 }
 
 // ------------------------------------------------------------------------------ getGradient + MSLD
