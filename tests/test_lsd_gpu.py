@@ -90,3 +90,20 @@ def test_nfa_table_equals_direct_evaluation(built_lib, monkeypatch, ang):
         ctx.close()
     for (s1, l1), (s0, l0) in zip(*out):
         assert len(s1) > 50 and np.array_equal(s1, s0) and np.array_equal(l1, l0)
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (33, 17), (130, 9), (16, 16)])
+def test_lsd_tiny_images(built_lib, w, h):
+    """Images smaller than the kernels' tiles and windows (a few scaled rows or columns): still the oracle's output."""
+    from lineslam_amd import capi
+    rng = np.random.default_rng(w * 100 + h)
+    img = np.zeros((h, w), np.uint8)
+    img[:, w // 2:] = 200                                   # one vertical edge
+    img[h // 3:h // 3 + max(2, h // 4), : w // 3] = 120     # and a small block
+    img = np.clip(img.astype(np.int32) + rng.integers(-6, 7, img.shape), 0, 255).astype(np.uint8)
+    ctx = capi.Context(w, h, max_batch=1)
+    segs, labels = ctx.lsd(img)
+    so, lo = O.lsd_oracle(img, 22.5, 0.7, flavour="lf")
+    assert np.array_equal(segs, so)
+    assert np.array_equal(labels.astype(np.int32), lo)
+    ctx.close()
