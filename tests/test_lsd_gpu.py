@@ -107,3 +107,16 @@ def test_lsd_tiny_images(built_lib, w, h):
     assert np.array_equal(segs, so)
     assert np.array_equal(labels.astype(np.int32), lo)
     ctx.close()
+
+
+def test_lsd_large_image(built_lib):
+    """A 1280x720 frame (four times the bench resolution) through the same kernels."""
+    from lineslam_amd import capi, synth
+    g, _, _ = synth.sequence(1, seed=9, w=1280, h=720)
+    ctx = capi.Context(1280, 720, max_batch=1)
+    segs, labels = ctx.lsd(g[0])
+    so, lo = O.lsd_oracle(g[0], 22.5, 0.7, flavour="lf")
+    assert len(so) > 50
+    assert np.array_equal(segs, so)
+    assert np.array_equal(labels.astype(np.int32), lo)
+    ctx.close()
