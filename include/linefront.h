@@ -326,6 +326,35 @@ LF_API int lf_match_node_pair(lf_ctx *ctx, const lf_line_record *newer, int n_ne
                               const lf_line_record *older, int n_older, uint64_t id_older,
                               lf_pair_result *out);
 
+/* ---- callers of the pair solver (HOST functions, no device work) ---------------
+ * The pose graph as GraphManager sees it when it picks comparison candidates: node ids 0 .. n_nodes-1 in
+ * insertion order (vertex id == node id), Node::matchable_ per node (null: all matchable), the edges added so
+ * far (undirected), and GraphManager::keyframe_ids_. */
+typedef struct lf_graph_view {
+  int32_t n_nodes;
+  const uint8_t *matchable;
+  int32_t n_edges;
+  const int32_t *edge_from, *edge_to;
+  int32_t n_keyframes;
+  const int32_t *keyframe_ids;
+} lf_graph_view;
+/* QList<int> GraphManager::getPotentialEdgeTargetsWithDijkstra(new_node, sequential_targets, geodesic_targets,
+ * sampled_targets, predecessor_id, include_predecessor) (src/graph_manager.cpp:204-320): the older nodes the new
+ * node is to be compared with, in the reference's list order (sampled and geodesic picks are pushed to the front,
+ * sequential ones and the predecessor to the back).  geodesic_depth is the ParameterServer value of that name;
+ * the reference's rand() draws come from lf_rand31(rng_seed, rng_stream, 0, 1, ...).  predecessor_id < 0 means
+ * the newest node.  Returns LF_ERR_CAPACITY (with *n_out set) if out_cap is too small. */
+LF_API int lf_candidate_targets(const lf_graph_view *graph, int predecessor_id, int sequential_targets,
+                                int geodesic_targets, int sampled_targets, int geodesic_depth,
+                                int include_predecessor, uint64_t rng_seed, uint64_t rng_stream, int32_t *out_ids,
+                                int out_cap, int *n_out);
+/* Node::vel as GraphManager::addNode sets it (src/graph_manager.cpp:764-784): translation difference of the two
+ * row-major 4x4 double poses (the node itself and the node five ids before it) over |dt|, cast to float. */
+LF_API int lf_instant_velocity(const double *T_new, const double *T_old, double dt, float *vel3);
+/* The constant-velocity edge of Node::matchNodePair (src/node.cpp:1584-1599), used when no transformation was
+ * found and apply_const_vel is set: T = [I | R_older^T (dt vel_older)] in float, row-major 4x4. */
+LF_API int lf_const_velocity_transform(const float *pose_older, const float *vel3, double dt, float *T);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,9 @@ SYMBOLS = {
     "lf_relmotion_lines": (_i, [_vp, _vp, _vp, _i, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _i, _pi]),
     "lf_match_node_pair_hybrid": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, _vp, _i, C.c_uint64, _vp, _i, _vp, _vp, _i,
                                        _vp, _vp]),
+    "lf_candidate_targets": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.c_uint64, C.c_uint64, _vp, _i, _pi]),
+    "lf_instant_velocity": (_i, [_vp, _vp, _d, _vp]),
+    "lf_const_velocity_transform": (_i, [_vp, _vp, _d, _vp]),
 }
 
 
@@ -431,3 +434,47 @@ class Context:
                                                   mq.ctypes.data, mt.ctypes.data, len(mq), Kc.ctypes.data, C.byref(r)),
                   "lf_match_node_pair_hybrid")
         return r
+
+
+# ---- host-side callers of the pair solver (no device work) --------------------------
+class LfGraphView(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("matchable", C.c_void_p), ("n_edges", C.c_int32), ("edge_from", C.c_void_p),
+                ("edge_to", C.c_void_p), ("n_keyframes", C.c_int32), ("keyframe_ids", C.c_void_p)]
+
+
+def candidate_targets(n_nodes, edges, matchable=None, keyframes=(), predecessor_id=-1, sequential_targets=1,
+                      geodesic_targets=2, sampled_targets=2, geodesic_depth=3, include_predecessor=False, rng_seed=0,
+                      rng_stream=0):
+    """GraphManager::getPotentialEdgeTargetsWithDijkstra: ids of the older nodes to compare the new node with."""
+    e = np.ascontiguousarray(np.asarray(edges, np.int32).reshape(-1, 2))
+    ef, et = np.ascontiguousarray(e[:, 0]), np.ascontiguousarray(e[:, 1])
+    kf = np.ascontiguousarray(keyframes, np.int32)
+    mt = None if matchable is None else np.ascontiguousarray(matchable, np.uint8)
+    g = LfGraphView(int(n_nodes), None if mt is None else mt.ctypes.data, len(ef), ef.ctypes.data if len(ef) else None,
+                    et.ctypes.data if len(et) else None, len(kf), kf.ctypes.data if len(kf) else None)
+    out = np.zeros(int(n_nodes) + 1, np.int32)
+    n = C.c_int(0)
+    r = lib().lf_candidate_targets(C.byref(g), int(predecessor_id), int(sequential_targets), int(geodesic_targets),
+                                   int(sampled_targets), int(geodesic_depth), int(bool(include_predecessor)),
+                                   C.c_uint64(rng_seed), C.c_uint64(rng_stream), out.ctypes.data, len(out), C.byref(n))
+    if r != LF_OK:
+        raise LinefrontError(r, "lf_candidate_targets")
+    return out[:n.value].copy()
+
+
+def instant_velocity(T_new, T_old, dt):
+    a, b = np.ascontiguousarray(T_new, np.float64), np.ascontiguousarray(T_old, np.float64)
+    v = np.zeros(3, np.float32)
+    r = lib().lf_instant_velocity(a.ctypes.data, b.ctypes.data, C.c_double(dt), v.ctypes.data)
+    if r != LF_OK:
+        raise LinefrontError(r, "lf_instant_velocity")
+    return v
+
+
+def const_velocity_transform(pose_older, vel, dt):
+    p, v = np.ascontiguousarray(pose_older, np.float32), np.ascontiguousarray(vel, np.float32)
+    T = np.zeros((4, 4), np.float32)
+    r = lib().lf_const_velocity_transform(p.ctypes.data, v.ctypes.data, C.c_double(dt), T.ctypes.data)
+    if r != LF_OK:
+        raise LinefrontError(r, "lf_const_velocity_transform")
+    return T
