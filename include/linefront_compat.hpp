@@ -156,4 +156,20 @@ inline std::vector<int> computeRelativeMotion_Ransac(Context* ctx, const std::ve
   return std::vector<int>(inl.begin(), inl.begin() + n);
 }
 
+// QList<int> GraphManager::getPotentialEdgeTargetsWithDijkstra(const Node* new_node, int sequential_targets,
+// int geodesic_targets, int sampled_targets, int predecessor_id = -1, bool include_predecessor = false)
+// (src/graph_manager.h, graph_manager.cpp:204-320) over a flat view of the pose graph; geodesic_depth is the
+// ParameterServer value, (seed, stream) replace the process-wide rand().
+inline std::vector<int> getPotentialEdgeTargetsWithDijkstra(const lf_graph_view& graph, int sequential_targets,
+                                                            int geodesic_targets, int sampled_targets, int geodesic_depth,
+                                                            int predecessor_id = -1, bool include_predecessor = false,
+                                                            uint64_t seed = 0, uint64_t stream = 0) {
+  std::vector<int32_t> ids((size_t)graph.n_nodes + 1);
+  int n = 0;
+  int r = lf_candidate_targets(&graph, predecessor_id, sequential_targets, geodesic_targets, sampled_targets, geodesic_depth,
+                               include_predecessor ? 1 : 0, seed, stream, ids.data(), (int)ids.size(), &n);
+  if (r != LF_OK) throw Error(r, "lf_candidate_targets");
+  return std::vector<int>(ids.begin(), ids.begin() + n);
+}
+
 }  // namespace lf
