@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(256) k_match(PairConsts c, PairBuffers b) {
   __shared__ int s_pos[512];
   __shared__ double s_val[512];
   __shared__ int s_wbase[4];
+  __shared__ int s_queue[1024], s_qn;   // pairs that passed the direction gate
   const int pr = blockIdx.x, tid = threadIdx.x;
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];
   int n1 = b.nlines[fq], n2 = b.nlines_t[ft];
@@ -59,19 +60,38 @@ __global__ void __launch_bounds__(256) k_match(PairConsts c, PairBuffers b) {
   const double lineDistThresh = adjacent ? 45 : 80, descDiffThresh = adjacent ? 0.85 : 0.7;
   const double lineOverlapThresh = adjacent ? 0 : -1, ratio = 0.7;
   if (n1 == 0 || n2 == 0) { if (tid == 0) b.nmatches[pr] = 0; return; }
-  for (int idx = tid; idx < n1 * n2; idx += 256) {
-    int i = idx / n2, j = idx - i * n2;
-    const lf_line_record *a = &f1[i], *bb = &f2[j];
-    double v = 100;
-    if ((a->r[0] * bb->r[0] + a->r[1] * bb->r[1] > c.cos_angle_thresh) &&
-        (0.25 * m_pt_line2d(a->p, bb->lineEq2d) + 0.25 * m_pt_line2d(a->q, bb->lineEq2d) +
-         0.25 * m_pt_line2d(bb->p, a->lineEq2d) + 0.25 * m_pt_line2d(bb->q, a->lineEq2d) < lineDistThresh) &&
-        (m_overlap(a, bb) > lineOverlapThresh)) {
-      double s = 0;
-      for (int k = 0; k < 72; k++) { double d = a->des[k] - bb->des[k]; s += d * d; }
-      v = lf_sqrt(s);
+  // The cheap direction gate first, for 1024 (query, train) pairs at a time; the pairs that pass are queued in LDS and
+  // the expensive gates (eight fp64 divisions, a square root) and the descriptor distance then run on densely
+  // packed lanes.  Every entry of D is written exactly once, with the value the nested conditions give.
+  for (int base = 0; base < n1 * n2; base += 1024) {
+    if (tid == 0) s_qn = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int idx = base + r * 256 + tid;
+      if (idx < n1 * n2) {
+        const int i = idx / n2, j = idx - i * n2;
+        const lf_line_record *a = &f1[i], *bb = &f2[j];
+        if (a->r[0] * bb->r[0] + a->r[1] * bb->r[1] > c.cos_angle_thresh) s_queue[atomicAdd(&s_qn, 1)] = idx;
+        else D[(size_t)i * n2 + j] = 100;
+      }
     }
-    D[(size_t)i * n2 + j] = v;
+    __syncthreads();
+    const int qn = s_qn;
+    for (int k = tid; k < qn; k += 256) {
+      const int idx = s_queue[k], i = idx / n2, j = idx - i * n2;
+      const lf_line_record *a = &f1[i], *bb = &f2[j];
+      double v = 100;
+      if ((0.25 * m_pt_line2d(a->p, bb->lineEq2d) + 0.25 * m_pt_line2d(a->q, bb->lineEq2d) +
+           0.25 * m_pt_line2d(bb->p, a->lineEq2d) + 0.25 * m_pt_line2d(bb->q, a->lineEq2d) < lineDistThresh) &&
+          (m_overlap(a, bb) > lineOverlapThresh)) {
+        double s = 0;
+        for (int kk = 0; kk < 72; kk++) { double d = a->des[kk] - bb->des[kk]; s += d * d; }
+        v = lf_sqrt(s);
+      }
+      D[(size_t)i * n2 + j] = v;
+    }
+    __syncthreads();
   }
   __syncthreads();
   for (int i = tid; i < 512; i += 256) s_pos[i] = -1;
