@@ -577,6 +577,28 @@ int oracle_mle_line3d(const orpt *pts, int n, int maxIter, double A[3], double B
   return nit;
 }
 
+/* compPt3dCov + the RandomPoint3d ctor for one point (utils.cpp:690-722, lineslam.h:59-81): cov, DU, W_sqrt */
+void oracle_pt_cov(const double pt[3], double focal, const lf_params *P, double cov[9], double DU[9], double Ws[3]) {
+  orpt o;
+  int i;
+  o_comp_pt3d_cov(pt, focal, P, &o);
+  for (i = 0; i < 9; i++) { cov[i] = o.cov[i]; DU[i] = o.DU[i]; }
+  for (i = 0; i < 3; i++) Ws[i] = o.W_sqrt[i];
+}
+
+/* MLEstimateLine3d on caller-supplied support points (the free function of src/line/utils.h; the points'
+ * covariances come from compPt3dCov as at lineslam.cpp:283-285): pts [n][3], AB = the RANSAC line on entry, the
+ * MLE end points on return.  For the golden-vector tests (tests/golden/mle_fixtures.npz).                        */
+int oracle_mle_points(const double *pts, int n, double focal, const lf_params *P, double AB[6], double covA[9],
+                      double covB[9], double info[10]) {
+  orpt *rp = (orpt *)malloc(sizeof(orpt) * (size_t)(n > 0 ? n : 1));
+  int i, nit;
+  for (i = 0; i < n; i++) o_comp_pt3d_cov(pts + 3 * i, focal, P, &rp[i]);
+  nit = oracle_mle_line3d(rp, n, P->line3d_mle_iter_num, AB, AB + 3, covA, covB, info);
+  free(rp);
+  return nit;
+}
+
 /* --------------------------------------------------------------------------------------------
  * Node::detect3DLines after the LSD call (lineslam.cpp:213-357).
  *   segs[nseg][5]        LSD output rows

@@ -273,3 +273,17 @@ def project_to_3d_oracle(kp, depth, K, depth_scaling=1.0, max_keyp=600, flavour=
                                  C.c_int(d.shape[1]), C.c_int(d.shape[0]), C.c_void_p(Kc.ctypes.data), C.c_double(depth_scaling),
                                  C.c_int(max_keyp), C.c_void_p(pts.ctypes.data), C.c_void_p(kept.ctypes.data))
     return pts[:m].copy(), kept[:m].copy()
+
+
+def mle_points_oracle(pts, A0, B0, params, focal=525.0, flavour="lf"):
+    """oracle_mle_points: MLEstimateLine3d + MleLine3dCov on caller-supplied support points.
+    Returns (A, B, covA[3,3], covB[3,3], levmar iterations, info[10])."""
+    lib = oracle_lib(flavour)
+    p = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+    AB = np.concatenate([np.asarray(A0, np.float64), np.asarray(B0, np.float64)])
+    cA, cB, info = np.zeros(9), np.zeros(9), np.zeros(10)
+    lib.oracle_mle_points.restype = C.c_int
+    nit = lib.oracle_mle_points(C.c_void_p(p.ctypes.data), C.c_int(len(p)), C.c_double(focal), C.byref(params),
+                                C.c_void_p(AB.ctypes.data), C.c_void_p(cA.ctypes.data), C.c_void_p(cB.ctypes.data),
+                                C.c_void_p(info.ctypes.data))
+    return AB[:3].copy(), AB[3:].copy(), cA.reshape(3, 3), cB.reshape(3, 3), nit, info

@@ -1,0 +1,56 @@
+"""The C oracle of the pair solver (oracle/pair_oracle.c, which compiles the product's lf_pose.h / lf_linalg.h) against the
+golden vectors of the source-INDEPENDENT restatement (oracle/pose_indep.py -> tests/golden/pose_fixtures.npz): this is what
+pins the shared math to the reference's formulas ("SE(3) parity ... self-referential").  Tolerances are the
+north-star's: 1e-4 rad / 1e-3 m (observed: float rounding of the 4x4, ~1e-7)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _golden as G   # noqa: E402
+import _oracle as O   # noqa: E402
+from lineslam_amd import capi   # noqa: E402  (only for the lf_params layout and defaults)
+
+ROT_TOL, TRANS_TOL = 1e-4, 1e-3
+
+
+def _stream(idq, idt):
+    return ((idq << 32) ^ (idt & 0xFFFFFFFF) ^ 0x2000000000000000) & ((1 << 64) - 1)
+
+
+@pytest.mark.parametrize("flavour", ["ref", "lf"])
+def test_c_oracle_equals_the_independent_restatement(flavour):
+    P = capi.default_params(launch=True)
+    worst_r = worst_t = 0.0
+    for name in G.pose_names():
+        c = G.pose_case(name)
+        ok, tf, rmse, pin, lin, dbg = O.pose_hybrid_oracle(
+            c["train"], c["query"], c["train_pts"], c["query_pts"], c["pm"][:, 0], c["pm"][:, 1], c["lm"][:, 0], c["lm"][:, 1],
+            c["id_train"], c["id_query"], P, _stream(c["id_query"], c["id_train"]), flavour=flavour)
+        assert ok == c["ok"], name
+        if c["best_iter"] < 0 or c["ransac_inliers"] < 3:     # RANSAC never started (:621-624) or found < 3 inliers (:725-728)
+            assert rmse == pytest.approx(1e9) and not ok, name
+            continue
+        assert dbg[0] == c["best_iter"], "%s: RANSAC winner %d vs %d" % (name, dbg[0], c["best_iter"])
+        assert dbg[2] == c["rounds"], name
+        assert list(pin) == list(c["pin"]) and list(lin) == list(c["lin"]), name
+        dr, dt = G.pose_error(tf, c["tf"])
+        worst_r, worst_t = max(worst_r, dr), max(worst_t, dt)
+        assert dr < ROT_TOL and dt < TRANS_TOL, "%s: %.3e rad %.3e m" % (name, dr, dt)
+        assert abs(rmse - c["rmse"]) < 1e-4 * max(1.0, c["rmse"]), name
+    print("worst deviation from the independent restatement: %.2e rad, %.2e m" % (worst_r, worst_t))
+    assert worst_r < 1e-5 and worst_t < 1e-5      # what is actually observed is far inside the budget
+
+
+def test_fixture_motions_are_close_to_ground_truth():
+    """sanity of the fixtures themselves: valid solutions recover the synthetic motion to the noise level"""
+    n = 0
+    for name in G.pose_names():
+        c = G.pose_case(name)
+        if c["ok"] and len(c["lin"]) + len(c["pin"]) >= 20:
+            dr, dt = G.pose_error(c["tf"], c["T_true"])
+            assert dr < 0.02 and dt < 0.03, name
+            n += 1
+    assert n >= 25
