@@ -43,6 +43,20 @@ int main(int argc, char** argv) {
     float T[16], rmse;
     bool ok = newer.getRelativeTransformationTo(&older, &none, T, rmse, inl);
     printf("getRelativeTransformationTo: %d (%zu inliers)\n", ok, inl.size());
+    // the three operators on their own, with the reference's signatures
+    std::vector<lf::DMatch> lm_adj, lm_far, pin, lin;
+    newer.lineMatching(&older, true, &lm_adj);
+    newer.lineMatching(&older, false, &lm_far);
+    printf("lineMatching: adjacent %zu, non-adjacent %zu\n", lm_adj.size(), lm_far.size());
+    float T2[16], rmse2;
+    bool ok2 = lf::getTransform_PtsLines_ransac(&older, &newer, none, lm_adj, pin, lin, T2, rmse2);
+    printf("getTransform_PtsLines_ransac: %d (%zu line inliers) rmse %g\n", ok2, lin.size(), (double)rmse2);
+    for (int r = 0; r < 4; r++) printf("%+.6f %+.6f %+.6f %+.6f\n", T2[4 * r], T2[4 * r + 1], T2[4 * r + 2], T2[4 * r + 3]);
+    float T3[16];
+    for (int i = 0; i < 16; i++) T3[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    lf::getTransformFromHybridMatchesG2O(&older, &newer, none, lin, T3, 10);
+    printf("getTransformFromHybridMatchesG2O from identity:\n");
+    for (int r = 0; r < 4; r++) printf("%+.6f %+.6f %+.6f %+.6f\n", T3[4 * r], T3[4 * r + 1], T3[4 * r + 2], T3[4 * r + 3]);
   } catch (const lf::Error& e) {
     fprintf(stderr, "linefront error: %s\n", e.what());
     return 1;

@@ -39,7 +39,7 @@ typedef enum lf_status {
   LF_ERR_NO_DEVICE = -2,    /* no usable HIP device / kernel image */
   LF_ERR_HIP = -3,          /* a HIP runtime call failed (see lf_last_error) */
   LF_ERR_CAPACITY = -4,     /* a caller- or context-sized buffer was too small */
-  LF_ERR_UNSUPPORTED = -5   /* e.g. algorithm "EDLINES" (binary-only in the reference) */
+  LF_ERR_UNSUPPORTED = -5   /* a parameter value outside what this build supports */
 } lf_status;
 
 /* Mirror of the reference's global `SystemParameters sysPara` (src/line/lineslam.h:215-275,
@@ -111,6 +111,19 @@ typedef struct lf_line_record {
 
 typedef struct lf_ctx lf_ctx;
 
+/* Capacities of a context.  The reference's containers are unbounded std::vectors; the device buffers are not, so
+ * every bound is a context parameter and exceeding one is REPORTED (LF_ERR_CAPACITY from the getter of the frame /
+ * pair concerned, lf_pair_result::overflow), never silently truncated.  lf_caps_init() stores the defaults, which
+ * are also the compiled maxima of this build (larger values: LF_ERR_UNSUPPORTED from lf_ctx_create_caps); smaller
+ * values save device memory. */
+typedef struct lf_caps {
+  int32_t seg_cap;       /* 4096  LSD segments per frame (= candidates examined by the 3D-line stage)           */
+  int32_t line_cap;      /* 512   3D lines (Node::lines) per frame; also the row stride of the all-gather payload */
+  int32_t match_cap;     /* 256   line matches per pair handed to the pose solver                                */
+  int32_t pt_match_cap;  /* 512   point matches per pair handed to the pose solver                               */
+} lf_caps;
+LF_API void lf_caps_init(lf_caps *caps);
+
 LF_API void lf_params_init(lf_params *p);
 LF_API void lf_params_init_launch(lf_params *p);
 LF_API const char *lf_version(void);
@@ -124,6 +137,9 @@ LF_API const char *lf_last_error(const lf_ctx *ctx);   /* text of the last faili
  * (e.g. torch.cuda.current_stream().cuda_stream). */
 LF_API int lf_ctx_create(lf_ctx **out, int device, void *hip_stream, int width, int height,
                          int max_batch, const lf_params *params);
+LF_API int lf_ctx_create_caps(lf_ctx **out, int device, void *hip_stream, int width, int height,
+                              int max_batch, const lf_params *params, const lf_caps *caps);
+LF_API int lf_ctx_get_caps(const lf_ctx *ctx, lf_caps *caps);
 LF_API void lf_ctx_destroy(lf_ctx *ctx);
 LF_API int lf_ctx_set_params(lf_ctx *ctx, const lf_params *params);
 LF_API int lf_ctx_synchronize(lf_ctx *ctx);
@@ -203,7 +219,13 @@ typedef struct lf_pair_result {
   int32_t n_point_matches;    /* all_matches.size()    (0 unless the hybrid entry points are used)         */
   int32_t n_point_inliers;    /* inlier_matches.size()                                                     */
   double information_scale;   /* edge.informationMatrix = I6 * (n_pt_inl + n_ln_inl * weight) / rmse^2 (node.cpp:1533) */
+  int32_t overflow;           /* 0, or a mask of LF_OVF_*: an input of this pair exceeded a context capacity and was cut (the
+                                 getters of the pair then return LF_ERR_CAPACITY; the reference has no such bounds)        */
+  int32_t reserved_;
 } lf_pair_result;
+#define LF_OVF_LINES 1        /* a node of the pair has more than line_cap lines                 */
+#define LF_OVF_MATCHES 2      /* more than match_cap line matches                                */
+#define LF_OVF_PT_MATCHES 4   /* more than pt_match_cap point matches                            */
 
 /* For each pair i: newer = frame slot query_frames[i], older = train_frames[i] of the LAST
  * lf_detect3d_batch_device batch (node ids = the frame_ids given there).  Runs
@@ -218,8 +240,66 @@ LF_API int lf_pair_get_matches(lf_ctx *ctx, int pair, int32_t *query_idx, int32_
                                int cap, int *n_out);
 /* inlier_line_matches as indices into the match list. */
 LF_API int lf_pair_get_inliers(lf_ctx *ctx, int pair, int32_t *match_idx, int cap, int *n_out);
-/* descDiff matrix of pair `pair` (n_query x n_train doubles, 100 = gated out) for parity tests. */
+/* descDiff matrix of pair `pair` (n_query x n_train doubles, 100 = gated out) for parity tests.  The matcher itself
+ * never materialises it; this call evaluates it with a separate kernel for the pair list of the last launch. */
 LF_API int lf_pair_get_descdiff(lf_ctx *ctx, int pair, double *D, size_t cap_doubles, int *n_query, int *n_train);
+
+/* ---- the three operators of the pair path on their own ------------------------------------
+ * unsigned Node::lineMatching(const Node* other, bool adjacentFrame, std::vector<cv::DMatch>* matches) const
+ * (src/node.h:288, src/node.cpp:1619-1694) for a batch of pairs, WITHOUT the pose solve: query = frame slot
+ * query_frames[i] (`this`), train = train_frames[i] (`other`) of the last batch -- or, if d_ext_recs is not NULL, slot
+ * train_frames[i] of that external device-resident map (layout as lf_match_external_device; BASELINE.json config 4: one
+ * query against 256 key frames in one launch).  adjacent: HOST array [n_pairs] of the adjacentFrame argument (0 / 1), or
+ * NULL = derived from the node ids as Node::matchNodePair does (|id difference| <= adjacent_linematch_window,
+ * node.cpp:1505-1507).  Results: lf_pair_get_matches.  Asynchronous. */
+LF_API int lf_line_matching_device(lf_ctx *ctx, const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
+                                   const uint8_t *adjacent, const lf_line_record *d_ext_recs,
+                                   const int32_t *d_ext_nlines, const uint64_t *d_ext_ids, int ext_frames,
+                                   int ext_line_cap);
+/* The same for two nodes in HOST memory -- the exact shape of  unsigned Node::lineMatching(const Node* other, bool
+ * adjacentFrame, std::vector<cv::DMatch>* matches) const : `query` = this, `train` = other; adjacent = 0 / 1, or -1 =
+ * derived from the node ids.  Uploads both line maps into slots 0 / 1, matches, returns the list (cv::DMatch queryIdx,
+ * trainIdx, distance; *n_out = its length, LF_ERR_CAPACITY if > cap).  Synchronous.  Needs max_batch >= 2. */
+LF_API int lf_line_matching_node_pair(lf_ctx *ctx, const lf_line_record *query, int n_query, uint64_t id_query,
+                                      const lf_line_record *train, int n_train, uint64_t id_train, int adjacent,
+                                      int32_t *query_idx, int32_t *train_idx, double *dist, int cap, int *n_out);
+/* bool getTransform_PtsLines_ransac(const Node* train, const Node* query, all_point_matches, all_line_matches,
+ *      pt_inliers&, ln_inliers&, Eigen::Matrix4f& tf, float& rmse)  (src/line/utils.h:147-153, motion.cpp:605-849) for a
+ * batch of pairs with CALLER-SUPPLIED match lists:
+ *   lm_query / lm_train  HOST [n_pairs][lm_cap]: cv::DMatch::queryIdx / trainIdx of the line matches (indices into the
+ *                        newer / older frame's Node::lines);  n_lm HOST [n_pairs]
+ *   d_points .. K        the point side exactly as lf_match_pairs_hybrid_device takes it; d_points == NULL: no point
+ *                        matches (pm_* and n_pm are then ignored)
+ * A count above the context's match_cap / pt_match_cap is LF_ERR_CAPACITY (nothing is launched).  Results:
+ * lf_pair_get_result (valid == the function's return value, T, rmse), lf_pair_get_inliers / _point_inliers (indices
+ * into the lists given here).  Asynchronous. */
+LF_API int lf_solve_pairs_device(lf_ctx *ctx, const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
+                                 const int32_t *lm_query, const int32_t *lm_train, const int32_t *n_lm, int lm_cap,
+                                 const float *d_points, int pt_cap, const int32_t *pm_query, const int32_t *pm_train,
+                                 const int32_t *n_pm, int pm_cap, const double K[9]);
+/* void getTransformFromHybridMatchesG2O(const Node* earlier, const Node* newer, pt_matches, ln_matches,
+ *      Eigen::Matrix4f& transformation_estimate (in: guess, out: result), int iterations)
+ * (src/transformation_estimation.h:21-26, .cpp:218-461) for two nodes in HOST memory: Levenberg-Marquardt over the older
+ * camera's pose and one landmark per match, every match given is used.  T: row-major 4x4, newer -> older, in / out.
+ * pts_*: [n][4] floats (x, y, z, 1) or NULL with n_pts_* = 0.  Synchronous.  Needs max_batch >= 2. */
+LF_API int lf_refine_pair(lf_ctx *ctx, const lf_line_record *newer, int n_newer, const float *pts_newer, int n_pts_newer,
+                          const lf_line_record *older, int n_older, const float *pts_older, int n_pts_older,
+                          const int32_t *lm_query, const int32_t *lm_train, int n_lm, const int32_t *pm_query,
+                          const int32_t *pm_train, int n_pm, const double K[9], float T[16], int iterations);
+/* As lf_match_node_pair, for the two operators above with host-resident nodes: uploads both line maps (and point
+ * arrays) into slots 0 / 1 and calls lf_solve_pairs_device for the one pair; the result is pair 0. */
+LF_API int lf_solve_node_pair(lf_ctx *ctx, const lf_line_record *newer, int n_newer, uint64_t id_newer,
+                              const float *pts_newer, int n_pts_newer, const lf_line_record *older, int n_older,
+                              uint64_t id_older, const float *pts_older, int n_pts_older, const int32_t *lm_query,
+                              const int32_t *lm_train, int n_lm, const int32_t *pm_query, const int32_t *pm_train,
+                              int n_pm, const double K[9], lf_pair_result *out);
+/* void MLEstimateLine3d(RandomLine3d& line, int maxIter) (src/line/utils.h, utils.cpp:980-1050) for n_lines lines in
+ * HOST memory: line i has npts[i] support points pts[pt_offset[i] .. ) (xyz doubles, the RANSAC consensus set
+ * `line.pts`, at most 104 each; their covariances are compPt3dCov(pt, K) as at lineslam.cpp:283-285) and the RANSAC
+ * end points AB_init[i][6].  out[i] receives A, B, covA, covB, DUa, DUb, Wsa, Wsb (the other members are zeroed);
+ * iters[i] (may be NULL) levmar's iteration count.  Synchronous; at most line_cap lines per call. */
+LF_API int lf_mle_lines(lf_ctx *ctx, const double *pts, const int32_t *pt_offset, const int32_t *npts, int n_lines,
+                        const double *AB_init, const double K[9], lf_line_record *out, int32_t *iters);
 
 /* ---- points + lines (BASELINE.json config 3) ------------------------------------------------
  * As lf_match_pairs_device, but getTransform_PtsLines_ransac (motion.cpp:605-849) also receives point
@@ -291,8 +371,9 @@ LF_API int lf_feature_match_pairs_device(lf_ctx *ctx, const uint8_t *d_desc, con
                                          double nn_distance_ratio, int32_t *d_match_q, int32_t *d_match_t,
                                          float *d_match_dist, int32_t *d_nmatch);
 /* lf_match_pairs_hybrid_device with the point matches already on the DEVICE (e.g. straight from
- * lf_feature_match_pairs_device): rows of pm_stride entries, counts above 512 are truncated to the first 512
- * (lf_pair_result::n_point_matches still reports the full count). */
+ * lf_feature_match_pairs_device): rows of pm_stride entries.  A count above pt_match_cap cannot be refused on the host
+ * here: the solver then uses the first pt_match_cap matches, sets LF_OVF_PT_MATCHES in lf_pair_result::overflow, and the
+ * getters of that pair return LF_ERR_CAPACITY (lf_pair_result::n_point_matches reports the full count). */
 LF_API int lf_match_pairs_hybrid_device_pm(lf_ctx *ctx, const int32_t *query_frames, const int32_t *train_frames,
                                            int n_pairs, const float *d_points, int pt_cap, const int32_t *d_pm_query,
                                            const int32_t *d_pm_train, const int32_t *d_n_pm, int pm_stride,

@@ -68,14 +68,16 @@ class Node {
     lf_params p = ctx->params;
     p.line_segment_len_thresh = line2d_len_thres; p.ratio_of_collinear_pts = ratio_of_collinear_pts;
     p.line3d_length_thresh = line_3d_len_thres_m; p.depth_scaling = depth_scaling;
-    check(lf_ctx_set_params(ctx->h, &p), "lf_ctx_set_params");
+    check(lf_ctx_set_params(ctx->h, &p), "lf_ctx_set_params");   // (cheap: the LSD tables are rebuilt only when an lsd_* member changes)
     for (int i = 0; i < 9; i++) this->K[i] = K[i];
-    lines.resize(512);
+    lf_caps caps;
+    check(lf_ctx_get_caps(ctx->h, &caps), "lf_ctx_get_caps");
+    lines.resize((size_t)caps.line_cap);
     int n = 0;
-    int r = lf_detect3d(ctx->h, gray_uchar, gray_stride, depth_float, depth_stride, width, height, K,
-                        (uint64_t)id_, lines.data(), (int)lines.size(), &n);
-    if (r != LF_OK && r != LF_ERR_CAPACITY) throw Error(r, "lf_detect3d");
-    lines.resize(n < 512 ? n : 512);
+    // more lines than the context's line_cap is an error (LF_ERR_CAPACITY), never a silently shortened Node::lines
+    check(lf_detect3d(ctx->h, gray_uchar, gray_stride, depth_float, depth_stride, width, height, K,
+                      (uint64_t)id_, lines.data(), (int)lines.size(), &n), "lf_detect3d");
+    lines.resize((size_t)n);
   }
 
   // Node::matchNodePair (src/node.cpp:1494-1615): valid edge <=> mr.edge.id1 >= 0.
@@ -104,14 +106,13 @@ class Node {
       check(lf_match_node_pair(ctx->h, lines.data(), (int)lines.size(), (uint64_t)id_, older_node->lines.data(),
                                (int)older_node->lines.size(), (uint64_t)older_node->id_, &r), "lf_match_node_pair");
     }
-    std::vector<int32_t> q(256), t(256), inl(256);
-    std::vector<double> d(256);
+    const int mc = (int)lines.size() + 1;              // a match list is never longer than the query's line list
+    std::vector<int32_t> q((size_t)mc), t((size_t)mc), inl((size_t)mc);
+    std::vector<double> d((size_t)mc);
     int n = 0, ni = 0;
-    int s = lf_pair_get_matches(ctx->h, 0, q.data(), t.data(), d.data(), 256, &n);
-    if (s != LF_OK && s != LF_ERR_CAPACITY) throw Error(s, "lf_pair_get_matches");
-    if (n > 256) n = 256;
+    check(lf_pair_get_matches(ctx->h, 0, q.data(), t.data(), d.data(), mc, &n), "lf_pair_get_matches");   // LF_ERR_CAPACITY: > match_cap
     for (int i = 0; i < n; i++) mr.all_line_matches.push_back({q[i], t[i], (float)d[i]});
-    check(lf_pair_get_inliers(ctx->h, 0, inl.data(), 256, &ni), "lf_pair_get_inliers");
+    check(lf_pair_get_inliers(ctx->h, 0, inl.data(), mc, &ni), "lf_pair_get_inliers");
     for (int i = 0; i < ni; i++) mr.inlier_line_matches.push_back(mr.all_line_matches[inl[i]]);
     mr.rmse = r.rmse;
     for (int i = 0; i < 16; i++) { mr.ransac_trafo[i] = mr.final_trafo[i] = r.T[i]; mr.edge.transform[i] = r.T[i]; }
@@ -121,11 +122,17 @@ class Node {
     return mr;
   }
 
-  // Node::lineMatching (src/node.cpp:1619-1694): appends to *matches, returns matches->size()
-  unsigned lineMatching(const Node* other, bool /*adjacentFrame: derived from the node ids as matchNodePair does*/,
-                        std::vector<DMatch>* matches) const {
-    MatchingResult mr = matchNodePair(other);
-    matches->insert(matches->end(), mr.all_line_matches.begin(), mr.all_line_matches.end());
+  // Node::lineMatching (src/node.cpp:1619-1694): the matcher alone (no pose solve), with the reference's adjacentFrame
+  // argument selecting the threshold set (45 px / 0.85 / overlap > 0  vs  80 px / 0.7 / -1, :1622-1635); appends to
+  // *matches, returns matches->size()
+  unsigned lineMatching(const Node* other, bool adjacentFrame, std::vector<DMatch>* matches) const {
+    std::vector<int32_t> q(lines.size() + 1), t(lines.size() + 1);
+    std::vector<double> d(lines.size() + 1);
+    int n = 0;
+    check(lf_line_matching_node_pair(ctx->h, lines.data(), (int)lines.size(), (uint64_t)id_, other->lines.data(),
+                                     (int)other->lines.size(), (uint64_t)other->id_, adjacentFrame ? 1 : 0, q.data(), t.data(),
+                                     d.data(), (int)q.size(), &n), "lf_line_matching_node_pair");
+    for (int i = 0; i < n; i++) matches->push_back({q[i], t[i], (float)d[i]});
     return (unsigned)matches->size();
   }
 
@@ -141,6 +148,57 @@ class Node {
     return mr.edge.id1 >= 0;
   }
 };
+
+// bool getTransform_PtsLines_ransac(const Node* trainNode, const Node* queryNode, const std::vector<cv::DMatch> all_point_matches,
+//      const std::vector<cv::DMatch> all_line_matches, std::vector<cv::DMatch>& output_point_inlier_matches,
+//      std::vector<cv::DMatch>& output_line_inlier_matches, Eigen::Matrix4f& ransac_tf, float& inlier_rmse)
+// (src/line/utils.h:147-153, motion.cpp:605-849): the caller supplies BOTH match lists; ransac_tf row-major, query -> train.
+inline bool getTransform_PtsLines_ransac(const Node* trainNode, const Node* queryNode, const std::vector<DMatch>& all_point_matches,
+                                         const std::vector<DMatch>& all_line_matches, std::vector<DMatch>& output_point_inlier_matches,
+                                         std::vector<DMatch>& output_line_inlier_matches, float ransac_tf[16], float& inlier_rmse) {
+  std::vector<int32_t> lq, lt, pq, pt;
+  for (const DMatch& m : all_line_matches) { lq.push_back(m.queryIdx); lt.push_back(m.trainIdx); }
+  for (const DMatch& m : all_point_matches) { pq.push_back(m.queryIdx); pt.push_back(m.trainIdx); }
+  lf_pair_result r;
+  lf_ctx* h = queryNode->ctx->h;
+  check(lf_solve_node_pair(h, queryNode->lines.data(), (int)queryNode->lines.size(), (uint64_t)queryNode->id_,
+                           queryNode->feature_locations_3d_.empty() ? nullptr : queryNode->feature_locations_3d_[0].data(),
+                           (int)queryNode->feature_locations_3d_.size(), trainNode->lines.data(), (int)trainNode->lines.size(),
+                           (uint64_t)trainNode->id_,
+                           trainNode->feature_locations_3d_.empty() ? nullptr : trainNode->feature_locations_3d_[0].data(),
+                           (int)trainNode->feature_locations_3d_.size(), lq.data(), lt.data(), (int)lq.size(), pq.data(), pt.data(),
+                           (int)pq.size(), queryNode->K, &r), "lf_solve_node_pair");
+  std::vector<int32_t> li(lq.size() + 1), pi(pq.size() + 1);
+  int nl = 0, np = 0;
+  check(lf_pair_get_inliers(h, 0, li.data(), (int)li.size(), &nl), "lf_pair_get_inliers");
+  output_line_inlier_matches.clear();
+  for (int i = 0; i < nl; i++) output_line_inlier_matches.push_back(all_line_matches[li[i]]);
+  output_point_inlier_matches.clear();
+  if (!pq.empty()) {
+    check(lf_pair_get_point_inliers(h, 0, pi.data(), (int)pi.size(), &np), "lf_pair_get_point_inliers");
+    for (int i = 0; i < np; i++) output_point_inlier_matches.push_back(all_point_matches[pi[i]]);
+  }
+  for (int i = 0; i < 16; i++) ransac_tf[i] = r.T[i];
+  inlier_rmse = r.rmse;
+  return r.valid != 0;
+}
+
+// void getTransformFromHybridMatchesG2O(const Node* earlier_node, const Node* newer_node, const std::vector<cv::DMatch>& pt_matches,
+//      const std::vector<cv::DMatch>& ln_matches, Eigen::Matrix4f& transformation_estimate, int iterations = 10)
+// (src/transformation_estimation.h:21-26): transformation_estimate is the start value on entry and the result on return.
+inline void getTransformFromHybridMatchesG2O(const Node* earlier_node, const Node* newer_node, const std::vector<DMatch>& pt_matches,
+                                             const std::vector<DMatch>& ln_matches, float transformation_estimate[16],
+                                             int iterations = 10) {
+  std::vector<int32_t> lq, lt, pq, pt;
+  for (const DMatch& m : ln_matches) { lq.push_back(m.queryIdx); lt.push_back(m.trainIdx); }
+  for (const DMatch& m : pt_matches) { pq.push_back(m.queryIdx); pt.push_back(m.trainIdx); }
+  check(lf_refine_pair(newer_node->ctx->h, newer_node->lines.data(), (int)newer_node->lines.size(),
+                       newer_node->feature_locations_3d_.empty() ? nullptr : newer_node->feature_locations_3d_[0].data(),
+                       (int)newer_node->feature_locations_3d_.size(), earlier_node->lines.data(), (int)earlier_node->lines.size(),
+                       earlier_node->feature_locations_3d_.empty() ? nullptr : earlier_node->feature_locations_3d_[0].data(),
+                       (int)earlier_node->feature_locations_3d_.size(), lq.data(), lt.data(), (int)lq.size(), pq.data(), pt.data(),
+                       (int)pq.size(), newer_node->K, transformation_estimate, iterations), "lf_refine_pair");
+}
 
 // std::vector<int> computeRelativeMotion_Ransac(std::vector<RandomLine3d> a, std::vector<RandomLine3d> b, cv::Mat& Ro,
 // cv::Mat& to) (src/line/utils.h:132, motion.cpp:367-526): a[i] <-> b[i]; Ro (3x3 row-major) / to untouched when the

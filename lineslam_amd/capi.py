@@ -93,6 +93,16 @@ SYMBOLS = {
     "lf_candidate_targets": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.c_uint64, C.c_uint64, _vp, _i, _pi]),
     "lf_instant_velocity": (_i, [_vp, _vp, _d, _vp]),
     "lf_const_velocity_transform": (_i, [_vp, _vp, _d, _vp]),
+    "lf_caps_init": (None, [_vp]),
+    "lf_ctx_create_caps": (_i, [C.POINTER(_vp), _i, _vp, _i, _i, _i, C.POINTER(LfParams), _vp]),
+    "lf_ctx_get_caps": (_i, [_vp, _vp]),
+    "lf_line_matching_device": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i]),
+    "lf_solve_pairs_device": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "lf_refine_pair": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i]),
+    "lf_solve_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, _vp, _i, C.c_uint64, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
+                                _vp, _vp]),
+    "lf_mle_lines": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "lf_line_matching_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, C.c_uint64, _i, _vp, _vp, _vp, _i, _pi]),
 }
 
 
@@ -109,7 +119,22 @@ class LfPairResult(C.Structure):
     _fields_ = [("T", C.c_float * 16), ("rmse", C.c_float), ("valid", C.c_int32), ("n_matches", C.c_int32),
                 ("n_inliers", C.c_int32), ("id_older", C.c_int32), ("id_newer", C.c_int32),
                 ("ransac_best_iter", C.c_int32), ("refine_rounds", C.c_int32), ("n_point_matches", C.c_int32),
-                ("n_point_inliers", C.c_int32), ("information_scale", C.c_double)]
+                ("n_point_inliers", C.c_int32), ("information_scale", C.c_double), ("overflow", C.c_int32),
+                ("reserved_", C.c_int32)]
+
+
+LF_OVF_LINES, LF_OVF_MATCHES, LF_OVF_PT_MATCHES = 1, 2, 4
+
+
+class LfCaps(C.Structure):
+    """struct lf_caps: capacities of a context (defaults = the compiled maxima)."""
+    _fields_ = [("seg_cap", C.c_int32), ("line_cap", C.c_int32), ("match_cap", C.c_int32), ("pt_match_cap", C.c_int32)]
+
+
+def default_caps():
+    k = LfCaps()
+    lib().lf_caps_init(C.byref(k))
+    return k
 
 
 # numpy view of struct lf_line_record (1040 bytes)
@@ -152,15 +177,18 @@ def default_params(launch=False):
 class Context:
     """RAII wrapper of lf_ctx: one HIP stream + device buffers for batches of <= max_batch frames."""
 
-    def __init__(self, width, height, max_batch=1, params=None, device=0, stream=None):
+    def __init__(self, width, height, max_batch=1, params=None, device=0, stream=None, caps=None):
         self._h = _vp()
         self.params = params if params is not None else default_params()
         self.width, self.height, self.max_batch = width, height, max_batch
-        r = lib().lf_ctx_create(C.byref(self._h), device, _vp(stream) if stream else None, width,
-                                height, max_batch, C.byref(self.params))
+        r = lib().lf_ctx_create_caps(C.byref(self._h), device, _vp(stream) if stream else None, width,
+                                     height, max_batch, C.byref(self.params), C.byref(caps) if caps is not None else None)
         if r != LF_OK:
             self._h = _vp()
-            raise LinefrontError(r, "lf_ctx_create")
+            raise LinefrontError(r, "lf_ctx_create_caps")
+        self.caps = LfCaps()
+        lib().lf_ctx_get_caps(self._h, C.byref(self.caps))
+        self.line_cap = self.caps.line_cap
         n, m = C.c_int(), C.c_int()
         lib().lf_lsd_dims(self._h, C.byref(n), C.byref(m))
         self.N, self.M = n.value, m.value
@@ -250,7 +278,7 @@ class Context:
                   "lf_frame_get_lines")
         return recs[:n.value].copy()
 
-    def frame_candidates(self, frame, cap=1024):
+    def frame_candidates(self, frame, cap=4096):
         flags = np.zeros(cap, np.int32)
         info = np.zeros((cap, CAND_STRIDE), np.float64)
         n = C.c_int()
@@ -350,17 +378,112 @@ class Context:
                                                         int(pt_cap), int(d_pm_q), int(d_pm_t), int(d_npm), int(pm_stride),
                                                         Kc.ctypes.data), "lf_match_pairs_hybrid_device_pm")
 
-    def pair_point_inliers(self, pair, cap=512):
+    def pair_point_inliers(self, pair, cap=512, allow_overflow=False):
         m = np.zeros(cap, np.int32)
         n = C.c_int()
         self._chk(lib().lf_pair_get_point_inliers(self._h, pair, m.ctypes.data, cap, C.byref(n)),
-                  "lf_pair_get_point_inliers")
+                  "lf_pair_get_point_inliers", ok=(LF_OK, LF_ERR_CAPACITY) if allow_overflow else (LF_OK,))
         return m[:n.value].copy()
 
-    def pair_result(self, pair):
+    def pair_result(self, pair, allow_overflow=False):
+        """lf_pair_result of a pair.  An input of the pair that exceeded a context capacity is an error
+        (LF_ERR_CAPACITY) unless allow_overflow: then the record is returned with its `overflow` mask set."""
         r = LfPairResult()
-        self._chk(lib().lf_pair_get_result(self._h, pair, C.byref(r)), "lf_pair_get_result")
+        self._chk(lib().lf_pair_get_result(self._h, pair, C.byref(r)), "lf_pair_get_result",
+                  ok=(LF_OK, LF_ERR_CAPACITY) if allow_overflow else (LF_OK,))
         return r
+
+    # ---- the operators of the pair path on their own (SURVEY.md 8b) ---------------------------
+    def line_matching_device(self, query_frames, train_frames, adjacent=None, ext=None):
+        """Node::lineMatching alone for a batch of pairs (async).  adjacent: per-pair adjacentFrame flags or None
+        (derived from the node ids); ext = (recs_ptr, nlines_ptr, ids_ptr, frames, line_cap) of an external map."""
+        q = np.ascontiguousarray(query_frames, np.int32)
+        t = np.ascontiguousarray(train_frames, np.int32)
+        adj = None if adjacent is None else np.ascontiguousarray(adjacent, np.uint8)
+        e = ext or (None, None, None, 0, 0)
+        self._chk(lib().lf_line_matching_device(self._h, q.ctypes.data, t.ctypes.data, len(q),
+                                                adj.ctypes.data if adj is not None else None, _vp(e[0]) if e[0] else None,
+                                                _vp(e[1]) if e[1] else None, _vp(e[2]) if e[2] else None, int(e[3]), int(e[4])),
+                  "lf_line_matching_device")
+
+    def line_matching_node_pair(self, query_recs, id_query, train_recs, id_train, adjacent=None, cap=256):
+        """Node::lineMatching(other, adjacentFrame, &matches) for two host-resident nodes -> (queryIdx, trainIdx, distance)."""
+        a, b = np.ascontiguousarray(query_recs), np.ascontiguousarray(train_recs)
+        q, t, d = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+        n = C.c_int()
+        self._chk(lib().lf_line_matching_node_pair(self._h, a.ctypes.data, len(a), int(id_query), b.ctypes.data, len(b),
+                                                   int(id_train), -1 if adjacent is None else int(bool(adjacent)),
+                                                   q.ctypes.data, t.ctypes.data, d.ctypes.data, cap, C.byref(n)),
+                  "lf_line_matching_node_pair")
+        return q[:n.value].copy(), t[:n.value].copy(), d[:n.value].copy()
+
+    def solve_pairs_device(self, query_frames, train_frames, lm_query, lm_train, n_lm, d_points_ptr=0, pt_cap=0,
+                           pm_query=None, pm_train=None, n_pm=None, K=None):
+        """getTransform_PtsLines_ransac for a batch of pairs with caller-supplied match lists (async)."""
+        q = np.ascontiguousarray(query_frames, np.int32)
+        t = np.ascontiguousarray(train_frames, np.int32)
+        a, b = np.ascontiguousarray(lm_query, np.int32), np.ascontiguousarray(lm_train, np.int32)
+        n = np.ascontiguousarray(n_lm, np.int32)
+        assert a.shape == b.shape and a.ndim == 2 and a.shape[0] == len(q) == len(n)
+        Kc = np.ascontiguousarray(K if K is not None else np.eye(3), np.float64).reshape(9)
+        if d_points_ptr:
+            pa, pb = np.ascontiguousarray(pm_query, np.int32), np.ascontiguousarray(pm_train, np.int32)
+            pn = np.ascontiguousarray(n_pm, np.int32)
+            assert pa.shape == pb.shape and pa.ndim == 2 and pa.shape[0] == len(q) == len(pn)
+            args = (int(d_points_ptr), int(pt_cap), pa.ctypes.data, pb.ctypes.data, pn.ctypes.data, pa.shape[1])
+        else:
+            args = (None, 0, None, None, None, 0)
+        self._chk(lib().lf_solve_pairs_device(self._h, q.ctypes.data, t.ctypes.data, len(q), a.ctypes.data, b.ctypes.data,
+                                              n.ctypes.data, a.shape[1], *args, Kc.ctypes.data), "lf_solve_pairs_device")
+
+    def solve_node_pair(self, newer_recs, id_newer, older_recs, id_older, lm_query, lm_train, newer_pts=None, older_pts=None,
+                        pm_query=(), pm_train=(), K=None):
+        """getTransform_PtsLines_ransac for two host-resident nodes with caller-supplied matches -> LfPairResult (pair 0)."""
+        a, b = np.ascontiguousarray(newer_recs), np.ascontiguousarray(older_recs)
+        pa = np.ascontiguousarray(newer_pts if newer_pts is not None else np.zeros((0, 4)), np.float32).reshape(-1, 4)
+        pb = np.ascontiguousarray(older_pts if older_pts is not None else np.zeros((0, 4)), np.float32).reshape(-1, 4)
+        lq, lt = np.ascontiguousarray(lm_query, np.int32), np.ascontiguousarray(lm_train, np.int32)
+        mq, mt = np.ascontiguousarray(pm_query, np.int32), np.ascontiguousarray(pm_train, np.int32)
+        Kc = np.ascontiguousarray(K if K is not None else np.eye(3), np.float64).reshape(9)
+        r = LfPairResult()
+        self._chk(lib().lf_solve_node_pair(self._h, a.ctypes.data, len(a), int(id_newer), pa.ctypes.data if len(pa) else None,
+                                           len(pa), b.ctypes.data, len(b), int(id_older), pb.ctypes.data if len(pb) else None,
+                                           len(pb), lq.ctypes.data if len(lq) else None, lt.ctypes.data if len(lt) else None,
+                                           len(lq), mq.ctypes.data if len(mq) else None, mt.ctypes.data if len(mt) else None,
+                                           len(mq), Kc.ctypes.data, C.byref(r)), "lf_solve_node_pair")
+        return r
+
+    def refine_pair(self, newer_recs, older_recs, lm_query, lm_train, T, iterations, newer_pts=None, older_pts=None,
+                    pm_query=(), pm_train=(), K=None):
+        """getTransformFromHybridMatchesG2O for two host-resident nodes: returns the refined 4x4 float transform."""
+        a, b = np.ascontiguousarray(newer_recs), np.ascontiguousarray(older_recs)
+        pa = np.ascontiguousarray(newer_pts if newer_pts is not None else np.zeros((0, 4)), np.float32).reshape(-1, 4)
+        pb = np.ascontiguousarray(older_pts if older_pts is not None else np.zeros((0, 4)), np.float32).reshape(-1, 4)
+        lq, lt = np.ascontiguousarray(lm_query, np.int32), np.ascontiguousarray(lm_train, np.int32)
+        mq, mt = np.ascontiguousarray(pm_query, np.int32), np.ascontiguousarray(pm_train, np.int32)
+        Kc = np.ascontiguousarray(K if K is not None else np.eye(3), np.float64).reshape(9)
+        Tc = np.ascontiguousarray(T, np.float32).reshape(16).copy()
+        self._chk(lib().lf_refine_pair(self._h, a.ctypes.data, len(a), pa.ctypes.data if len(pa) else None, len(pa),
+                                       b.ctypes.data, len(b), pb.ctypes.data if len(pb) else None, len(pb),
+                                       lq.ctypes.data if len(lq) else None, lt.ctypes.data if len(lt) else None, len(lq),
+                                       mq.ctypes.data if len(mq) else None, mt.ctypes.data if len(mt) else None, len(mq),
+                                       Kc.ctypes.data, Tc.ctypes.data, int(iterations)), "lf_refine_pair")
+        return Tc.reshape(4, 4)
+
+    def mle_lines(self, pts_list, AB_init, K):
+        """MLEstimateLine3d for a list of support-point arrays ([n_i,3]) and RANSAC end points [n,6] -> (records, iterations)."""
+        n = len(pts_list)
+        off = np.zeros(n, np.int32)
+        cnt = np.array([len(p) for p in pts_list], np.int32)
+        off[1:] = np.cumsum(cnt)[:-1]
+        allp = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float64).reshape(-1, 3) for p in pts_list]))
+        ab = np.ascontiguousarray(AB_init, np.float64).reshape(n, 6)
+        Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+        out = np.zeros(n, REC_DTYPE)
+        it = np.zeros(n, np.int32)
+        self._chk(lib().lf_mle_lines(self._h, allp.ctypes.data, off.ctypes.data, cnt.ctypes.data, n, ab.ctypes.data,
+                                     Kc.ctypes.data, out.ctypes.data, it.ctypes.data), "lf_mle_lines")
+        return out, it
 
     def pair_matches(self, pair, cap=256):
         q, t, d = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float64)

@@ -26,6 +26,7 @@ struct lf_ctx {
   bool own_stream = false;
   int W = 0, H = 0, maxB = 0;
   lf_params params;
+  lf_caps caps;
   LsdConsts lc;
   LsdBuffers lb;
   std::vector<void *> allocs;
@@ -48,6 +49,9 @@ struct lf_ctx {
   int *d_pm_q = nullptr, *d_pm_t = nullptr, *d_npm = nullptr;
   float *d_pts_stage = nullptr;      // lf_match_node_pair_hybrid staging: 2 x LF_NODE_PT_CAP float4
   bool last_hybrid = false;
+  PairBuffers last_pb;               // the buffers of the last pair launch (train side may be an external map)
+  unsigned char *d_adjacent = nullptr;   // [maxB] adjacentFrame flags of lf_line_matching_device
+  double *d_descdiff = nullptr;      // lf_pair_get_descdiff scratch (line_cap^2 doubles), allocated on first use
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint8_t *d_gray_stage = nullptr;   // staging for the host-pointer convenience entry points
   float *d_depth_stage = nullptr;
@@ -131,6 +135,10 @@ void lf_params_init(lf_params *p) {
   p->pt2line3d_dist_relmotion = 0.05;     // :188
   p->line3d_angle_relmotion = 10;         // :189
 }
+void lf_caps_init(lf_caps *k) {
+  if (!k) return;
+  k->seg_cap = 4096; k->line_cap = LF_MATCH_LINE_CAP; k->match_cap = LF_MAX_MATCHES; k->pt_match_cap = LF_MAX_PT_MATCHES;
+}
 void lf_params_init_launch(lf_params *p) {
   lf_params_init(p);
   if (!p) return;
@@ -145,7 +153,7 @@ const char *lf_status_str(int s) {
     case LF_ERR_NO_DEVICE: return "no usable gfx950 HIP device (this library has no CPU path)";
     case LF_ERR_HIP: return "HIP runtime error";
     case LF_ERR_CAPACITY: return "buffer capacity exceeded";
-    case LF_ERR_UNSUPPORTED: return "unsupported";
+    case LF_ERR_UNSUPPORTED: return "unsupported parameter value for this build";
     default: return "unknown status";
   }
 }
@@ -214,7 +222,7 @@ static int build_lsd_consts(lf_ctx *c) {
     lc.log10p[k] = log10(pk);
     pk /= 2.0;
   }
-  lc.seg_cap = 4096;
+  lc.seg_cap = c->caps.seg_cap;
   {
     // wavefronts per frame in the seed sweep: 0 = automatic (speculative 8-wave sweep for small batches,
     // where per-frame latency is what matters; sequential 1-wave sweep once >= 1 frame per SIMD is in flight)
@@ -320,12 +328,15 @@ static int alloc_lsd(lf_ctx *c) {
   memset(&fc, 0, sizeof fc);
   memset(&fb, 0, sizeof fb);
   fc.W = c->W; fc.H = c->H;
-  fc.cand_cap = 1024; fc.line_cap = 512; fc.seg_cap = lc.seg_cap;
+  fc.cand_cap = lc.seg_cap; fc.line_cap = c->caps.line_cap; fc.seg_cap = lc.seg_cap;   // every LSD segment is examined
+  fc.pts_slots = fc.line_cap;
   ALLOC(c, fb.gxy, B * (size_t)c->W * c->H * 2);
   ALLOC(c, c->d_frame_ids, B);
   ALLOC(c, fb.cand_flag, B * fc.cand_cap);
   ALLOC(c, fb.cand_out, B * (size_t)fc.cand_cap * LF_CAND_STRIDE);
-  ALLOC(c, fb.pts, B * (size_t)fc.cand_cap * LF_MAX_SAMPLES * 3);
+  ALLOC(c, fb.pts, B * (size_t)fc.pts_slots * LF_MAX_SAMPLES * 3);
+  ALLOC(c, fb.pts_cnt, B);
+  ALLOC(c, fb.cand_slot, B * (size_t)fc.cand_cap);
   ALLOC(c, fb.recs, B * (size_t)fc.line_cap);
   ALLOC(c, fb.nlines, B);
   ALLOC(c, fb.mle_list, B * 3 * (size_t)fc.line_cap);
@@ -337,11 +348,15 @@ static int alloc_lsd(lf_ctx *c) {
   PairBuffers &pb = c->pb;
   memset(&pcn, 0, sizeof pcn);
   memset(&pb, 0, sizeof pb);
-  pcn.line_cap = fc.line_cap; pcn.match_cap = LF_MAX_MATCHES;
+  pcn.line_cap = fc.line_cap; pcn.match_cap = c->caps.match_cap; pcn.pt_match_cap = c->caps.pt_match_cap;
+  pcn.mode = LF_MODE_SOLVE; pcn.refine_iters = 0;
   pcn.cos_angle_thresh = cos(30 * 3.14159265 / 180);   // node.cpp:1624 with lineslam.h:38 PI
   pcn.cos_degeneracy = cos(5 * 3.14159265 / 180);      // motion.cpp:407
   ALLOC(c, c->d_pair_q, B); ALLOC(c, c->d_pair_t, B);
-  ALLOC(c, pb.D, B * (size_t)fc.line_cap * fc.line_cap);
+  ALLOC(c, pb.live_idx, B * (size_t)fc.line_cap * fc.line_cap);
+  ALLOC(c, pb.live_val, B * (size_t)fc.line_cap * fc.line_cap);
+  ALLOC(c, c->d_adjacent, B);
+  pb.adjacent = nullptr;
   ALLOC(c, pb.match_q, B * (size_t)pcn.match_cap); ALLOC(c, pb.match_t, B * (size_t)pcn.match_cap);
   ALLOC(c, pb.match_d, B * (size_t)pcn.match_cap);
   ALLOC(c, pb.nmatches, B);
@@ -359,14 +374,33 @@ extern "C" {
 
 int lf_ctx_create(lf_ctx **out, int device, void *hip_stream, int width, int height, int max_batch,
                   const lf_params *params) {
+  return lf_ctx_create_caps(out, device, hip_stream, width, height, max_batch, params, nullptr);
+}
+int lf_ctx_get_caps(const lf_ctx *c, lf_caps *k) {
+  if (!c || !k) return LF_ERR_INVALID;
+  *k = c->caps;
+  return LF_OK;
+}
+int lf_ctx_create_caps(lf_ctx **out, int device, void *hip_stream, int width, int height, int max_batch,
+                       const lf_params *params, const lf_caps *caps) {
   if (!out || width < 8 || height < 8 || max_batch < 1) return LF_ERR_INVALID;
   *out = nullptr;
+  lf_caps k;
+  lf_caps_init(&k);
+  if (caps) {
+    if (caps->seg_cap < 1 || caps->line_cap < 1 || caps->match_cap < 3 || caps->pt_match_cap < 0) return LF_ERR_INVALID;
+    if (caps->seg_cap > 65535 /* 16-bit region labels */ || caps->line_cap > LF_MATCH_LINE_CAP || caps->match_cap > LF_MAX_MATCHES ||
+        caps->pt_match_cap > LF_MAX_PT_MATCHES)
+      return LF_ERR_UNSUPPORTED;
+    k = *caps;
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return LF_ERR_NO_DEVICE;
   lf_ctx *c = new lf_ctx();
   c->device = device;
   c->W = width; c->H = height; c->maxB = max_batch;
+  c->caps = k;
   if (params) c->params = *params; else lf_params_init(&c->params);
   int r = LF_OK;
   do {
@@ -413,7 +447,13 @@ int lf_ctx_set_params(lf_ctx *c, const lf_params *p) {
   if (p->lsd_scale != c->params.lsd_scale || p->lsd_sigma_scale != c->params.lsd_sigma_scale)
     return LF_ERR_UNSUPPORTED;   // buffer geometry is fixed at creation
   lf_params old = c->params;
+  // the device tables (Gaussian taps, log-gamma, nfa) depend on the lsd_* members only: a change of any other
+  // parameter (Node::detect3DLines passes its scalars with every frame) costs nothing
+  const bool lsd_same = p->lsd_angle_th == old.lsd_angle_th && p->lsd_density_th == old.lsd_density_th &&
+                        p->lsd_quant == old.lsd_quant && p->lsd_log_eps == old.lsd_log_eps && p->lsd_n_bins == old.lsd_n_bins &&
+                        p->lsd_max_grad == old.lsd_max_grad;
   c->params = *p;
+  if (lsd_same) return LF_OK;
   int r = build_lsd_consts(c);
   if (r != LF_OK) { c->params = old; build_lsd_consts(c); return r; }
   HIPCHK(c, hipSetDevice(c->device));
@@ -563,8 +603,9 @@ int lf_detect3d_batch_device(lf_ctx *c, const uint8_t *d_gray, size_t gray_frame
 int lf_frame_get_lines(lf_ctx *c, int frame, lf_line_record *out, int cap, int *n_out) {
   if (!c || frame < 0 || frame >= c->last_batch || !n_out || cap < 0 || (cap > 0 && !out)) return LF_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
-  int n = 0;
+  int n = 0, nseg = 0;
   HIPCHK(c, hipMemcpyAsync(&n, c->fb.nlines + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&nseg, c->lb.nsegs + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *n_out = n;
   int m = n < cap ? n : cap;
@@ -574,7 +615,7 @@ int lf_frame_get_lines(lf_ctx *c, int frame, lf_line_record *out, int cap, int *
                              hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  return (n > cap || n > c->fc.line_cap) ? LF_ERR_CAPACITY : LF_OK;
+  return (n > cap || n > c->fc.line_cap || nseg > c->fc.seg_cap) ? LF_ERR_CAPACITY : LF_OK;   // nothing is dropped silently
 }
 
 int lf_frame_get_candidates(lf_ctx *c, int frame, int32_t *flags, double *info, int cap, int *n_out) {
@@ -583,13 +624,14 @@ int lf_frame_get_candidates(lf_ctx *c, int frame, int32_t *flags, double *info, 
   int n = 0;
   HIPCHK(c, hipMemcpyAsync(&n, c->lb.nsegs + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  const bool seg_overflow = n > c->fc.cand_cap;      // LSD itself found more than seg_cap segments (lf_lsd_get_segments says so too)
   if (n > c->fc.cand_cap) n = c->fc.cand_cap;
   *n_out = n;
   int m = n < cap ? n : cap;
   if (m > 0 && flags) HIPCHK(c, hipMemcpyAsync(flags, c->fb.cand_flag + (size_t)frame * c->fc.cand_cap, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   if (m > 0 && info) HIPCHK(c, hipMemcpyAsync(info, c->fb.cand_out + (size_t)frame * c->fc.cand_cap * LF_CAND_STRIDE, (size_t)m * LF_CAND_STRIDE * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return n > cap ? LF_ERR_CAPACITY : LF_OK;
+  return (n > cap || seg_overflow) ? LF_ERR_CAPACITY : LF_OK;
 }
 
 int lf_detect3d(lf_ctx *c, const uint8_t *gray, int gray_row_stride, const float *depth_m, int depth_row_stride,
@@ -616,7 +658,8 @@ static int hybrid_prepare(lf_ctx *c, const HybridArgs &h, int n_pairs, PairBuffe
   if (!h.d_points || h.pt_cap < 1 || !h.pm_q || !h.pm_t || !h.n_pm || h.pm_cap < 0 || !h.K) return LF_ERR_INVALID;
   for (int i = 0; i < n_pairs && !h.pm_on_device; i++) {
     if (h.n_pm[i] < 0) return LF_ERR_INVALID;
-    if (h.n_pm[i] > h.pm_cap || h.n_pm[i] > LF_MAX_PT_MATCHES) { c->err = "point matches per pair exceed the capacity (512)"; return LF_ERR_CAPACITY; }
+    if (h.n_pm[i] > h.pm_cap) return LF_ERR_INVALID;
+    if (h.n_pm[i] > c->pcn.pt_match_cap) { c->err = "point matches per pair exceed the context's pt_match_cap"; return LF_ERR_CAPACITY; }
     for (int k = 0; k < h.n_pm[i]; k++) {
       int a = h.pm_q[(size_t)i * h.pm_cap + k], b = h.pm_t[(size_t)i * h.pm_cap + k];
       if (a < 0 || a >= h.pt_cap || b < 0 || b >= h.pt_cap) { c->err = "point match index outside the point array"; return LF_ERR_INVALID; }
@@ -655,16 +698,37 @@ static int hybrid_prepare(lf_ctx *c, const HybridArgs &h, int n_pairs, PairBuffe
   return LF_OK;
 }
 
-static int match_pairs_impl(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
-                            const lf_line_record *d_ext_recs, const int32_t *d_ext_nlines,
-                            const uint64_t *d_ext_ids, int ext_frames, int ext_line_cap, const HybridArgs *hy = nullptr,
-                            bool relmotion = false) {
+struct PairCall {
+  const lf_line_record *d_ext_recs = nullptr; const int32_t *d_ext_nlines = nullptr; const uint64_t *d_ext_ids = nullptr;
+  int ext_frames = 0, ext_line_cap = 0;                 // train side = an external device-resident map
+  const HybridArgs *hy = nullptr;                       // point matches (hybrid solver)
+  int solver = LF_SOLVER_LINES;
+  const uint8_t *adjacent = nullptr;                    // HOST [n_pairs] adjacentFrame flags (null: from the node ids)
+  const int32_t *lm_q = nullptr, *lm_t = nullptr, *n_lm = nullptr; int lm_cap = 0;   // HOST caller-supplied line matches
+  int mode = LF_MODE_SOLVE, refine_iters = 0;
+};
+
+static int match_pairs_impl(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs, const PairCall &pcall) {
   if (!c || !query_frames || !train_frames || n_pairs < 1) return LF_ERR_INVALID;
   if (n_pairs > c->maxB) return LF_ERR_CAPACITY;
-  const int ntrain = d_ext_recs ? ext_frames : c->last_batch;
+  const int ntrain = pcall.d_ext_recs ? pcall.ext_frames : c->last_batch;
   for (int i = 0; i < n_pairs; i++)
     if (query_frames[i] < 0 || query_frames[i] >= c->last_batch || train_frames[i] < 0 || train_frames[i] >= ntrain)
       return LF_ERR_INVALID;
+  if (pcall.lm_q) {   // caller-supplied line matches: validated before anything is enqueued
+    if (!pcall.lm_t || !pcall.n_lm || pcall.lm_cap < 0) return LF_ERR_INVALID;
+    for (int i = 0; i < n_pairs; i++) {
+      if (pcall.n_lm[i] < 0 || pcall.n_lm[i] > pcall.lm_cap) return LF_ERR_INVALID;
+      if (pcall.n_lm[i] > c->pcn.match_cap) { c->err = "line matches per pair exceed the context's match_cap"; return LF_ERR_CAPACITY; }
+      for (int k = 0; k < pcall.n_lm[i]; k++) {
+        int a = pcall.lm_q[(size_t)i * pcall.lm_cap + k], b = pcall.lm_t[(size_t)i * pcall.lm_cap + k];
+        if (a < 0 || a >= c->fc.line_cap || b < 0 || b >= (pcall.d_ext_recs ? pcall.ext_line_cap : c->fc.line_cap)) {
+          c->err = "line match index outside the line map";
+          return LF_ERR_INVALID;
+        }
+      }
+    }
+  }
   HIPCHK(c, hipSetDevice(c->device));
   {   // pair lists through the pinned staging area (the caller's arrays may be temporaries)
     const unsigned sl = c->stage_pairs_next++ % LF_PAIR_STAGE_SLOTS;
@@ -678,27 +742,52 @@ static int match_pairs_impl(lf_ctx *c, const int32_t *query_frames, const int32_
     c->stage_pairs_pending[sl] = true;
   }
   c->pcn.P = c->params;
+  c->pcn.mode = pcall.mode; c->pcn.refine_iters = pcall.refine_iters;
   PairBuffers pb = c->pb;
-  if (hy) { int r = hybrid_prepare(c, *hy, n_pairs, pb); if (r != LF_OK) return r; }
-  if (d_ext_recs) { pb.recs_t = d_ext_recs; pb.nlines_t = d_ext_nlines; pb.frame_ids_t = d_ext_ids; pb.line_cap_t = ext_line_cap; }
+  if (pcall.hy) { int r = hybrid_prepare(c, *pcall.hy, n_pairs, pb); if (r != LF_OK) return r; }
+  if (pcall.d_ext_recs) { pb.recs_t = pcall.d_ext_recs; pb.nlines_t = pcall.d_ext_nlines; pb.frame_ids_t = pcall.d_ext_ids; pb.line_cap_t = pcall.ext_line_cap; }
+  pb.adjacent = nullptr;
+  if (pcall.adjacent) {
+    HIPCHK(c, hipMemcpyAsync(c->d_adjacent, pcall.adjacent, (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // (the caller's array may be a temporary)
+    pb.adjacent = c->d_adjacent;
+  }
+  if (pcall.lm_q) {
+    std::vector<int> hq((size_t)n_pairs * c->pcn.match_cap, 0), ht((size_t)n_pairs * c->pcn.match_cap, 0);
+    std::vector<double> hd((size_t)n_pairs * c->pcn.match_cap, 0.0);
+    for (int i = 0; i < n_pairs; i++)
+      for (int k = 0; k < pcall.n_lm[i]; k++) {
+        hq[(size_t)i * c->pcn.match_cap + k] = pcall.lm_q[(size_t)i * pcall.lm_cap + k];
+        ht[(size_t)i * c->pcn.match_cap + k] = pcall.lm_t[(size_t)i * pcall.lm_cap + k];
+      }
+    HIPCHK(c, hipMemcpyAsync(pb.match_q, hq.data(), hq.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(pb.match_t, ht.data(), ht.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(pb.match_d, hd.data(), hd.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(pb.nmatches, pcall.n_lm, sizeof(int) * (size_t)n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-  lf_pair_launch(c->pcn, pb, n_pairs, c->stream, hy ? LF_SOLVER_HYBRID : (relmotion ? LF_SOLVER_RELMOTION : LF_SOLVER_LINES));
-  c->last_hybrid = hy != nullptr;
+  lf_pair_launch(c->pcn, pb, n_pairs, c->stream, pcall.solver, pcall.lm_q == nullptr);
+  c->last_hybrid = pcall.hy != nullptr;
+  c->last_pb = pb;
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   HIPCHK(c, hipGetLastError());
   c->last_pairs = n_pairs;
+  c->pcn.mode = LF_MODE_SOLVE;
   return LF_OK;
 }
 
 int lf_match_pairs_device(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs) {
-  return match_pairs_impl(c, query_frames, train_frames, n_pairs, nullptr, nullptr, nullptr, 0, 0);
+  return match_pairs_impl(c, query_frames, train_frames, n_pairs, PairCall());
 }
 
 int lf_match_external_device(lf_ctx *c, const int32_t *query_frames, const int32_t *train_slots, int n_pairs,
                              const lf_line_record *d_ext_recs, const int32_t *d_ext_nlines,
                              const uint64_t *d_ext_ids, int ext_frames, int ext_line_cap) {
   if (!d_ext_recs || !d_ext_nlines || !d_ext_ids || ext_frames < 1 || ext_line_cap < 1) return LF_ERR_INVALID;
-  return match_pairs_impl(c, query_frames, train_slots, n_pairs, d_ext_recs, d_ext_nlines, d_ext_ids, ext_frames, ext_line_cap);
+  PairCall pc;
+  pc.d_ext_recs = d_ext_recs; pc.d_ext_nlines = d_ext_nlines; pc.d_ext_ids = d_ext_ids; pc.ext_frames = ext_frames; pc.ext_line_cap = ext_line_cap;
+  return match_pairs_impl(c, query_frames, train_slots, n_pairs, pc);
 }
 
 int lf_match_pairs_hybrid_device(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
@@ -706,7 +795,9 @@ int lf_match_pairs_hybrid_device(lf_ctx *c, const int32_t *query_frames, const i
                                  const int32_t *n_pm, int pm_cap, const double K[9]) {
   if (!c) return LF_ERR_INVALID;
   HybridArgs h = {d_points, pt_cap, pm_query, pm_train, n_pm, pm_cap, K, false};
-  return match_pairs_impl(c, query_frames, train_frames, n_pairs, nullptr, nullptr, nullptr, 0, 0, &h);
+  PairCall pc;
+  pc.hy = &h; pc.solver = LF_SOLVER_HYBRID;
+  return match_pairs_impl(c, query_frames, train_frames, n_pairs, pc);
 }
 
 int lf_match_pairs_hybrid_device_pm(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
@@ -714,7 +805,9 @@ int lf_match_pairs_hybrid_device_pm(lf_ctx *c, const int32_t *query_frames, cons
                                     const int32_t *d_n_pm, int pm_stride, const double K[9]) {
   if (!c || pm_stride < 1) return LF_ERR_INVALID;
   HybridArgs h = {d_points, pt_cap, d_pm_query, d_pm_train, d_n_pm, pm_stride, K, true};
-  return match_pairs_impl(c, query_frames, train_frames, n_pairs, nullptr, nullptr, nullptr, 0, 0, &h);
+  PairCall pc;
+  pc.hy = &h; pc.solver = LF_SOLVER_HYBRID;
+  return match_pairs_impl(c, query_frames, train_frames, n_pairs, pc);
 }
 
 int lf_project_keypoints_device(lf_ctx *c, const float *d_depth, size_t depth_frame_stride, int depth_row_stride,
@@ -784,7 +877,9 @@ int lf_feature_match_pairs_device(lf_ctx *c, const uint8_t *d_desc, const int32_
 }
 
 int lf_relmotion_pairs_device(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs) {
-  return match_pairs_impl(c, query_frames, train_frames, n_pairs, nullptr, nullptr, nullptr, 0, 0, nullptr, true);
+  PairCall pc;
+  pc.solver = LF_SOLVER_RELMOTION;
+  return match_pairs_impl(c, query_frames, train_frames, n_pairs, pc);
 }
 
 // computeRelativeMotion_Ransac(a, b, Ro, to) for two HOST vectors of already matched lines (a[i] <-> b[i]).
@@ -816,6 +911,7 @@ int lf_relmotion_lines(lf_ctx *c, const lf_line_record *a, const lf_line_record 
   HIPCHK(c, hipGetLastError());
   c->last_pairs = 1;
   c->last_hybrid = false;
+  c->last_pb = c->pb;
   lf_pair_result r;
   int rc = lf_pair_get_result(c, 0, &r);
   if (rc != LF_OK) return rc;
@@ -844,14 +940,14 @@ int lf_pair_get_point_inliers(lf_ctx *c, int pair, int32_t *match_idx, int cap, 
   if (!c || !n_out || pair < 0 || pair >= c->last_pairs || cap < 0) return LF_ERR_INVALID;
   lf_pair_result r;
   int rc = lf_pair_get_result(c, pair, &r);
-  if (rc != LF_OK) return rc;
+  if (rc != LF_OK && rc != LF_ERR_CAPACITY) return rc;
   *n_out = r.n_point_inliers;
   int m = r.n_point_inliers < cap ? r.n_point_inliers : cap;
   if (m > 0 && match_idx && c->last_hybrid) {
     HIPCHK(c, hipMemcpyAsync(match_idx, c->pb.pt_inliers + (size_t)pair * LF_MAX_PT_MATCHES, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  return LF_OK;
+  return (r.n_point_inliers > cap || r.overflow) ? LF_ERR_CAPACITY : LF_OK;
 }
 
 int lf_get_device_records(lf_ctx *c, lf_line_record **d_recs, int32_t **d_nlines, uint64_t **d_ids, int *line_cap) {
@@ -868,7 +964,7 @@ int lf_pair_get_result(lf_ctx *c, int pair, lf_pair_result *out) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(out, c->pb.results + pair, sizeof(lf_pair_result), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return LF_OK;
+  return out->overflow ? LF_ERR_CAPACITY : LF_OK;   // the record is complete either way; `overflow` says what was cut
 }
 
 int lf_pair_get_matches(lf_ctx *c, int pair, int32_t *qi, int32_t *ti, double *dist, int cap, int *n_out) {
@@ -892,27 +988,29 @@ int lf_pair_get_inliers(lf_ctx *c, int pair, int32_t *match_idx, int cap, int *n
   if (!c || !n_out || pair < 0 || pair >= c->last_pairs || cap < 0) return LF_ERR_INVALID;
   lf_pair_result r;
   int rc = lf_pair_get_result(c, pair, &r);
-  if (rc != LF_OK) return rc;
+  if (rc != LF_OK && rc != LF_ERR_CAPACITY) return rc;
   *n_out = r.n_inliers;
   int m = r.n_inliers < cap ? r.n_inliers : cap;
   if (m > 0 && match_idx) {
     HIPCHK(c, hipMemcpyAsync(match_idx, c->pb.inliers + (size_t)pair * LF_MAX_MATCHES, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  return r.n_inliers > cap ? LF_ERR_CAPACITY : LF_OK;
+  return (r.n_inliers > cap || r.overflow) ? LF_ERR_CAPACITY : LF_OK;
 }
 
 int lf_pair_get_descdiff(lf_ctx *c, int pair, double *D, size_t cap_doubles, int *n_query, int *n_train) {
   if (!c || pair < 0 || pair >= c->last_pairs) return LF_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  const PairBuffers &pb = c->last_pb;
   int pq = 0, pt = 0, n1 = 0, n2 = 0;
   HIPCHK(c, hipMemcpyAsync(&pq, c->d_pair_q + pair, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&pt, c->d_pair_t + pair, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpyAsync(&n1, c->fb.nlines + pq, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(&n2, c->fb.nlines + pt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&n1, pb.nlines + pq, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&n2, pb.nlines_t + pt, sizeof(int), hipMemcpyDeviceToHost, c->stream));   // (train side: possibly an external map)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (n1 > c->fc.line_cap) n1 = c->fc.line_cap;
+  if (n2 > pb.line_cap_t) n2 = pb.line_cap_t;
   if (n2 > c->fc.line_cap) n2 = c->fc.line_cap;
   if (n_query) *n_query = n1;
   if (n_train) *n_train = n2;
@@ -920,7 +1018,11 @@ int lf_pair_get_descdiff(lf_ctx *c, int pair, double *D, size_t cap_doubles, int
   if (!D) return LF_OK;
   if (cap_doubles < need) return LF_ERR_CAPACITY;
   if (need) {
-    HIPCHK(c, hipMemcpyAsync(D, c->pb.D + (size_t)pair * c->fc.line_cap * c->fc.line_cap, need * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (!c->d_descdiff) ALLOC(c, c->d_descdiff, (size_t)c->fc.line_cap * c->fc.line_cap);
+    c->pcn.P = c->params;
+    lf_pair_descdiff_launch(c->pcn, pb, pair, c->d_descdiff, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(D, c->d_descdiff, need * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return LF_OK;
@@ -993,7 +1095,7 @@ int lf_match_node_pair_hybrid(lf_ctx *c, const lf_line_record *newer, int n_newe
   if (!c->hybrid_ready) {
     PairBuffers tmp;
     float dummy_pt = 0;
-    HybridArgs h0 = {&dummy_pt, 1, &zero, &zero, &zero, 0, K};
+    HybridArgs h0 = {&dummy_pt, 1, &zero, &zero, &zero, 0, K, false};
     int r0 = hybrid_prepare(c, h0, 1, tmp);
     if (r0 != LF_OK) return r0;
   }
@@ -1004,6 +1106,174 @@ int lf_match_node_pair_hybrid(lf_ctx *c, const lf_line_record *newer, int n_newe
   int r = lf_match_pairs_hybrid_device(c, &q, &t, 1, c->d_pts_stage, LF_NODE_PT_CAP, pq, pt, &npm, n_pm > 0 ? n_pm : 1, K);
   if (r != LF_OK) return r;
   return lf_pair_get_result(c, 0, out);
+}
+
+
+// ---- the operators of the pair path on their own ---------------------------------------------------------------------
+int lf_line_matching_device(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
+                            const uint8_t *adjacent, const lf_line_record *d_ext_recs, const int32_t *d_ext_nlines,
+                            const uint64_t *d_ext_ids, int ext_frames, int ext_line_cap) {
+  if (!c) return LF_ERR_INVALID;
+  PairCall pc;
+  if (d_ext_recs) {
+    if (!d_ext_nlines || !d_ext_ids || ext_frames < 1 || ext_line_cap < 1) return LF_ERR_INVALID;
+    pc.d_ext_recs = d_ext_recs; pc.d_ext_nlines = d_ext_nlines; pc.d_ext_ids = d_ext_ids; pc.ext_frames = ext_frames; pc.ext_line_cap = ext_line_cap;
+  }
+  pc.solver = LF_SOLVER_NONE;
+  pc.adjacent = adjacent;
+  return match_pairs_impl(c, query_frames, train_frames, n_pairs, pc);
+}
+
+int lf_solve_pairs_device(lf_ctx *c, const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
+                          const int32_t *lm_query, const int32_t *lm_train, const int32_t *n_lm, int lm_cap,
+                          const float *d_points, int pt_cap, const int32_t *pm_query, const int32_t *pm_train,
+                          const int32_t *n_pm, int pm_cap, const double K[9]) {
+  if (!c || !lm_query || !lm_train || !n_lm || lm_cap < 0) return LF_ERR_INVALID;
+  PairCall pc;
+  pc.lm_q = lm_query; pc.lm_t = lm_train; pc.n_lm = n_lm; pc.lm_cap = lm_cap;
+  if (d_points) {
+    HybridArgs h = {d_points, pt_cap, pm_query, pm_train, n_pm, pm_cap, K, false};
+    pc.hy = &h; pc.solver = LF_SOLVER_HYBRID;
+    return match_pairs_impl(c, query_frames, train_frames, n_pairs, pc);
+  }
+  return match_pairs_impl(c, query_frames, train_frames, n_pairs, pc);
+}
+
+// both nodes of a pair from HOST memory into frame slots 0 (newer) / 1 (older) (+ their 3D points into the staging area)
+static int upload_node_pair(lf_ctx *c, const lf_line_record *newer, int n_newer, uint64_t id_newer, const float *pts_newer,
+                            int n_pts_newer, const lf_line_record *older, int n_older, uint64_t id_older,
+                            const float *pts_older, int n_pts_older, const double K[9], bool want_points) {
+  if (n_newer < 0 || n_older < 0 || (n_newer && !newer) || (n_older && !older) || n_pts_newer < 0 || n_pts_older < 0 ||
+      (n_pts_newer && !pts_newer) || (n_pts_older && !pts_older))
+    return LF_ERR_INVALID;
+  if (c->maxB < 2) return LF_ERR_CAPACITY;
+  if (n_newer > c->fc.line_cap || n_older > c->fc.line_cap || n_pts_newer > LF_NODE_PT_CAP || n_pts_older > LF_NODE_PT_CAP)
+    return LF_ERR_CAPACITY;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t ids[2] = {id_newer, id_older};
+  const int nl[2] = {n_newer, n_older};
+  if (n_newer) HIPCHK(c, hipMemcpyAsync(c->fb.recs, newer, sizeof(lf_line_record) * (size_t)n_newer, hipMemcpyHostToDevice, c->stream));
+  if (n_older) HIPCHK(c, hipMemcpyAsync(c->fb.recs + c->fc.line_cap, older, sizeof(lf_line_record) * (size_t)n_older, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->fb.nlines, nl, sizeof nl, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_frame_ids, ids, sizeof ids, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->last_batch < 2) c->last_batch = 2;
+  if (want_points) {
+    if (!c->hybrid_ready) {   // first hybrid call allocates the staging buffers
+      PairBuffers tmp;
+      float dummy_pt = 0;
+      const int32_t zero = 0;
+      HybridArgs h0 = {&dummy_pt, 1, &zero, &zero, &zero, 0, K, false};
+      int r0 = hybrid_prepare(c, h0, 1, tmp);
+      if (r0 != LF_OK) return r0;
+    }
+    if (n_pts_newer) HIPCHK(c, hipMemcpyAsync(c->d_pts_stage, pts_newer, sizeof(float) * 4 * (size_t)n_pts_newer, hipMemcpyHostToDevice, c->stream));
+    if (n_pts_older) HIPCHK(c, hipMemcpyAsync(c->d_pts_stage + (size_t)LF_NODE_PT_CAP * 4, pts_older, sizeof(float) * 4 * (size_t)n_pts_older, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return LF_OK;
+}
+
+int lf_line_matching_node_pair(lf_ctx *c, const lf_line_record *query, int n_query, uint64_t id_query,
+                               const lf_line_record *train, int n_train, uint64_t id_train, int adjacent, int32_t *query_idx,
+                               int32_t *train_idx, double *dist, int cap, int *n_out) {
+  if (!c || !n_out || cap < 0 || adjacent < -1 || adjacent > 1) return LF_ERR_INVALID;
+  const double K0[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  int r = upload_node_pair(c, query, n_query, id_query, nullptr, 0, train, n_train, id_train, nullptr, 0, K0, false);
+  if (r != LF_OK) return r;
+  const int32_t q = 0, t = 1;
+  const uint8_t adj = (uint8_t)adjacent;
+  r = lf_line_matching_device(c, &q, &t, 1, adjacent < 0 ? nullptr : &adj, nullptr, nullptr, nullptr, 0, 0);
+  if (r != LF_OK) return r;
+  return lf_pair_get_matches(c, 0, query_idx, train_idx, dist, cap, n_out);
+}
+
+int lf_solve_node_pair(lf_ctx *c, const lf_line_record *newer, int n_newer, uint64_t id_newer, const float *pts_newer,
+                       int n_pts_newer, const lf_line_record *older, int n_older, uint64_t id_older, const float *pts_older,
+                       int n_pts_older, const int32_t *lm_query, const int32_t *lm_train, int n_lm, const int32_t *pm_query,
+                       const int32_t *pm_train, int n_pm, const double K[9], lf_pair_result *out) {
+  if (!c || !out || !K || n_lm < 0 || n_pm < 0 || (n_lm && (!lm_query || !lm_train)) || (n_pm && (!pm_query || !pm_train)))
+    return LF_ERR_INVALID;
+  for (int k = 0; k < n_lm; k++) if (lm_query[k] < 0 || lm_query[k] >= n_newer || lm_train[k] < 0 || lm_train[k] >= n_older) return LF_ERR_INVALID;
+  for (int k = 0; k < n_pm; k++) if (pm_query[k] < 0 || pm_query[k] >= n_pts_newer || pm_train[k] < 0 || pm_train[k] >= n_pts_older) return LF_ERR_INVALID;
+  const bool pts = n_pm > 0;
+  int r = upload_node_pair(c, newer, n_newer, id_newer, pts_newer, n_pts_newer, older, n_older, id_older, pts_older, n_pts_older, K, pts);
+  if (r != LF_OK) return r;
+  const int32_t q = 0, t = 1, nl = n_lm, np = n_pm, zero = 0;
+  r = lf_solve_pairs_device(c, &q, &t, 1, n_lm ? lm_query : &zero, n_lm ? lm_train : &zero, &nl, n_lm > 0 ? n_lm : 1,
+                            pts ? c->d_pts_stage : nullptr, LF_NODE_PT_CAP, pm_query, pm_train, &np, n_pm > 0 ? n_pm : 1, K);
+  if (r != LF_OK) return r;
+  return lf_pair_get_result(c, 0, out);
+}
+
+int lf_refine_pair(lf_ctx *c, const lf_line_record *newer, int n_newer, const float *pts_newer, int n_pts_newer,
+                   const lf_line_record *older, int n_older, const float *pts_older, int n_pts_older,
+                   const int32_t *lm_query, const int32_t *lm_train, int n_lm, const int32_t *pm_query, const int32_t *pm_train,
+                   int n_pm, const double K[9], float T[16], int iterations) {
+  if (!c || !T || !K || iterations < 0 || n_lm < 0 || n_pm < 0 || (n_lm && (!lm_query || !lm_train)) || (n_pm && (!pm_query || !pm_train)))
+    return LF_ERR_INVALID;
+  for (int k = 0; k < n_lm; k++) if (lm_query[k] < 0 || lm_query[k] >= n_newer || lm_train[k] < 0 || lm_train[k] >= n_older) return LF_ERR_INVALID;
+  for (int k = 0; k < n_pm; k++) if (pm_query[k] < 0 || pm_query[k] >= n_pts_newer || pm_train[k] < 0 || pm_train[k] >= n_pts_older) return LF_ERR_INVALID;
+  int r = upload_node_pair(c, newer, n_newer, 1, pts_newer, n_pts_newer, older, n_older, 0, pts_older, n_pts_older, K, true);
+  if (r != LF_OK) return r;
+  lf_pair_result seed;
+  memset(&seed, 0, sizeof seed);
+  for (int i = 0; i < 16; i++) seed.T[i] = T[i];
+  HIPCHK(c, hipMemcpyAsync(c->pb.results, &seed, sizeof seed, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int32_t q = 0, t = 1, nl = n_lm, np = n_pm, zero = 0;
+  HybridArgs h = {c->d_pts_stage, LF_NODE_PT_CAP, n_pm ? pm_query : &zero, n_pm ? pm_train : &zero, &np, n_pm > 0 ? n_pm : 1, K, false};
+  PairCall pc;
+  pc.lm_q = n_lm ? lm_query : &zero; pc.lm_t = n_lm ? lm_train : &zero; pc.n_lm = &nl; pc.lm_cap = n_lm > 0 ? n_lm : 1;
+  pc.hy = &h; pc.solver = LF_SOLVER_HYBRID; pc.mode = LF_MODE_REFINE; pc.refine_iters = iterations;
+  r = match_pairs_impl(c, &q, &t, 1, pc);
+  if (r != LF_OK) return r;
+  lf_pair_result res;
+  r = lf_pair_get_result(c, 0, &res);
+  if (r != LF_OK) return r;
+  for (int i = 0; i < 16; i++) T[i] = res.T[i];
+  return LF_OK;
+}
+
+int lf_mle_lines(lf_ctx *c, const double *pts, const int32_t *pt_offset, const int32_t *npts, int n_lines, const double *AB_init,
+                 const double K[9], lf_line_record *out, int32_t *iters) {
+  if (!c || !pts || !pt_offset || !npts || !AB_init || !K || !out || n_lines < 1) return LF_ERR_INVALID;
+  if (n_lines > c->fc.line_cap || n_lines > c->fc.cand_cap) return LF_ERR_CAPACITY;
+  for (int i = 0; i < n_lines; i++) {
+    if (npts[i] < 2 || pt_offset[i] < 0) return LF_ERR_INVALID;
+    if (npts[i] > LF_MAX_SAMPLES) return LF_ERR_CAPACITY;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  set_camera(c, K);
+  // frame slot 0: candidate i == line i == point slot i
+  const int L = c->fc.line_cap;
+  std::vector<double> hp((size_t)n_lines * LF_MAX_SAMPLES * 3, 0.0), ho((size_t)n_lines * LF_CAND_STRIDE, 0.0);
+  std::vector<lf_line_record> hr((size_t)n_lines);
+  std::vector<int> hslot((size_t)n_lines), hlist((size_t)3 * L, 0);
+  int cnt[3] = {0, 0, 0};
+  memset(hr.data(), 0, sizeof(lf_line_record) * (size_t)n_lines);
+  for (int i = 0; i < n_lines; i++) {
+    memcpy(&hp[(size_t)i * LF_MAX_SAMPLES * 3], pts + 3 * (size_t)pt_offset[i], sizeof(double) * 3 * (size_t)npts[i]);
+    for (int k = 0; k < 6; k++) ho[(size_t)i * LF_CAND_STRIDE + k] = AB_init[6 * (size_t)i + k];
+    ho[(size_t)i * LF_CAND_STRIDE + 26] = (double)npts[i];
+    hr[i].lid = i; hr[i].seg = i;
+    hslot[i] = i;
+    const int which = npts[i] <= 32 ? 1 : 2;          // the work lists of k_records
+    hlist[(size_t)which * L + cnt[which]++] = i;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->fb.pts, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->fb.cand_out, ho.data(), ho.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->fb.cand_slot, hslot.data(), hslot.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->fb.recs, hr.data(), hr.size() * sizeof(lf_line_record), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->fb.mle_list, hlist.data(), hlist.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->fb.mle_cnt, cnt, sizeof cnt, hipMemcpyHostToDevice, c->stream));
+  lf_front_launch_mle(c->fc, c->fb, 1, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(out, c->fb.recs, sizeof(lf_line_record) * (size_t)n_lines, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(ho.data(), c->fb.cand_out, ho.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (iters) for (int i = 0; i < n_lines; i++) iters[i] = (int)ho[(size_t)i * LF_CAND_STRIDE + 27];
+  return LF_OK;
 }
 
 }  // extern "C"

@@ -15,9 +15,10 @@ struct FrontConsts {
   int W, H;
   double K[9], Kinv[9];
   lf_params P;
-  int cand_cap;      // candidates (LSD segments) examined per frame
+  int cand_cap;      // candidates (LSD segments) examined per frame (= seg_cap: every segment LSD reports is examined)
   int line_cap;      // records per frame
   int seg_cap;       // row capacity of the LSD segment output
+  int pts_slots;     // support-point slots per frame (one per 3D line; >= line_cap)
 };
 
 struct FrontBuffers {
@@ -29,7 +30,10 @@ struct FrontBuffers {
   const uint64_t *frame_ids; // [B]  keys of the counter-based generator
   int *cand_flag;            // [B][cand_cap]: 0 short, 1 no depth, 2 3D line
   double *cand_out;          // [B][cand_cap][LF_CAND_STRIDE]
-  double *pts;               // [B][cand_cap][LF_MAX_SAMPLES*3] supporting points of each RANSAC line
+  double *pts;               // [B][pts_slots][LF_MAX_SAMPLES*3] supporting points of each RANSAC line, in slots handed out
+  int *pts_cnt;              // [B]  by an atomic counter per frame (zeroed by lf_front_launch);
+  int *cand_slot;            // [B][cand_cap] slot of a candidate's points, -1 if the frame ran out of slots (then it also
+                             //   has more than line_cap lines: lf_frame_get_lines reports LF_ERR_CAPACITY)
   lf_line_record *recs;      // [B][line_cap]
   int *nlines;               // [B]  (may exceed line_cap: overflow)
   int *mle_list;             // [B][3][line_cap] line ids for the MLE stage by #support points: <= 16, 17..32, more
@@ -37,3 +41,5 @@ struct FrontBuffers {
 };
 
 void lf_front_launch(const FrontConsts &c, const FrontBuffers &b, int n_frames, hipStream_t stream);
+// only the MLE kernels, on work lists / support points the caller has placed in the buffers (lf_mle_lines)
+void lf_front_launch_mle(const FrontConsts &c, const FrontBuffers &b, int n_frames, hipStream_t stream);

@@ -427,10 +427,17 @@ __global__ void __launch_bounds__(64) k_line3d(FrontConsts c, FrontBuffers b) {
   if (!have) { if (lane == 0) *flag = 1; return; }                                          // lineslam.cpp:302-307
   // ---- hand the supporting points (line.pts, in list order) to the MLE kernel
   {
-    double *pts = b.pts + ((size_t)f * c.cand_cap + cand) * (LF_MAX_SAMPLES * 3);
-    bool in0 = (best0 >> lane) & 1ull, in1 = (best1 >> lane) & 1ull;
-    if (in0) { int r = __popcll(best0 & f_lt()); for (int k = 0; k < 3; k++) pts[3 * r + k] = S.pos[3 * lane + k]; }
-    if (in1) { int r = __popcll(best0) + __popcll(best1 & f_lt()); for (int k = 0; k < 3; k++) pts[3 * r + k] = S.pos[3 * (lane + 64) + k]; }
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(&b.pts_cnt[f], 1);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot >= c.pts_slots) slot = -1;              // more 3D lines than slots: the frame overflows line_cap as well
+    if (lane == 0) b.cand_slot[(size_t)f * c.cand_cap + cand] = slot;
+    if (slot >= 0) {
+      double *pts = b.pts + ((size_t)f * c.pts_slots + slot) * (LF_MAX_SAMPLES * 3);
+      bool in0 = (best0 >> lane) & 1ull, in1 = (best1 >> lane) & 1ull;
+      if (in0) { int r = __popcll(best0 & f_lt()); for (int k = 0; k < 3; k++) pts[3 * r + k] = S.pos[3 * lane + k]; }
+      if (in1) { int r = __popcll(best0) + __popcll(best1 & f_lt()); for (int k = 0; k < 3; k++) pts[3 * r + k] = S.pos[3 * (lane + 64) + k]; }
+    }
   }
   if (lane == 0) {
 #pragma unroll
@@ -803,7 +810,9 @@ __device__ __forceinline__ void f_mle_line(const FrontConsts &c, const FrontBuff
   lf_line_record *R = b.recs + (size_t)f * c.line_cap + lid;
   const int seg = R->seg;
   double *out = b.cand_out + ((size_t)f * c.cand_cap + seg) * LF_CAND_STRIDE;
-  const double *pts = b.pts + ((size_t)f * c.cand_cap + seg) * (LF_MAX_SAMPLES * 3);
+  const int pslot = b.cand_slot[(size_t)f * c.cand_cap + seg];
+  if (pslot < 0) return;                     // no support points were kept (frame over capacity, reported by the getters)
+  const double *pts = b.pts + ((size_t)f * c.pts_slots + pslot) * (LF_MAX_SAMPLES * 3);
   int ns = (int)out[26];
   if (ns > Cfg::ROWS) ns = Cfg::ROWS;
   double LA[3] = {out[0], out[1], out[2]}, LB[3] = {out[3], out[4], out[5]};
@@ -1116,7 +1125,12 @@ __global__ void __launch_bounds__(64) k_describe(FrontConsts c, FrontBuffers b) 
 }
 
 // ----------------------------------------------------------------------------------------------
+void lf_front_launch_mle(const FrontConsts &c, const FrontBuffers &b, int B, hipStream_t st) {
+  hipLaunchKernelGGL((k_mle<32, 32, 1>), dim3((c.line_cap + 1) / 2, B), dim3(64), 0, st, c, b);
+  hipLaunchKernelGGL((k_mle<64, MLE_N, 2>), dim3(c.line_cap, B), dim3(64), 0, st, c, b);
+}
 void lf_front_launch(const FrontConsts &c, const FrontBuffers &b, int B, hipStream_t st) {
+  (void)hipMemsetAsync(b.pts_cnt, 0, sizeof(int) * (size_t)B, st);
   hipLaunchKernelGGL(k_sobel5, dim3((c.W + 255) / 256, (c.H + SOBEL_ROWS - 1) / SOBEL_ROWS, B), dim3(256), 0, st, c, b);
   hipLaunchKernelGGL(k_line3d, dim3(c.cand_cap, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_records, dim3(B), dim3(64), 0, st, c, b);

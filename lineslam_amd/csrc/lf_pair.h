@@ -9,6 +9,7 @@
 #include "lf_pose.h"
 
 #define LF_MAX_MATCHES 256        // line matches per pair handled by the pose kernel (4 per lane)
+#define LF_MATCH_LINE_CAP 512     // lines per frame the matcher stages in LDS (the compiled maximum of lf_caps::line_cap)
 #define LF_RANSAC_MAX_ITERS 1024  // sample table capacity
 #define LF_MOTION_STRIDE 16
 #define LF_MAX_PT_MATCHES 512     // point matches per pair handled by the hybrid pose kernel (8 per lane)
@@ -22,7 +23,11 @@ struct PairConsts {
   lf_point_model pm;         // hybrid solver: errorFunction2 constants (misc.cpp:704-711, host libm)
   double focal;              //   K(0,0) for compPt3dCov (transformation_estimation.cpp:245)
   double cos_degeneracy;     // cos(5 * 3.14159265 / 180), host libm (motion.cpp:407,428)
+  int pt_match_cap;          // point matches per pair (<= LF_MAX_PT_MATCHES)
+  int mode;                  // LF_MODE_SOLVE: RANSAC + refinement;  LF_MODE_REFINE: getTransformFromHybridMatchesG2O alone on
+  int refine_iters;          //   every match given, starting from results[pair].T, refine_iters iterations (k_pose_hybrid)
 };
+enum { LF_MODE_SOLVE = 0, LF_MODE_REFINE = 1 };
 
 struct PairBuffers {
   const lf_line_record *recs;   // [B][line_cap]   query (newer) side: this context's last batch
@@ -33,7 +38,9 @@ struct PairBuffers {
   const uint64_t *frame_ids_t;
   int line_cap_t;
   const int *pair_q, *pair_t;   // [n_pairs] frame slots of the newer (query) and older (train) node
-  double *D;                    // [n_pairs][line_cap*line_cap] descDiff scratch
+  unsigned *live_idx;           // [n_pairs][line_cap*line_cap] live entries of descDiff (all gates passed, value < 100):
+  double *live_val;             //   (query << 16 | train), distance -- the matrix itself is never materialised
+  const unsigned char *adjacent;// [n_pairs] Node::lineMatching's adjacentFrame argument: 0 / 1, 255 = from the node ids; may be null
   int *match_q, *match_t;       // [n_pairs][match_cap]
   double *match_d;              // [n_pairs][match_cap]
   int *nmatches;                // [n_pairs] (may exceed match_cap)
@@ -51,8 +58,11 @@ struct PairBuffers {
   double *motion_d;             // [n_pairs][LF_MOTION_STRIDE] lines-only RANSAC: R (9), t (3), diagnostics
 };
 
-enum { LF_SOLVER_LINES = 0, LF_SOLVER_HYBRID = 1, LF_SOLVER_RELMOTION = 2 };   // what follows k_match
-void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t stream, int solver = LF_SOLVER_LINES);
+enum { LF_SOLVER_LINES = 0, LF_SOLVER_HYBRID = 1, LF_SOLVER_RELMOTION = 2, LF_SOLVER_NONE = 3 };   // what follows k_match
+// run_match = false: the match lists (match_q / match_t / nmatches) were supplied by the caller
+void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t stream, int solver = LF_SOLVER_LINES,
+                    bool run_match = true);
+void lf_pair_descdiff_launch(const PairConsts &c, const PairBuffers &b, int pair, double *D, hipStream_t stream);
 void lf_pair_relmotion_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t stream);
 size_t lf_pair_hybrid_ws_doubles();
 void lf_pair_hybrid_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t stream);

@@ -41,11 +41,64 @@ __device__ double m_overlap(const lf_line_record *a, const lf_line_record *b) { 
   }
 }
 
-__global__ void __launch_bounds__(256) k_match(PairConsts c, PairBuffers b) {
-  __shared__ int s_pos[512];
-  __shared__ double s_val[512];
-  __shared__ int s_wbase[4];
-  __shared__ int s_queue[1024], s_qn;   // pairs that passed the direction gate
+// The descDiff matrix of the reference (node.cpp:1643-1654) is never materialised: an entry is either 100 (a gate
+// failed) or the descriptor distance of a LIVE pair (all three gates passed), and everything lineMatching reads off
+// the matrix afterwards -- first minimum of a row / column, second smallest value of a row / column, both started
+// at 100 -- is a function of the live entries below 100 alone:
+//   * a live value >= 100 can neither be a minimum that passes descDiffThresh (< 1) nor lower a second-best that
+//     starts at 100: it is dropped;
+//   * a NaN distance (the unguarded sqrt of computeMSLD, utils.cpp:1593) is skipped by every `<` of the scans except
+//     where a scan STARTS on it: D[i][0] = NaN kills row i (minMaxLoc keeps NaN), D[0][j] = NaN kills column j
+//     (minV stays NaN, minP = 0, and row 0 cannot have its minimum there).
+// The 2D members of both line maps are staged once in LDS (SoA), the direction gate runs on all n1 x n2 pairs, the
+// pairs that pass are queued and take the expensive gates + the 72-d distance on densely packed lanes; live entries
+// go to a small list (L2 resident) and to LDS atomic minima (fp64 bit patterns of non-negative values order like
+// unsigned integers).  Two more sweeps over the list give the first arg-min (smallest index among ties, as
+// cv::minMaxLoc / the strict `<` of node.cpp:1664-1669) and the second-best values.
+#define MT_N 512                          // threads per pair
+#define MT_W (MT_N / 64)
+#define MT_CHUNK 2048                     // (query, train) pairs per direction-gate round
+#define LF_D_INF 0x7ff0000000000000ull    // +inf: "no live entry"
+struct MatchShared {
+  double q2d[9][LF_MATCH_LINE_CAP];       // p0 p1 q0 q1 l0 l1 l2 r0 r1 of the query lines
+  double t2d[9][LF_MATCH_LINE_CAP];       //                          ... of the train lines
+  unsigned long long rmin[LF_MATCH_LINE_CAP], cmin[LF_MATCH_LINE_CAP], rmin2[LF_MATCH_LINE_CAP], cmin2[LF_MATCH_LINE_CAP];
+  int rarg[LF_MATCH_LINE_CAP], carg[LF_MATCH_LINE_CAP];
+  unsigned char rdead[LF_MATCH_LINE_CAP], cdead[LF_MATCH_LINE_CAP];
+  int queue[MT_CHUNK], qn, nlive, wbase[MT_W];
+};
+__device__ __forceinline__ double m_pl(double px, double py, double l0, double l1, double l2) {   // pt_to_line_dist2d
+  return lf_fabs((l0 * px + l1 * py + l2)) / lf_sqrt(l0 * l0 + l1 * l1);
+}
+__device__ __forceinline__ double m_n2(double ax, double ay, double bx, double by) {
+  return lf_sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by));
+}
+__device__ __forceinline__ double m_pr(double Xx, double Xy, double Ax, double Ay, double Bx, double By) {   // projectPt2d_to_line2d
+  double BX0 = Xx - Bx, BX1 = Xy - By, BA0 = Ax - Bx, BA1 = Ay - By;
+  double n = lf_sqrt(BA0 * BA0 + BA1 * BA1);
+  return (BX0 * BA0 + BX1 * BA1) / n / n;
+}
+// lineSegmentOverlap(a, b), utils.cpp:1620-1638, on (p, q) of both lines
+__device__ __forceinline__ double m_ov(const double *a, const double *b) {
+  if (m_n2(a[0], a[1], a[2], a[3]) < m_n2(b[0], b[1], b[2], b[3])) {
+    double lp = m_pr(a[0], a[1], b[0], b[1], b[2], b[3]), lq = m_pr(a[2], a[3], b[0], b[1], b[2], b[3]);
+    if ((lp < 0 && lq < 0) || (lp > 1 && lq > 1)) return -1;
+    return lf_fabs(lp - lq) * m_n2(b[0], b[1], b[2], b[3]);
+  } else {
+    double lp = m_pr(b[0], b[1], a[0], a[1], a[2], a[3]), lq = m_pr(b[2], b[3], a[0], a[1], a[2], a[3]);
+    if ((lp < 0 && lq < 0) || (lp > 1 && lq > 1)) return -1;
+    return lf_fabs(lp - lq) * m_n2(a[0], a[1], a[2], a[3]);
+  }
+}
+__device__ __forceinline__ bool m_adjacent(const PairConsts &c, const PairBuffers &b, int pr, int fq, int ft) {
+  if (b.adjacent && b.adjacent[pr] != 255) return b.adjacent[pr] != 0;   // Node::lineMatching's adjacentFrame argument
+  long long idd = (long long)b.frame_ids[fq] - (long long)b.frame_ids_t[ft];
+  if (idd < 0) idd = -idd;
+  return !(idd > c.P.adjacent_linematch_window);                           // as matchNodePair passes it, node.cpp:1505-1507
+}
+
+__global__ void __launch_bounds__(MT_N) k_match(PairConsts c, PairBuffers b) {
+  __shared__ MatchShared S;
   const int pr = blockIdx.x, tid = threadIdx.x;
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];
   int n1 = b.nlines[fq], n2 = b.nlines_t[ft];
@@ -53,85 +106,153 @@ __global__ void __launch_bounds__(256) k_match(PairConsts c, PairBuffers b) {
   if (n2 > b.line_cap_t) n2 = b.line_cap_t;
   if (n2 > c.line_cap) n2 = c.line_cap;
   const lf_line_record *f1 = b.recs + (size_t)fq * c.line_cap, *f2 = b.recs_t + (size_t)ft * b.line_cap_t;
-  double *D = b.D + (size_t)pr * c.line_cap * c.line_cap;
-  long long idd = (long long)b.frame_ids[fq] - (long long)b.frame_ids_t[ft];
-  if (idd < 0) idd = -idd;
-  const bool adjacent = !(idd > c.P.adjacent_linematch_window);                       // node.cpp:1505-1507
-  const double lineDistThresh = adjacent ? 45 : 80, descDiffThresh = adjacent ? 0.85 : 0.7;
+  unsigned *live_idx = b.live_idx + (size_t)pr * c.line_cap * c.line_cap;
+  double *live_val = b.live_val + (size_t)pr * c.line_cap * c.line_cap;
+  const bool adjacent = m_adjacent(c, b, pr, fq, ft);
+  const double lineDistThresh = adjacent ? 45 : 80, descDiffThresh = adjacent ? 0.85 : 0.7;   // node.cpp:1623-1635
   const double lineOverlapThresh = adjacent ? 0 : -1, ratio = 0.7;
   if (n1 == 0 || n2 == 0) { if (tid == 0) b.nmatches[pr] = 0; return; }
-  // The cheap direction gate first, for 1024 (query, train) pairs at a time; the pairs that pass are queued in LDS and
-  // the expensive gates (eight fp64 divisions, a square root) and the descriptor distance then run on densely
-  // packed lanes.  Every entry of D is written exactly once, with the value the nested conditions give.
-  for (int base = 0; base < n1 * n2; base += 1024) {
-    if (tid == 0) s_qn = 0;
+  for (int l = tid; l < n1; l += MT_N) {
+    const lf_line_record *a = &f1[l];
+    S.q2d[0][l] = a->p[0]; S.q2d[1][l] = a->p[1]; S.q2d[2][l] = a->q[0]; S.q2d[3][l] = a->q[1];
+    S.q2d[4][l] = a->lineEq2d[0]; S.q2d[5][l] = a->lineEq2d[1]; S.q2d[6][l] = a->lineEq2d[2];
+    S.q2d[7][l] = a->r[0]; S.q2d[8][l] = a->r[1];
+    S.rmin[l] = LF_D_INF; S.rarg[l] = 0x7fffffff; S.rmin2[l] = 0x4059000000000000ull /* 100.0 */; S.rdead[l] = 0;
+  }
+  for (int l = tid; l < n2; l += MT_N) {
+    const lf_line_record *a = &f2[l];
+    S.t2d[0][l] = a->p[0]; S.t2d[1][l] = a->p[1]; S.t2d[2][l] = a->q[0]; S.t2d[3][l] = a->q[1];
+    S.t2d[4][l] = a->lineEq2d[0]; S.t2d[5][l] = a->lineEq2d[1]; S.t2d[6][l] = a->lineEq2d[2];
+    S.t2d[7][l] = a->r[0]; S.t2d[8][l] = a->r[1];
+    S.cmin[l] = LF_D_INF; S.carg[l] = 0x7fffffff; S.cmin2[l] = 0x4059000000000000ull; S.cdead[l] = 0;
+  }
+  if (tid == 0) S.nlive = 0;
+  __syncthreads();
+  for (int base = 0; base < n1 * n2; base += MT_CHUNK) {
+    if (tid == 0) S.qn = 0;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int idx = base + r * 256 + tid;
+    for (int r = 0; r < MT_CHUNK / MT_N; r++) {
+      const int idx = base + r * MT_N + tid;
       if (idx < n1 * n2) {
         const int i = idx / n2, j = idx - i * n2;
-        const lf_line_record *a = &f1[i], *bb = &f2[j];
-        if (a->r[0] * bb->r[0] + a->r[1] * bb->r[1] > c.cos_angle_thresh) s_queue[atomicAdd(&s_qn, 1)] = idx;
-        else D[(size_t)i * n2 + j] = 100;
+        if (S.q2d[7][i] * S.t2d[7][j] + S.q2d[8][i] * S.t2d[8][j] > c.cos_angle_thresh) S.queue[atomicAdd(&S.qn, 1)] = idx;
       }
     }
     __syncthreads();
-    const int qn = s_qn;
-    for (int k = tid; k < qn; k += 256) {
-      const int idx = s_queue[k], i = idx / n2, j = idx - i * n2;
-      const lf_line_record *a = &f1[i], *bb = &f2[j];
-      double v = 100;
-      if ((0.25 * m_pt_line2d(a->p, bb->lineEq2d) + 0.25 * m_pt_line2d(a->q, bb->lineEq2d) +
-           0.25 * m_pt_line2d(bb->p, a->lineEq2d) + 0.25 * m_pt_line2d(bb->q, a->lineEq2d) < lineDistThresh) &&
-          (m_overlap(a, bb) > lineOverlapThresh)) {
+    const int qn = S.qn;
+    for (int k = tid; k < qn; k += MT_N) {
+      const int idx = S.queue[k], i = idx / n2, j = idx - i * n2;
+      double a[7], t[7];
+#pragma unroll
+      for (int e = 0; e < 7; e++) { a[e] = S.q2d[e][i]; t[e] = S.t2d[e][j]; }
+      if ((0.25 * m_pl(a[0], a[1], t[4], t[5], t[6]) + 0.25 * m_pl(a[2], a[3], t[4], t[5], t[6]) +
+           0.25 * m_pl(t[0], t[1], a[4], a[5], a[6]) + 0.25 * m_pl(t[2], t[3], a[4], a[5], a[6]) < lineDistThresh) &&
+          (m_ov(a, t) > lineOverlapThresh)) {
+        const double *da = f1[i].des, *db = f2[j].des;
         double s = 0;
-        for (int kk = 0; kk < 72; kk++) { double d = a->des[kk] - bb->des[kk]; s += d * d; }
-        v = lf_sqrt(s);
+        for (int kk = 0; kk < 72; kk += 8) {          // eight loads of each side in flight, the sum in index order
+          double x[8], y[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) { x[u] = da[kk + u]; y[u] = db[kk + u]; }
+#pragma unroll
+          for (int u = 0; u < 8; u++) { double d = x[u] - y[u]; s += d * d; }
+        }
+        const double v = lf_sqrt(s);
+        if (v != v) { if (j == 0) S.rdead[i] = 1; if (i == 0) S.cdead[j] = 1; }
+        else if (v < 100) {
+          const int o = atomicAdd(&S.nlive, 1);
+          live_idx[o] = ((unsigned)i << 16) | (unsigned)j;
+          live_val[o] = v;
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+          atomicMin(&S.rmin[i], bits);
+          atomicMin(&S.cmin[j], bits);
+        }
       }
-      D[(size_t)i * n2 + j] = v;
     }
     __syncthreads();
   }
+  __threadfence_block();
   __syncthreads();
-  for (int i = tid; i < 512; i += 256) s_pos[i] = -1;
-  __syncthreads();
-  for (int i = tid; i < n1; i += 256) {
-    const double *row = D + (size_t)i * n2;
-    double minVal = row[0], rowmin2 = 100, colmin2 = 100;
-    int minPos = 0, minP = 0;
-    for (int j = 1; j < n2; j++) if (row[j] < minVal) { minVal = row[j]; minPos = j; }   // minMaxLoc: first minimum
-    if (!(minVal < descDiffThresh)) continue;
-    double minV = D[minPos];
-    for (int j = 1; j < n1; j++) { double v = D[(size_t)j * n2 + minPos]; if (v < minV) { minV = v; minP = j; } }
-    if (i != minP) continue;
-    for (int j = 0; j < n2; ++j) { if (j == minPos) continue; if (rowmin2 > row[j]) rowmin2 = row[j]; }
-    for (int j = 0; j < n1; ++j) { if (j == minP) continue; double v = D[(size_t)j * n2 + minPos]; if (colmin2 > v) colmin2 = v; }
-    if (rowmin2 * ratio > minVal && colmin2 * ratio > minVal) { s_pos[i] = minPos; s_val[i] = minVal; }
+  const int nlive = S.nlive;
+  for (int k = tid; k < nlive; k += MT_N) {      // first arg-min of every row / column
+    const unsigned e = live_idx[k];
+    const int i = (int)(e >> 16), j = (int)(e & 0xffffu);
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(live_val[k]);
+    if (bits == S.rmin[i]) atomicMin(&S.rarg[i], j);
+    if (bits == S.cmin[j]) atomicMin(&S.carg[j], i);
   }
   __syncthreads();
-  // ordered emission (the reference loops over i ascending, node.cpp:1656)
+  for (int k = tid; k < nlive; k += MT_N) {      // second-best of every row / column (the entry AT the arg-min is excluded)
+    const unsigned e = live_idx[k];
+    const int i = (int)(e >> 16), j = (int)(e & 0xffffu);
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(live_val[k]);
+    if (j != S.rarg[i]) atomicMin(&S.rmin2[i], bits);
+    if (i != S.carg[j]) atomicMin(&S.cmin2[j], bits);
+  }
+  __syncthreads();
+  // decision per query line (node.cpp:1656-1690) and ordered emission (the reference loops over i ascending)
   int *mq = b.match_q + (size_t)pr * c.match_cap, *mt = b.match_t + (size_t)pr * c.match_cap;
   double *md = b.match_d + (size_t)pr * c.match_cap;
   int base = 0;
   const int wave = tid >> 6, lane = tid & 63;
-  for (int i0 = 0; i0 < n1; i0 += 256) {
-    int i = i0 + tid;
-    bool has = i < n1 && s_pos[i] >= 0;
-    u64 m = __ballot(has);
-    if (lane == 0) s_wbase[wave] = __popcll(m);
+  for (int i0 = 0; i0 < n1; i0 += MT_N) {
+    const int i = i0 + tid;
+    bool has = false;
+    int minPos = 0;
+    double minVal = 0;
+    if (i < n1 && !S.rdead[i] && S.rmin[i] != LF_D_INF) {
+      minVal = __longlong_as_double((long long)S.rmin[i]);
+      minPos = S.rarg[i];
+      if (minVal < descDiffThresh && !S.cdead[minPos] && S.carg[minPos] == i) {
+        const double rowmin2 = __longlong_as_double((long long)S.rmin2[i]), colmin2 = __longlong_as_double((long long)S.cmin2[minPos]);
+        has = rowmin2 * ratio > minVal && colmin2 * ratio > minVal;
+      }
+    }
+    const u64 m = __ballot(has);
+    if (lane == 0) S.wbase[wave] = __popcll(m);
     __syncthreads();
-    int off = 0;
-    for (int w = 0; w < wave; w++) off += s_wbase[w];
-    int tot = s_wbase[0] + s_wbase[1] + s_wbase[2] + s_wbase[3];
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < MT_W; w++) { const int cw = S.wbase[w]; if (w < wave) off += cw; tot += cw; }
     if (has) {
-      int o = base + off + __popcll(m & p_lt());
-      if (o < c.match_cap) { mq[o] = i; mt[o] = s_pos[i]; md[o] = s_val[i]; }
+      const int o = base + off + __popcll(m & p_lt());
+      if (o < c.match_cap) { mq[o] = i; mt[o] = minPos; md[o] = minVal; }
     }
     base += tot;
     __syncthreads();
   }
   if (tid == 0) b.nmatches[pr] = base;
+}
+
+// The dense descDiff matrix itself, for parity tests only (lf_pair_get_descdiff): one entry per thread.
+__global__ void __launch_bounds__(256) k_descdiff(PairConsts c, PairBuffers b, int pr, double *D) {
+  const int fq = b.pair_q[pr], ft = b.pair_t[pr];
+  int n1 = b.nlines[fq], n2 = b.nlines_t[ft];
+  if (n1 > c.line_cap) n1 = c.line_cap;
+  if (n2 > b.line_cap_t) n2 = b.line_cap_t;
+  if (n2 > c.line_cap) n2 = c.line_cap;
+  const lf_line_record *f1 = b.recs + (size_t)fq * c.line_cap, *f2 = b.recs_t + (size_t)ft * b.line_cap_t;
+  const bool adjacent = m_adjacent(c, b, pr, fq, ft);
+  const double lineDistThresh = adjacent ? 45 : 80, lineOverlapThresh = adjacent ? 0 : -1;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n1 * n2) return;
+  const int i = idx / n2, j = idx - i * n2;
+  const lf_line_record *a = &f1[i], *bb = &f2[j];
+  double v = 100;
+  if ((a->r[0] * bb->r[0] + a->r[1] * bb->r[1] > c.cos_angle_thresh) &&
+      (0.25 * m_pt_line2d(a->p, bb->lineEq2d) + 0.25 * m_pt_line2d(a->q, bb->lineEq2d) +
+       0.25 * m_pt_line2d(bb->p, a->lineEq2d) + 0.25 * m_pt_line2d(bb->q, a->lineEq2d) < lineDistThresh) &&
+      (m_overlap(a, bb) > lineOverlapThresh)) {
+    double s = 0;
+    for (int kk = 0; kk < 72; kk++) { double d = a->des[kk] - bb->des[kk]; s += d * d; }
+    v = lf_sqrt(s);
+  }
+  D[idx] = v;
+}
+void lf_pair_descdiff_launch(const PairConsts &c, const PairBuffers &b, int pair, double *D, hipStream_t st) {
+  const int blocks = (c.line_cap * c.line_cap + 255) / 256;
+  hipLaunchKernelGGL(k_descdiff, dim3(blocks), dim3(256), 0, st, c, b, pair, D);
 }
 
 // ------------------------------------------------------------------------------ k_pose
@@ -434,11 +555,15 @@ __global__ void __launch_bounds__(PT_N, 2) k_pose(PairConsts c, PairBuffers b) {
     res->refine_rounds = rounds;
     float r2 = rmse_out * rmse_out;                                   // float arithmetic as node.cpp:1533-1534
     res->information_scale = valid ? (double)((float)(0 + n_inl * lw) / r2) : 0.0;
+    res->overflow = ((n_all > c.match_cap || n_all > LF_MAX_MATCHES) ? LF_OVF_MATCHES : 0) |
+                    ((b.nlines[fq] > c.line_cap || b.nlines_t[ft] > b.line_cap_t) ? LF_OVF_LINES : 0);
+    res->reserved_ = 0;
   }
 }
 
-void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t st, int solver) {
-  hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(256), 0, st, c, b);
+void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t st, int solver, bool run_match) {
+  if (run_match) hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(MT_N), 0, st, c, b);
+  if (solver == LF_SOLVER_NONE) return;
   if (solver == LF_SOLVER_HYBRID) lf_pair_hybrid_launch(c, b, n_pairs, st);
   else if (solver == LF_SOLVER_RELMOTION) lf_pair_relmotion_launch(c, b, n_pairs, st);
   else hipLaunchKernelGGL(k_pose, dim3(n_pairs), dim3(PT_N), 0, st, c, b);

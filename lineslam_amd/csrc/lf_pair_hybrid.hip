@@ -357,7 +357,28 @@ __global__ void __launch_bounds__(PT_N, 2) k_pose_hybrid(PairConsts c, PairBuffe
   if (nLn > c.match_cap) nLn = c.match_cap;
   if (nLn > LF_MAX_MATCHES) nLn = LF_MAX_MATCHES;
   if (nPt > LF_MAX_PT_MATCHES) nPt = LF_MAX_PT_MATCHES;
+  if (nPt > c.pt_match_cap) nPt = c.pt_match_cap;
   const int nTot = nPt + nLn;
+  const int ovf = ((n_all > c.match_cap || n_all > LF_MAX_MATCHES) ? LF_OVF_MATCHES : 0) | ((np_all > nPt) ? LF_OVF_PT_MATCHES : 0) |
+                  ((b.nlines[fq] > c.line_cap || b.nlines_t[ft] > b.line_cap_t) ? LF_OVF_LINES : 0);
+  if (c.mode == LF_MODE_REFINE) {
+    // getTransformFromHybridMatchesG2O on its own (lf_refine_pair): every match given is an edge, the start value is
+    // the transform the host stored in the result slot
+    float tf[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) tf[i] = res->T[i];
+    for (int i = tid; i < nPt; i += PT_N) S.pset[i] = i;
+    for (int i = tid; i < nLn; i += PT_N) S.lset[i] = i;
+    __syncthreads();
+    h_refine(S, pc, S.pset, nPt, S.lset, nLn, tf, c.refine_iters);
+    if (tid == 0) {
+      for (int i = 0; i < 16; i++) res->T[i] = tf[i];
+      res->rmse = 0.0f; res->valid = 1; res->n_matches = n_all; res->n_inliers = nLn; res->n_point_matches = np_all;
+      res->n_point_inliers = nPt; res->id_older = (int)b.frame_ids_t[ft]; res->id_newer = (int)b.frame_ids[fq];
+      res->ransac_best_iter = -1; res->refine_rounds = 0; res->information_scale = 0.0; res->overflow = ovf; res->reserved_ = 0;
+    }
+    return;
+  }
   const long long id_t = (long long)b.frame_ids_t[ft], id_q = (long long)b.frame_ids[fq];
   const uint64_t stream = LF_STREAM_PAIR((uint64_t)id_q, (uint64_t)id_t);
   float tf_out[16];
@@ -471,6 +492,8 @@ __global__ void __launch_bounds__(PT_N, 2) k_pose_hybrid(PairConsts c, PairBuffe
     res->refine_rounds = rounds;
     float r2 = rmse_out * rmse_out;
     res->information_scale = valid ? (double)((float)(n_pinl + n_linl * lw) / r2) : 0.0;   // node.cpp:1533-1534
+    res->overflow = ovf;
+    res->reserved_ = 0;
   }
 }
 

@@ -101,7 +101,9 @@ LF_HD int lf_rel_motion_lines(const double *la, const double *lb, int n, double 
       udr[r] = udr[r] + s;
     }
   }
-  if (!lf_inv3(uu, uui)) { t[0] = t[1] = t[2] = lf_from_bits(0x7ff8000000000000ULL); return 1; }
+  /* uu.inv(): cv::Mat::inv (DECOMP_LU) returns a ZERO matrix for a singular input (three parallel lines), so the
+   * reference goes on with t = 0 and still scores the hypothesis (motion.cpp:363) */
+  if (!lf_inv3(uu, uui)) { t[0] = t[1] = t[2] = 0.0; return 1; }
   for (r = 0; r < 3; r++) t[r] = uui[3 * r] * udr[0] + uui[3 * r + 1] * udr[1] + uui[3 * r + 2] * udr[2];
   return 1;
 }

@@ -4,7 +4,9 @@ meaning as the reference so that the parity tests read like the reference's call
 
     Node(gray, depth, K, id)                 <-> Node::Node(...)  (runs detect3DLines, node.cpp:198-217)
     node.detect3DLines(...)                  <-> Node::detect3DLines          (lineslam.cpp:200-357)
-    node.lineMatching(other, adjacent)       <-> Node::lineMatching           (node.cpp:1619-1694)
+    node.lineMatching(other, adjacent)       <-> Node::lineMatching           (node.cpp:1619-1694), the matcher alone
+    node.getTransform_PtsLines_ransac(train, pt, ln)          <-> src/line/utils.h:147-153 (caller-supplied matches)
+    node.getTransformFromHybridMatchesG2O(earlier, pt, ln, T) <-> src/transformation_estimation.h:21-26
     node.matchNodePair(older)                <-> Node::matchNodePair          (node.cpp:1494-1615)
     node.getRelativeTransformationTo(older)  <-> Node::getRelativeTransformationTo (node.h:124-128): the
         legacy point-RANSAC entry, routed to the same solver; `initial_matches` are the point matches.
@@ -81,11 +83,38 @@ class Node:
         return r, mq, mt, md, inl, pinl
 
     def lineMatching(self, other, adjacentFrame=None, matches=None):
-        """Appends (queryIdx, trainIdx, distance) to `matches`; returns the count (node.cpp:1619)."""
-        r, mq, mt, md, _, _ = self._pair(other)
+        """Node::lineMatching(other, adjacentFrame, &matches): the matcher alone (no pose solve).  adjacentFrame selects
+        the threshold set as in the reference (node.cpp:1622-1635); None = derived from the node ids as matchNodePair
+        does.  Appends (queryIdx, trainIdx, distance) to `matches`; returns the count (node.cpp:1619)."""
+        self._ctx.set_params(self.params)
+        mq, mt, md = self._ctx.line_matching_node_pair(self.lines, self.id_, other.lines, other.id_, adjacentFrame,
+                                                       cap=max(len(self.lines), 1))
         out = matches if matches is not None else []
         out.extend(zip(mq.tolist(), mt.tolist(), md.tolist()))
         return len(out)
+
+    def getTransform_PtsLines_ransac(self, train_node, all_point_matches, all_line_matches):
+        """bool getTransform_PtsLines_ransac(trainNode, queryNode = self, all_point_matches, all_line_matches, ...)
+        (src/line/utils.h:147-153) with caller-supplied match lists ((queryIdx, trainIdx[, distance]) tuples):
+        returns (ok, point inlier matches, line inlier matches, tf [4,4] float32 query -> train, rmse)."""
+        self._ctx.set_params(self.params)
+        pm = np.asarray([(m[0], m[1]) for m in all_point_matches], np.int32).reshape(-1, 2)
+        lm = np.asarray([(m[0], m[1]) for m in all_line_matches], np.int32).reshape(-1, 2)
+        r = self._ctx.solve_node_pair(self.lines, self.id_, train_node.lines, train_node.id_, lm[:, 0], lm[:, 1],
+                                      self.feature_locations_3d_, train_node.feature_locations_3d_, pm[:, 0], pm[:, 1], self.K)
+        lin = self._ctx.pair_inliers(0) if r.n_inliers else np.zeros(0, np.int32)
+        pin = self._ctx.pair_point_inliers(0) if r.n_point_inliers else np.zeros(0, np.int32)
+        return (bool(r.valid), [all_point_matches[i] for i in pin.tolist()], [all_line_matches[i] for i in lin.tolist()],
+                np.array(list(r.T), np.float32).reshape(4, 4), float(r.rmse))
+
+    def getTransformFromHybridMatchesG2O(self, earlier_node, pt_matches, ln_matches, transformation_estimate, iterations=10):
+        """void getTransformFromHybridMatchesG2O(earlier_node, newer_node = self, pt_matches, ln_matches, T in/out,
+        iterations) (src/transformation_estimation.h:21-26): returns the refined 4x4 float transform."""
+        self._ctx.set_params(self.params)
+        pm = np.asarray([(m[0], m[1]) for m in pt_matches], np.int32).reshape(-1, 2)
+        lm = np.asarray([(m[0], m[1]) for m in ln_matches], np.int32).reshape(-1, 2)
+        return self._ctx.refine_pair(self.lines, earlier_node.lines, lm[:, 0], lm[:, 1], transformation_estimate, iterations,
+                                     self.feature_locations_3d_, earlier_node.feature_locations_3d_, pm[:, 0], pm[:, 1], self.K)
 
     def matchNodePair(self, older_node, point_matches=None):
         """point_matches: MatchingResult::all_matches as (queryIdx, trainIdx[, distance]) tuples, or None."""

@@ -47,7 +47,9 @@ def pose_case(name):
     return dict(train=_recs(z, name, "t"), query=_recs(z, name, "q"), train_pts=z[name + "_t_pts"], query_pts=z[name + "_q_pts"],
                 pm=z[name + "_pm"], lm=z[name + "_lm"], id_train=int(z[name + "_ids"][0]), id_query=int(z[name + "_ids"][1]),
                 ok=bool(ok[0]), best_iter=int(ok[1]), rounds=int(ok[2]), ransac_inliers=int(ok[3]), tf=z[name + "_tf"],
-                rmse=float(z[name + "_rmse"][0]), pin=z[name + "_pin"], lin=z[name + "_lin"], T_true=z[name + "_T_true"])
+                rmse=float(z[name + "_rmse"][0]), pin=z[name + "_pin"], lin=z[name + "_lin"], T_true=z[name + "_T_true"],
+                refine_T0=z[name + "_refine_T0"] if name + "_refine_T0" in z.files else None,
+                refine_T=z[name + "_refine_T"] if name + "_refine_T" in z.files else None)
 
 
 def rot_angle(Ra, Rb):

@@ -206,6 +206,15 @@ def main():
         out[name + "_rmse"] = np.array([r["rmse"]], np.float32)
         out[name + "_pin"] = np.array(r["pt_inliers"], np.int32)
         out[name + "_lin"] = np.array(r["ln_inliers"], np.int32)
+        # getTransformFromHybridMatchesG2O on its own: the final inlier matches, a start value off the truth, 10 iterations
+        if r["ok"] and (name.startswith("lines") and ci % 3 == 0 or name.startswith("hybrid") and ci % 4 == 0):
+            T0 = T.copy()
+            T0[:3, :3] = T0[:3, :3] @ rand_rot(rs, 1.0)
+            T0[:3, 3] += rs.randn(3) * 0.01
+            T0 = T0.astype(np.float32)
+            sub_p, sub_l = [pm[i] for i in r["pt_inliers"]], [lm[i] for i in r["ln_inliers"]]
+            out[name + "_refine_T0"] = T0
+            out[name + "_refine_T"] = I.refine_g2o(train, query, sub_p, sub_l, T0, 10, P)
         tf = np.asarray(r["tf"], np.float64)
         print("%-14s ok=%d best_iter=%3d rounds=%d  lines %2d/%2d  pts %3d/%3d  rmse %.3f  dR %.2e rad  dt %.2e m  (%.0f s)" % (
             name, r["ok"], r["best_iter"], r["rounds"], len(r["ln_inliers"]), len(lm), len(r["pt_inliers"]), len(pm), r["rmse"],

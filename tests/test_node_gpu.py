@@ -87,3 +87,20 @@ def test_cpp_mirror_builds_and_agrees(built_lib, tmp_path):
     assert out[2].endswith("valid 1")
     T = np.array([[float(v) for v in ln.split()] for ln in out[3:7]])
     assert np.allclose(T, mr.final_trafo, atol=1e-6)
+    # the operators on their own, C++ signatures vs the Python mirror vs the oracle
+    import _oracle as O
+    la, lf_ = [], []
+    newer.lineMatching(older, True, la)
+    newer.lineMatching(older, False, lf_)
+    assert out[8] == "lineMatching: adjacent %d, non-adjacent %d" % (len(la), len(lf_))
+    mq, mt, md, _ = O.match_oracle(newer.lines, older.lines, True)
+    assert [m[0] for m in la] == mq.tolist() and [m[1] for m in la] == mt.tolist()
+    ok, pin, lin, T2, rmse = newer.getTransform_PtsLines_ransac(older, [], la)
+    assert out[9].startswith("getTransform_PtsLines_ransac: %d (%d line inliers)" % (ok, len(lin)))
+    Tc = np.array([[float(v) for v in ln.split()] for ln in out[10:14]])
+    assert np.allclose(Tc, T2, atol=1e-6) and np.allclose(T2, mr.final_trafo, atol=1e-6)   # same matches, same solver
+    T3 = newer.getTransformFromHybridMatchesG2O(older, [], lin, np.eye(4, dtype=np.float32), 10)
+    Tc3 = np.array([[float(v) for v in ln.split()] for ln in out[15:19]])
+    assert np.allclose(Tc3, T3, atol=1e-6)
+    Tgt = np.linalg.inv(poses[0]) @ poses[1]
+    assert np.linalg.norm(T3[:3, 3] - Tgt[:3, 3]) < 0.02        # ten LM iterations from identity reach the motion
