@@ -485,18 +485,20 @@ class Context:
                                      Kc.ctypes.data, out.ctypes.data, it.ctypes.data), "lf_mle_lines")
         return out, it
 
-    def pair_matches(self, pair, cap=256):
+    def pair_matches(self, pair, cap=256, allow_overflow=False):
         q, t, d = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float64)
         n = C.c_int()
         self._chk(lib().lf_pair_get_matches(self._h, pair, q.ctypes.data, t.ctypes.data, d.ctypes.data, cap,
-                                            C.byref(n)), "lf_pair_get_matches")
-        return q[:n.value].copy(), t[:n.value].copy(), d[:n.value].copy()
+                                            C.byref(n)), "lf_pair_get_matches", ok=(LF_OK, LF_ERR_CAPACITY) if allow_overflow else (LF_OK,))
+        m = min(n.value, cap)
+        return q[:m].copy(), t[:m].copy(), d[:m].copy()
 
-    def pair_inliers(self, pair, cap=256):
+    def pair_inliers(self, pair, cap=256, allow_overflow=False):
         m = np.zeros(cap, np.int32)
         n = C.c_int()
-        self._chk(lib().lf_pair_get_inliers(self._h, pair, m.ctypes.data, cap, C.byref(n)), "lf_pair_get_inliers")
-        return m[:n.value].copy()
+        self._chk(lib().lf_pair_get_inliers(self._h, pair, m.ctypes.data, cap, C.byref(n)), "lf_pair_get_inliers",
+                  ok=(LF_OK, LF_ERR_CAPACITY) if allow_overflow else (LF_OK,))
+        return m[:min(n.value, cap)].copy()
 
     def pair_descdiff(self, pair):
         n1, n2 = C.c_int(), C.c_int()
@@ -535,12 +537,14 @@ class Context:
                                                  _vp(ext_nlines_ptr), _vp(ext_ids_ptr), ext_frames, ext_line_cap),
                   "lf_match_external_device")
 
-    def match_node_pair(self, newer_recs, id_newer, older_recs, id_older):
-        """Node::matchNodePair for two host-resident line maps; returns LfPairResult (pair slot 0)."""
+    def match_node_pair(self, newer_recs, id_newer, older_recs, id_older, allow_overflow=False):
+        """Node::matchNodePair for two host-resident line maps; returns LfPairResult (pair slot 0).  More line matches
+        than the context's match_cap is LF_ERR_CAPACITY unless allow_overflow (the record then carries `overflow`)."""
         a, b = np.ascontiguousarray(newer_recs), np.ascontiguousarray(older_recs)
         r = LfPairResult()
         self._chk(lib().lf_match_node_pair(self._h, a.ctypes.data, len(a), int(id_newer), b.ctypes.data, len(b),
-                                           int(id_older), C.byref(r)), "lf_match_node_pair")
+                                           int(id_older), C.byref(r)), "lf_match_node_pair",
+                  ok=(LF_OK, LF_ERR_CAPACITY) if allow_overflow else (LF_OK,))
         return r
 
     def match_node_pair_hybrid(self, newer_recs, id_newer, newer_pts, older_recs, id_older, older_pts, pm_query,

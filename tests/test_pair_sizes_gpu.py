@@ -39,17 +39,24 @@ def test_pose_over_match_counts(built_lib, maps, m):
         m = len(older)                      # every line of the frame (more than the kernel's 256 when the scene allows)
     if m > len(older):
         pytest.skip("frame has only %d lines" % len(older))
+    from lineslam_amd import capi
     nw, od = newer[:m], older[:m]
     id_new, id_old = 8, 7
-    r = ctx.match_node_pair(nw, id_new, od, id_old)
+    over = m > 256
+    if over:                                # more matches than match_cap: reported, never cut silently
+        with pytest.raises(capi.LinefrontError) as e:
+            ctx.match_node_pair(nw, id_new, od, id_old)
+        assert e.value.status == capi.LF_ERR_CAPACITY
+    r = ctx.match_node_pair(nw, id_new, od, id_old, allow_overflow=over)
+    assert bool(r.overflow & capi.LF_OVF_MATCHES) == over
     mq, mt, md, _ = O.match_oracle(nw, od, True)
     assert r.n_matches == len(mq) == m      # identical descriptors: every line matches itself
-    mq, mt = mq[:256], mt[:256]             # the pose kernel takes the first LF_MAX_MATCHES
+    mq, mt = mq[:256], mt[:256]             # (what the solver then works on: the first match_cap matches)
     stream = (id_new << 32) ^ id_old ^ 0x2000000000000000
     ok, tf, rmse, inl, dbg = O.pose_oracle(od, nw, mq, mt, id_old, id_new, P, stream)
     assert bool(r.valid) == ok
     if len(mq) >= P.min_feature_matches:    # (below that the solver returns before RANSAC; the debug fields are unset)
         assert r.ransac_best_iter == dbg[0] and r.refine_rounds == dbg[2]
-    assert np.array_equal(ctx.pair_inliers(0), inl)
+    assert np.array_equal(ctx.pair_inliers(0, allow_overflow=over), inl)
     assert np.array_equal(np.array(list(r.T), np.float32).reshape(4, 4), tf)
     assert np.float32(r.rmse) == np.float32(rmse)
