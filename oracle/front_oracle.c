@@ -624,81 +624,121 @@ int oracle_detect3d(const uint8_t *gray, int gstride, const float *depth, int ds
   gx = (double *)malloc(sizeof(double) * (size_t)w * h);
   gy = (double *)malloc(sizeof(double) * (size_t)w * h);
   oracle_sobel5(gray, gstride, w, h, gx, gy);
-  for (i = 0; i < nseg; i++) {
-    const double *s = segs + 5 * (size_t)i;
-    double a = s[0], b = s[1], c = s[2], d = s[3], p[2], q[2], len, numSmp, pts3[128][3];
-    int np = 0, ninl, inl[128], have = 0;
-    orpt rp[128], sup[128];
-    double A[3], B[3];
-    if (cand_flag) cand_flag[i] = 0;
-    if (cand_info) for (k = 0; k < 8; k++) cand_info[8 * (size_t)i + k] = 0;
-    if (!(sqrt((a - c) * (a - c) + (b - d) * (b - d)) > P->line_segment_len_thresh)) continue; /* :218 */
-    if (cand_flag) cand_flag[i] = 1;
-    p[0] = a; p[1] = b; q[0] = c; q[1] = d;
-    len = sqrt((p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]));
-    numSmp = len / P->line_sample_interval;
-    if (numSmp < (double)P->line_sample_min_num) numSmp = (double)P->line_sample_min_num;
-    if (numSmp > (double)P->line_sample_max_num) numSmp = (double)P->line_sample_max_num;
-    for (j = 0; j <= numSmp && np < 128; ++j) { /* :252-288 */
-      double ptx = p[0] * (1 - j / numSmp) + q[0] * (j / numSmp);
-      double pty = p[1] * (1 - j / numSmp) + q[1] * (j / numSmp);
-      int row, col;
-      double depval, zval = -1;
-      if (ptx < 0 || pty < 0 || ptx >= w || pty >= h) continue;
-      if ((floor(ptx) == ptx) && (floor(pty) == pty)) {
-        col = (int)(ptx - 1); if (col < 0) col = 0;
-        row = (int)(pty - 1); if (row < 0) row = 0;
-      } else { col = (int)ptx; row = (int)pty; }
-      depval = depth[(size_t)row * dstride_elems + col];
-      if (depval < O_EPS || isnan((float)depval)) { } else zval = depval / P->depth_scaling;
-      if (zval > 0) {
-        double x = Kinv[0] * ptx + Kinv[1] * pty + Kinv[2] * 1.0;
-        double y = Kinv[3] * ptx + Kinv[4] * pty + Kinv[5] * 1.0;
-        double z = Kinv[6] * ptx + Kinv[7] * pty + Kinv[8] * 1.0;
-        x = x / z; y = y / z;
-        pts3[np][0] = x * zval; pts3[np][1] = y * zval; pts3[np][2] = zval;
-        np++;
+  /* Three phases, as the reference: (1) `#pragma omp parallel for` over the LSD segments (lineslam.cpp:246): sampling,
+   * point covariances, RANSAC line; (2) the serial compaction with lid = index and getGradient ("must not be
+   * parallelized", :332-341); (3) `#pragma omp parallel for` over the kept lines (:344): MSLD + MLE.  The pragmas are
+   * active only in the OpenMP flavour of this library (_build/liboracle_omp.so, the reference-shaped CPU baseline of
+   * bench.py); results do not depend on the schedule (the random streams are keyed by frame and segment).             */
+  {
+    typedef struct { int have, ninl; double A[3], B[3]; orpt *sup; } o_seg;
+    o_seg *sg = (o_seg *)calloc((size_t)(nseg > 0 ? nseg : 1), sizeof(o_seg));
+    int *kept = (int *)malloc(sizeof(int) * (size_t)(nseg > 0 ? nseg : 1));
+#pragma omp parallel for schedule(dynamic, 8) private(j, k)
+    for (i = 0; i < nseg; i++) {
+      const double *s = segs + 5 * (size_t)i;
+      double a = s[0], b = s[1], c = s[2], d = s[3], p[2], q[2], len, numSmp, pts3[128][3];
+      int np = 0, ninl, inl[128], have = 0;
+      orpt rp[128];
+      double A[3], B[3];
+      if (cand_flag) cand_flag[i] = 0;
+      if (cand_info) for (k = 0; k < 8; k++) cand_info[8 * (size_t)i + k] = 0;
+      if (!(sqrt((a - c) * (a - c) + (b - d) * (b - d)) > P->line_segment_len_thresh)) continue; /* :218 */
+      if (cand_flag) cand_flag[i] = 1;
+      p[0] = a; p[1] = b; q[0] = c; q[1] = d;
+      len = sqrt((p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]));
+      numSmp = len / P->line_sample_interval;
+      if (numSmp < (double)P->line_sample_min_num) numSmp = (double)P->line_sample_min_num;
+      if (numSmp > (double)P->line_sample_max_num) numSmp = (double)P->line_sample_max_num;
+      for (j = 0; j <= numSmp && np < 128; ++j) { /* :252-288 */
+        double ptx = p[0] * (1 - j / numSmp) + q[0] * (j / numSmp);
+        double pty = p[1] * (1 - j / numSmp) + q[1] * (j / numSmp);
+        int row, col;
+        double depval, zval = -1;
+        if (ptx < 0 || pty < 0 || ptx >= w || pty >= h) continue;
+        if ((floor(ptx) == ptx) && (floor(pty) == pty)) {
+          col = (int)(ptx - 1); if (col < 0) col = 0;
+          row = (int)(pty - 1); if (row < 0) row = 0;
+        } else { col = (int)ptx; row = (int)pty; }
+        depval = depth[(size_t)row * dstride_elems + col];
+        if (depval < O_EPS || isnan((float)depval)) { } else zval = depval / P->depth_scaling;
+        if (zval > 0) {
+          double x = Kinv[0] * ptx + Kinv[1] * pty + Kinv[2] * 1.0;
+          double y = Kinv[3] * ptx + Kinv[4] * pty + Kinv[5] * 1.0;
+          double z = Kinv[6] * ptx + Kinv[7] * pty + Kinv[8] * 1.0;
+          x = x / z; y = y / z;
+          pts3[np][0] = x * zval; pts3[np][1] = y * zval; pts3[np][2] = zval;
+          np++;
+        }
+      }
+      if (cand_info) { cand_info[8 * (size_t)i + 0] = numSmp; cand_info[8 * (size_t)i + 1] = np; }
+      { double need = numSmp * P->ratio_of_collinear_pts; if (need < 10.0) need = 10.0; if (np < need) continue; } /* :289 */
+      for (j = 0; j < np; j++) o_comp_pt3d_cov(pts3[j], K[0], P, &rp[j]);
+      ninl = o_extract3dline(rp, np, P, P->rng_seed, LF_STREAM_LINE3D(frame_id, i), A, B, inl);
+      if (cand_info) { cand_info[8 * (size_t)i + 2] = ninl; for (k = 0; k < 3; k++) cand_info[8 * (size_t)i + 3 + k] = A[k]; }
+      if (ninl / numSmp > P->ratio_of_collinear_pts &&
+          sqrt((A[0] - B[0]) * (A[0] - B[0]) + (A[1] - B[1]) * (A[1] - B[1]) + (A[2] - B[2]) * (A[2] - B[2])) > P->line3d_length_thresh)
+        have = 1; /* :302-307 */
+      if (!have) continue;
+      if (cand_flag) cand_flag[i] = 2;
+      sg[i].have = 1; sg[i].ninl = ninl;
+      for (k = 0; k < 3; k++) { sg[i].A[k] = A[k]; sg[i].B[k] = B[k]; }
+      sg[i].sup = (orpt *)malloc(sizeof(orpt) * (size_t)ninl);
+      for (j = 0; j < ninl; j++) sg[i].sup[j] = rp[inl[j]];
+    }
+    for (i = 0; i < nseg; i++) {     /* serial: lid = running index, complineEq2d, getGradient */
+      if (!sg[i].have) continue;
+      if (nrec < cap) {
+        const double *s = segs + 5 * (size_t)i;
+        lf_line_record *R = &recs[nrec];
+        double p[2] = {s[0], s[1]}, q[2] = {s[2], s[3]}, l0, l1, l2, nn;
+        memset(R, 0, sizeof *R);
+        R->p[0] = p[0]; R->p[1] = p[1]; R->q[0] = q[0]; R->q[1] = q[1];
+        R->lid = nrec; R->seg = i;
+        /* complineEq2d, lineslam.h:139-150: (p,1) x (q,1), normalised by sqrt(a^2+b^2) */
+        l0 = p[1] * 1.0 - 1.0 * q[1]; l1 = 1.0 * q[0] - p[0] * 1.0; l2 = p[0] * q[1] - p[1] * q[0];
+        nn = sqrt(l0 * l0 + l1 * l1);
+        R->lineEq2d[0] = l0 / nn; R->lineEq2d[1] = l1 / nn; R->lineEq2d[2] = l2 / nn;
+        oracle_line_gradient(gx, gy, w, h, p, q, R->r);
+        kept[nrec] = i;
+      }
+      nrec++;
+    }
+    {
+      const int nk = nrec < cap ? nrec : cap;
+      int li;
+#pragma omp parallel for schedule(dynamic, 4) private(k)
+      for (li = 0; li < nk; li++) {
+        const int si = kept[li];
+        lf_line_record *R = &recs[li];
+        double info[10], A9[9], V[9], wv[3], A[3], B[3];
+        int r2, c2;
+        oracle_msld(gx, gy, w, h, R->p, R->q, R->r, P->msld_sample_interval, P->rng_seed, LF_STREAM_LINE3D(frame_id, si), R->des);
+        for (k = 0; k < 3; k++) { A[k] = sg[si].A[k]; B[k] = sg[si].B[k]; }
+        oracle_mle_line3d(sg[si].sup, sg[si].ninl, P->line3d_mle_iter_num, A, B, R->covA, R->covB, info);
+        for (k = 0; k < 3; k++) { R->A[k] = A[k]; R->B[k] = B[k]; }
+        /* rndA / rndB = RandomPoint3d(A, covA) */
+        for (k = 0; k < 9; k++) A9[k] = R->covA[k];
+        lf_jacobi3(A9, V, wv);
+        for (r2 = 0; r2 < 3; r2++) { R->Wsa[r2] = sqrt(wv[r2]); for (c2 = 0; c2 < 3; c2++) R->DUa[3 * r2 + c2] = (1 / R->Wsa[r2]) * V[3 * c2 + r2]; }
+        for (k = 0; k < 9; k++) A9[k] = R->covB[k];
+        lf_jacobi3(A9, V, wv);
+        for (r2 = 0; r2 < 3; r2++) { R->Wsb[r2] = sqrt(wv[r2]); for (c2 = 0; c2 < 3; c2++) R->DUb[3 * r2 + c2] = (1 / R->Wsb[r2]) * V[3 * c2 + r2]; }
       }
     }
-    if (cand_info) { cand_info[8 * (size_t)i + 0] = numSmp; cand_info[8 * (size_t)i + 1] = np; }
-    { double need = numSmp * P->ratio_of_collinear_pts; if (need < 10.0) need = 10.0; if (np < need) continue; } /* :289 */
-    for (j = 0; j < np; j++) o_comp_pt3d_cov(pts3[j], K[0], P, &rp[j]);
-    ninl = o_extract3dline(rp, np, P, P->rng_seed, LF_STREAM_LINE3D(frame_id, i), A, B, inl);
-    if (cand_info) { cand_info[8 * (size_t)i + 2] = ninl; for (k = 0; k < 3; k++) cand_info[8 * (size_t)i + 3 + k] = A[k]; }
-    if (ninl / numSmp > P->ratio_of_collinear_pts &&
-        sqrt((A[0] - B[0]) * (A[0] - B[0]) + (A[1] - B[1]) * (A[1] - B[1]) + (A[2] - B[2]) * (A[2] - B[2])) > P->line3d_length_thresh)
-      have = 1; /* :302-307 */
-    if (!have) continue;
-    if (cand_flag) cand_flag[i] = 2;
-    if (nrec < cap) {
-      lf_line_record *R = &recs[nrec];
-      double l0, l1, l2, nn, info[10], A9[9], V[9], wv[3];
-      int r2, c2;
-      memset(R, 0, sizeof *R);
-      R->p[0] = p[0]; R->p[1] = p[1]; R->q[0] = q[0]; R->q[1] = q[1];
-      R->lid = nrec; R->seg = i;
-      /* complineEq2d, lineslam.h:139-150: (p,1) x (q,1), normalised by sqrt(a^2+b^2) */
-      l0 = p[1] * 1.0 - 1.0 * q[1]; l1 = 1.0 * q[0] - p[0] * 1.0; l2 = p[0] * q[1] - p[1] * q[0];
-      nn = sqrt(l0 * l0 + l1 * l1);
-      R->lineEq2d[0] = l0 / nn; R->lineEq2d[1] = l1 / nn; R->lineEq2d[2] = l2 / nn;
-      oracle_line_gradient(gx, gy, w, h, p, q, R->r);
-      oracle_msld(gx, gy, w, h, p, q, R->r, P->msld_sample_interval, P->rng_seed, LF_STREAM_LINE3D(frame_id, i), R->des);
-      for (j = 0; j < ninl; j++) sup[j] = rp[inl[j]];
-      oracle_mle_line3d(sup, ninl, P->line3d_mle_iter_num, A, B, R->covA, R->covB, info);
-      for (k = 0; k < 3; k++) { R->A[k] = A[k]; R->B[k] = B[k]; }
-      /* rndA / rndB = RandomPoint3d(A, covA) */
-      for (k = 0; k < 9; k++) A9[k] = R->covA[k];
-      lf_jacobi3(A9, V, wv);
-      for (r2 = 0; r2 < 3; r2++) { R->Wsa[r2] = sqrt(wv[r2]); for (c2 = 0; c2 < 3; c2++) R->DUa[3 * r2 + c2] = (1 / R->Wsa[r2]) * V[3 * c2 + r2]; }
-      for (k = 0; k < 9; k++) A9[k] = R->covB[k];
-      lf_jacobi3(A9, V, wv);
-      for (r2 = 0; r2 < 3; r2++) { R->Wsb[r2] = sqrt(wv[r2]); for (c2 = 0; c2 < 3; c2++) R->DUb[3 * r2 + c2] = (1 / R->Wsb[r2]) * V[3 * c2 + r2]; }
-    }
-    nrec++;
+    for (i = 0; i < nseg; i++) free(sg[i].sup);
+    free(sg); free(kept);
   }
   free(gx); free(gy);
   return nrec;
 }
+
+/* threads of the OpenMP flavour (bench.py's reference-shaped CPU baseline); 1 in the other flavours */
+#ifdef _OPENMP
+#include <omp.h>
+int oracle_omp_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int oracle_omp_threads(int n) { (void)n; return 1; }
+#endif
 
 /* exported helpers for primitive-level tests */
 void oracle_jacobi3(const double *A, double *V, double *w) { double T[9]; int i; for (i = 0; i < 9; i++) T[i] = A[i]; lf_jacobi3(T, V, w); }

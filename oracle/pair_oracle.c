@@ -73,6 +73,7 @@ int oracle_line_matching(const lf_line_record *f1, int n1, const lf_line_record 
   else { lineDistThresh = 80; descDiffThresh = 0.7; lineOverlapThresh = -1; }
   if (n1 == 0 || n2 == 0) return 0;
   D = (double *)malloc(sizeof(double) * (size_t)n1 * n2);
+#pragma omp parallel for private(j)      /* node.cpp:1644 (active in the OpenMP flavour only) */
   for (i = 0; i < n1; ++i)
     for (j = 0; j < n2; ++j) {
       double v = 100;

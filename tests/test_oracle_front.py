@@ -162,3 +162,28 @@ def test_front_end_is_deterministic_and_seed_sensitive(synth_frame):
     P.rng_seed = 123
     r3, f3, _ = O.detect3d_oracle(g, d, synth.K_TUM, P, 0, segs)
     assert abs(len(r3) - len(r1)) <= 3          # RANSAC draws change, the answer barely does
+
+
+def test_openmp_flavour_equals_the_serial_one():
+    """_build/liboracle_omp.so (the reference's OpenMP loops switched on: bench.py's reference-shaped CPU baseline) computes
+    bit for bit what the serial libm flavour computes, whatever the schedule."""
+    from lineslam_amd import capi
+    g, d, _ = synth.sequence(2, seed=8)
+    P = capi.default_params(launch=True)
+    omp = O.oracle_lib("omp")
+    omp.oracle_omp_threads.restype = int
+    assert omp.oracle_omp_threads(4) >= 1
+    recs = {}
+    for fl in ("ref", "omp"):
+        out = []
+        for k in range(2):
+            segs, _ = O.lsd_oracle(g[k], P.lsd_angle_th, P.lsd_density_th, flavour="ref")
+            r, flag, info = O.detect3d_oracle(g[k], d[k], synth.K_TUM, P, k, segs, flavour=fl)
+            out.append((r, flag, info))
+        recs[fl] = out
+    for k in range(2):
+        assert recs["ref"][k][0].tobytes() == recs["omp"][k][0].tobytes()
+        assert np.array_equal(recs["ref"][k][1], recs["omp"][k][1]) and np.array_equal(recs["ref"][k][2], recs["omp"][k][2])
+    a = O.match_oracle(recs["ref"][1][0], recs["ref"][0][0], True, flavour="ref")
+    b = O.match_oracle(recs["ref"][1][0], recs["ref"][0][0], True, flavour="omp")
+    assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b))
