@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--inflight", type=int, default=4, help="passes in flight (contexts / HIP streams); 1 = serial")
+    ap.add_argument("--exchange", choices=("lib", "torch"), default="lib",
+                    help="carrier of the key-frame all-gather with N > 1: lf_allgather_keyframes (RCCL inside liblinefront.so) "
+                         "or the same payload through torch.distributed (lineslam_amd/parallel.py)")
     ap.add_argument("--points", action="store_true",
                     help="BASELINE configs[2] instead of configs[1]: fused point + line odometry -- projectTo3D, Hamming "
                          "feature matching and the hybrid RANSAC / LM solver on synthetic key points (the ORB extractor "
@@ -142,7 +145,7 @@ def main():
     dist_on = world > 1 or os.environ.get("LF_BENCH_FORCE_EXCHANGE") == "1"
     import torch
     import torch.distributed as dist
-    from lineslam_amd import ate, build, capi, synth
+    from lineslam_amd import ate, build, capi, parallel, synth
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     torch.cuda.set_device(local)
@@ -169,8 +172,7 @@ def main():
     pq, pt = np.arange(1, F, dtype=np.int32), np.arange(0, F - 1, dtype=np.int32)
     K = synth.K_TUM
     # keyframe line maps for the loop-closure exchange (config 5): fixed-stride records, one all-gather per step
-    kf = np.linspace(0, F - 1, a.keyframes).astype(np.int64) if dist_on else None
-    rec_bytes, line_cap = 1040, 512
+    kf = parallel.pick_keyframes(F, a.keyframes) if dist_on else None
 
     pts_state = None
     if a.points:
@@ -187,9 +189,25 @@ def main():
                 md=torch.zeros((F, NK), dtype=torch.float32, device="cuda"), nm=torch.zeros(F, dtype=torch.int32, device="cuda")))
 
     n_lc = 64   # loop-closure queries per step on every rank (config 4 style: local frames vs all keyframes)
-    sel = torch.from_numpy(kf).cuda() if dist_on else None      # (device-resident: nothing in a step blocks the host)
-    lc_q = np.full(n_lc, F - 1, np.int32)
-    lc_t = (np.arange(n_lc) % (world * len(kf))).astype(np.int32) if dist_on else None
+    lc_q, lc_t = parallel.loop_closure_pairs(n_lc, F - 1, world, len(kf)) if dist_on else (None, None)
+    exch, carrier = {}, a.exchange
+    if dist_on:
+        # node ids of different ranks far apart (loop closures, never "adjacent"); ONE all-gather per step and context
+        if carrier == "lib":
+            try:
+                uid = [capi.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                for c in ctxs:
+                    exch[id(c)] = parallel.KeyframeExchange(c, torch, dist, world, rank, kf, 100000 * (rank + 1), "lib",
+                                                            comm_owner=ctxs[0] if c is not ctxs[0] else None, unique_id=uid[0])
+            except capi.LinefrontError as e:
+                if world > 1:
+                    raise                  # (a rank-dependent fallback would desynchronise the collectives)
+                print("bench: library exchange unavailable (%s): torch carrier" % e, file=sys.stderr)
+                carrier, exch = "torch", {}
+        if carrier == "torch":
+            for c in ctxs:
+                exch[id(c)] = parallel.KeyframeExchange(c, torch, dist, world, rank, kf, 100000 * (rank + 1), "torch")
 
     def step(i):
         ctx = ctxs[i % nfl]
@@ -212,23 +230,12 @@ def main():
         else:
             ctx.match_pairs_device(pq, pt)
         if dist_on:
-            recs_t, nl_t, ids_t = views[id(ctx)]
-            mine_r = recs_t[sel].contiguous()                                   # [kf, line_cap*1040] u8
-            mine_n = nl_t[sel].contiguous()
-            mine_i = (ids_t[sel] + 100000 * (rank + 1)).contiguous()           # node ids far apart: loop closures
-            all_r = torch.empty((world * len(kf), mine_r.shape[1]), dtype=torch.uint8, device="cuda")
-            all_n = torch.empty(world * len(kf), dtype=torch.int32, device="cuda")
-            all_i = torch.empty(world * len(kf), dtype=torch.int64, device="cuda")
-            dist.all_gather_into_tensor(all_r, mine_r)   # RCCL over xGMI: keyframe line maps of all ranks
-            dist.all_gather_into_tensor(all_n, mine_n)
-            dist.all_gather_into_tensor(all_i, mine_i)
-            # loop-closure candidates: the rank's newest frames against every gathered keyframe slot (round robin)
-            ctx.match_external_device(lc_q, lc_t, all_r.data_ptr(), all_n.data_ptr(), all_i.data_ptr(), world * len(kf), ctx.line_cap)
-            return all_r
+            # RCCL over xGMI: the key-frame line maps of all ranks, then loop-closure candidates against the gathered map
+            r_ptr, n_ptr, i_ptr, n_slots, ext_cap = exch[id(ctx)].exchange()
+            ctx.match_external_device(lc_q, lc_t, r_ptr, n_ptr, i_ptr, n_slots, ext_cap)
+            return n_slots
         return None
 
-    # zero-copy torch views of every context's line maps (taken once: importing a device array may synchronise)
-    views = {id(c): c.device_records(torch) for c in ctxs} if dist_on else {}
     sweep_ms, pre_ms, front_ms, pair_ms = [], [], [], []
     for c in ctxs[min(a.warmup, nfl):]:       # contexts the warm-up steps do not reach: one set-up pass each (tables, lazy loads)
         with torch.cuda.stream(streams[ctxs.index(c)]):
@@ -313,7 +320,8 @@ def main():
                        "frames_per_gpu": F, "params": "ParameterServer defaults" if a.default_params else "launch/lineslam.launch (lsd_angle_thres 40, min_matches 10)",
                        "lines_per_frame": nlines, "passes_in_flight": nfl,
                        "parallelism": "frames in flight: one wavefront per frame (LSD sweep), "
-                       "per segment (3D fit), per pair (pose); %d passes in flight on separate HIP streams" % nfl + ("; %d ranks, 1 sequence each, 1 all-gather/step" % world if world > 1 else "")},
+                       "per segment (3D fit), per pair (pose); %d passes in flight on separate HIP streams" % nfl +
+                       ("; %d ranks, 1 sequence each, 1 all-gather of %d key-frame maps per step (%s carrier)" % (world, len(kf), carrier) if dist_on else "")},
             "roofline": {"bound": "hbm", "kernel": "k_lsd_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": sw, "algorithmic_bytes_per_launch": algo,

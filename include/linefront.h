@@ -399,6 +399,28 @@ LF_API int lf_match_external_device(lf_ctx *ctx, const int32_t *query_frames, co
                                     const int32_t *d_ext_nlines, const uint64_t *d_ext_ids, int ext_frames,
                                     int ext_line_cap);
 
+/* ---- multi-GPU inside the library: ONE RCCL collective per batch of key frames ----------------
+ * One process per GPU.  A context joins a communicator of `world_size` ranks: rank 0 obtains a 128-byte id with
+ * lf_comm_unique_id and hands it to the other ranks by any side channel (MPI, torch.distributed, a file, ROS), then every
+ * rank calls lf_comm_init with it (collective: ncclCommInitRank).  RCCL is loaded at run time (the copy already in the
+ * process -- e.g. PyTorch's -- or /opt/rocm/lib/librccl.so.1); without it these calls return LF_ERR_UNSUPPORTED.
+ * Several contexts of one process may share a communicator (lf_comm_attach): their collectives are then issued in the
+ * same order on every rank, as RCCL requires. */
+#define LF_COMM_ID_BYTES 128
+LF_API int lf_comm_unique_id(uint8_t id[LF_COMM_ID_BYTES]);
+LF_API int lf_comm_init(lf_ctx *ctx, int world_size, int rank, const uint8_t id[LF_COMM_ID_BYTES], int max_keyframes);
+LF_API int lf_comm_attach(lf_ctx *ctx, lf_ctx *owner);     /* share owner's communicator (same device, same process) */
+LF_API int lf_comm_destroy(lf_ctx *ctx);
+/* The exchange of key-frame line maps: the n_kf frame slots kf_slots[] (HOST array) of this context's last batch are
+ * packed -- per key frame one header row (line count, node id + id_offset) followed by line_cap lf_line_record rows, all
+ * 1040-byte rows -- and gathered from every rank with ONE ncclAllGather on the context stream.  The result is the map
+ * lf_match_external_device / lf_line_matching_device take: *d_recs (row stride *ext_line_cap = line_cap + 1 records
+ * per key frame), *d_nlines, *d_ids, *n_frames = world_size * n_kf slots, slot = rank * n_kf + k.  The buffers stay owned
+ * by the context and are overwritten by its next exchange.  Asynchronous; every rank must pass the same n_kf. */
+LF_API int lf_allgather_keyframes(lf_ctx *ctx, const int32_t *kf_slots, int n_kf, uint64_t id_offset,
+                                  const lf_line_record **d_recs, const int32_t **d_nlines, const uint64_t **d_ids,
+                                  int *n_frames, int *ext_line_cap);
+
 /* MatchingResult Node::matchNodePair(const Node* older_node) (src/node.h:107) for two nodes whose
  * `lines` live in host memory: uploads both line maps into slots 0/1 of the context, runs
  * lineMatching + RANSAC + LM, returns the flat MatchingResult.  Matches / inliers of the pair are

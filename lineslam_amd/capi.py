@@ -102,6 +102,11 @@ SYMBOLS = {
     "lf_solve_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, _vp, _i, C.c_uint64, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
                                 _vp, _vp]),
     "lf_mle_lines": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "lf_comm_unique_id": (_i, [_vp]),
+    "lf_comm_init": (_i, [_vp, _i, _i, _vp, _i]),
+    "lf_comm_attach": (_i, [_vp, _vp]),
+    "lf_comm_destroy": (_i, [_vp]),
+    "lf_allgather_keyframes": (_i, [_vp, _vp, _i, C.c_uint64, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _pi, _pi]),
     "lf_line_matching_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, C.c_uint64, _i, _vp, _vp, _vp, _i, _pi]),
 }
 
@@ -515,6 +520,26 @@ class Context:
         self._chk(lib().lf_get_stage_ms(self._h, which, C.byref(v)), "lf_get_stage_ms")
         return float(v.value)
 
+    # ---- multi-GPU: key-frame exchange inside the library (RCCL) -------------------------------
+    def comm_init(self, world_size, rank, unique_id, max_keyframes=32):
+        """Join the communicator of the key-frame exchange (collective: every rank calls it with rank 0's id)."""
+        uid = np.ascontiguousarray(np.frombuffer(bytes(unique_id), np.uint8))
+        assert len(uid) == 128
+        self._chk(lib().lf_comm_init(self._h, int(world_size), int(rank), uid.ctypes.data, int(max_keyframes)), "lf_comm_init")
+
+    def comm_attach(self, owner):
+        self._chk(lib().lf_comm_attach(self._h, owner._h), "lf_comm_attach")
+
+    def allgather_keyframes(self, kf_slots, id_offset=0):
+        """lf_allgather_keyframes: pack + ONE ncclAllGather + header unpack on the context stream (async).
+        Returns (recs_ptr, nlines_ptr, ids_ptr, n_slots, ext_line_cap) for match_external_device / line_matching_device."""
+        kf = np.ascontiguousarray(kf_slots, np.int32)
+        r, n, i = _vp(), _vp(), _vp()
+        ns, cap = C.c_int(), C.c_int()
+        self._chk(lib().lf_allgather_keyframes(self._h, kf.ctypes.data, len(kf), C.c_uint64(int(id_offset)), C.byref(r), C.byref(n),
+                                               C.byref(i), C.byref(ns), C.byref(cap)), "lf_allgather_keyframes")
+        return r.value, n.value, i.value, ns.value, cap.value
+
     # ---- multi-GPU plumbing ---------------------------------------------------------------
     def device_records(self, torch):
         """torch uint8/int32/int64 views (no copy) of the record, count and node-id arrays of the last batch:
@@ -567,6 +592,15 @@ class Context:
 class LfGraphView(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("matchable", C.c_void_p), ("n_edges", C.c_int32), ("edge_from", C.c_void_p),
                 ("edge_to", C.c_void_p), ("n_keyframes", C.c_int32), ("keyframe_ids", C.c_void_p)]
+
+
+def comm_unique_id():
+    """128-byte id of a new communicator (rank 0 calls this and hands the bytes to the other ranks)."""
+    uid = np.zeros(128, np.uint8)
+    r = lib().lf_comm_unique_id(uid.ctypes.data)
+    if r != LF_OK:
+        raise LinefrontError(r, "lf_comm_unique_id")
+    return uid.tobytes()
 
 
 def candidate_targets(n_nodes, edges, matchable=None, keyframes=(), predecessor_id=-1, sequential_targets=1,

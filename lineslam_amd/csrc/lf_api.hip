@@ -11,6 +11,8 @@
 #include "lf_points.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: the library is bound at run time (dlopen), never at link time
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -52,6 +54,13 @@ struct lf_ctx {
   PairBuffers last_pb;               // the buffers of the last pair launch (train side may be an external map)
   unsigned char *d_adjacent = nullptr;   // [maxB] adjacentFrame flags of lf_line_matching_device
   double *d_descdiff = nullptr;      // lf_pair_get_descdiff scratch (line_cap^2 doubles), allocated on first use
+  // ---- key-frame exchange over RCCL
+  ncclComm_t comm = nullptr;
+  bool comm_owner = false;
+  int comm_world = 0, comm_rank = 0, comm_max_kf = 0;
+  lf_line_record *d_xsend = nullptr, *d_xrecv = nullptr;   // [max_kf][line_cap + 1], [world * max_kf][line_cap + 1]
+  int *d_xnlines = nullptr, *d_xslots = nullptr;
+  uint64_t *d_xids = nullptr;
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint8_t *d_gray_stage = nullptr;   // staging for the host-pointer convenience entry points
   float *d_depth_stage = nullptr;
@@ -433,6 +442,7 @@ void lf_ctx_destroy(lf_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)lf_comm_destroy(c);
   for (void *p : c->allocs) (void)hipFree(p);
   for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->ev_stage_ids) (void)hipEventDestroy(c->ev_stage_ids);
@@ -1273,6 +1283,137 @@ int lf_mle_lines(lf_ctx *c, const double *pts, const int32_t *pt_offset, const i
   HIPCHK(c, hipMemcpyAsync(ho.data(), c->fb.cand_out, ho.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (iters) for (int i = 0; i < n_lines; i++) iters[i] = (int)ho[(size_t)i * LF_CAND_STRIDE + 27];
+  return LF_OK;
+}
+
+
+// ---- key-frame exchange: RCCL bound at run time --------------------------------------------------------------------------
+struct RcclApi {
+  void *h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+static RcclApi &rccl() {
+  static RcclApi a;
+  static bool tried = false;
+  if (tried) return a;
+  tried = true;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (int pass = 0; pass < 2 && !a.h; pass++)          // first the copy already in the process (PyTorch ships its own)
+    for (const char *n : names) {
+      a.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+      if (a.h) break;
+    }
+  if (!a.h) return a;
+  a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.h, "ncclGetUniqueId");
+  a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.h, "ncclCommInitRank");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.h, "ncclCommDestroy");
+  a.AllGather = (decltype(a.AllGather))dlsym(a.h, "ncclAllGather");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.h, "ncclGetErrorString");
+  a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather;
+  return a;
+}
+static int fail_nccl(lf_ctx *c, ncclResult_t r, const char *what) {
+  if (c) { c->err = std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r) : "RCCL error"); }
+  return LF_ERR_HIP;
+}
+
+// pack: block (k, part) copies header / record rows of key frame k into the send buffer
+__global__ void __launch_bounds__(256) k_pack_keyframes(const lf_line_record *recs, const int *nlines, const uint64_t *ids, int line_cap,
+                                                         const int *slots, uint64_t id_offset, lf_line_record *send) {
+  const int k = blockIdx.y, slot = slots[k];
+  int n = nlines[slot];
+  if (n > line_cap) n = line_cap;
+  const uint4 *src = (const uint4 *)(recs + (size_t)slot * line_cap);
+  uint4 *dst = (uint4 *)(send + (size_t)k * (line_cap + 1) + 1);
+  const size_t words = (size_t)n * (sizeof(lf_line_record) / 16);          // 1040 = 65 x 16 bytes
+  for (size_t w = (size_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (size_t)gridDim.x * 256) dst[w] = src[w];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    lf_line_record *hdr = send + (size_t)k * (line_cap + 1);
+    hdr->lid = nlines[slot];                     // header row: line count in `lid`, node id in the first 8 bytes of `p`
+    hdr->seg = 0x4B46;                           // 'KF'
+    *(uint64_t *)hdr->p = ids[slot] + id_offset;
+  }
+}
+__global__ void k_unpack_headers(const lf_line_record *recv, int line_cap, int n_slots, int *nlines, uint64_t *ids) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const lf_line_record *hdr = recv + (size_t)s * (line_cap + 1);
+  nlines[s] = hdr->lid;
+  ids[s] = *(const uint64_t *)hdr->p;
+}
+
+int lf_comm_unique_id(uint8_t id[LF_COMM_ID_BYTES]) {
+  if (!id) return LF_ERR_INVALID;
+  if (!rccl().ok) return LF_ERR_UNSUPPORTED;
+  ncclUniqueId u;
+  static_assert(sizeof(u) == LF_COMM_ID_BYTES, "ncclUniqueId size");
+  if (rccl().GetUniqueId(&u) != ncclSuccess) return LF_ERR_HIP;
+  memcpy(id, &u, sizeof u);
+  return LF_OK;
+}
+static int comm_buffers(lf_ctx *c, int world, int max_kf) {
+  const size_t rows = (size_t)c->fc.line_cap + 1;
+  ALLOC(c, c->d_xsend, (size_t)max_kf * rows);
+  ALLOC(c, c->d_xrecv, (size_t)world * max_kf * rows);
+  ALLOC(c, c->d_xnlines, (size_t)world * max_kf);
+  ALLOC(c, c->d_xids, (size_t)world * max_kf);
+  ALLOC(c, c->d_xslots, (size_t)max_kf);
+  c->comm_max_kf = max_kf;
+  return LF_OK;
+}
+int lf_comm_init(lf_ctx *c, int world_size, int rank, const uint8_t id[LF_COMM_ID_BYTES], int max_keyframes) {
+  if (!c || !id || world_size < 1 || rank < 0 || rank >= world_size || max_keyframes < 1) return LF_ERR_INVALID;
+  if (c->comm) return LF_ERR_INVALID;
+  if (!rccl().ok) { c->err = "librccl.so.1 not found"; return LF_ERR_UNSUPPORTED; }
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  ncclResult_t r = rccl().CommInitRank(&c->comm, world_size, u, rank);
+  if (r != ncclSuccess) { c->comm = nullptr; return fail_nccl(c, r, "ncclCommInitRank"); }
+  c->comm_owner = true; c->comm_world = world_size; c->comm_rank = rank;
+  return comm_buffers(c, world_size, max_keyframes);
+}
+int lf_comm_attach(lf_ctx *c, lf_ctx *owner) {
+  if (!c || !owner || !owner->comm || c->comm || c->device != owner->device || c->fc.line_cap != owner->fc.line_cap) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->comm = owner->comm; c->comm_owner = false; c->comm_world = owner->comm_world; c->comm_rank = owner->comm_rank;
+  return comm_buffers(c, owner->comm_world, owner->comm_max_kf);
+}
+int lf_comm_destroy(lf_ctx *c) {
+  if (!c) return LF_ERR_INVALID;
+  if (c->comm && c->comm_owner) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)rccl().CommDestroy(c->comm);
+  }
+  c->comm = nullptr; c->comm_owner = false;
+  return LF_OK;
+}
+int lf_allgather_keyframes(lf_ctx *c, const int32_t *kf_slots, int n_kf, uint64_t id_offset, const lf_line_record **d_recs,
+                           const int32_t **d_nlines, const uint64_t **d_ids, int *n_frames, int *ext_line_cap) {
+  if (!c || !kf_slots || n_kf < 1 || !d_recs || !d_nlines || !d_ids || !n_frames || !ext_line_cap) return LF_ERR_INVALID;
+  if (!c->comm) { c->err = "lf_comm_init has not been called"; return LF_ERR_INVALID; }
+  if (n_kf > c->comm_max_kf) return LF_ERR_CAPACITY;
+  for (int k = 0; k < n_kf; k++) if (kf_slots[k] < 0 || kf_slots[k] >= c->last_batch) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(c->d_xslots, kf_slots, sizeof(int) * (size_t)n_kf, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));          // (the caller's slot list may be a temporary; 4 n_kf bytes)
+  const int L = c->fc.line_cap;
+  hipLaunchKernelGGL(k_pack_keyframes, dim3(16, n_kf), dim3(256), 0, c->stream, (const lf_line_record *)c->fb.recs, (const int *)c->fb.nlines,
+                     (const uint64_t *)c->d_frame_ids, L, (const int *)c->d_xslots, id_offset, c->d_xsend);
+  HIPCHK(c, hipGetLastError());
+  const size_t bytes = (size_t)n_kf * (L + 1) * sizeof(lf_line_record);
+  ncclResult_t r = rccl().AllGather(c->d_xsend, c->d_xrecv, bytes, ncclUint8, c->comm, c->stream);   // the ONE collective
+  if (r != ncclSuccess) return fail_nccl(c, r, "ncclAllGather");
+  const int ns = c->comm_world * n_kf;
+  hipLaunchKernelGGL(k_unpack_headers, dim3((ns + 255) / 256), dim3(256), 0, c->stream, (const lf_line_record *)c->d_xrecv, L, ns, c->d_xnlines, c->d_xids);
+  HIPCHK(c, hipGetLastError());
+  *d_recs = c->d_xrecv + 1;                 // the records of slot s start one (header) row into its block
+  *d_nlines = c->d_xnlines; *d_ids = c->d_xids; *n_frames = ns; *ext_line_cap = L + 1;
   return LF_OK;
 }
 

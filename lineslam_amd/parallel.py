@@ -1,9 +1,18 @@
-"""Multi-GPU plumbing (one process per GPU, torch.distributed; backend "nccl" == RCCL on ROCm, "gloo" in the
-CPU tests).  The front end shards with no data-path collective; the only exchange is the all-gather of
-keyframe line maps for loop-closure matching."""
+"""Multi-GPU plumbing (one process per GPU).  The front end shards with no data-path collective; the only exchange is ONE
+all-gather per step of key-frame line maps for loop-closure matching.
+
+Two carriers of the same payload (bit-identical layout, tests/test_exchange_gpu.py):
+  * `KeyframeExchange(..., carrier="lib")`  -- lf_allgather_keyframes: pack kernel + ONE ncclAllGather (RCCL over xGMI) +
+    header unpack inside liblinefront.so, on the context's HIP stream (what a C++ / ROS caller uses);
+  * `carrier="torch"`                        -- the same packing with torch ops and ONE dist.all_gather_into_tensor
+    (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests, where no GPU and no liblinefront compute exist).
+Payload per key frame: one 1040-byte header row (node id in bytes 0..7, line count in the int32 at byte 1032 = the `lid`
+member) followed by line_cap lf_line_record rows; slot of (rank r, key frame k) in the gathered map = r * n_kf + k.
+"""
 import numpy as np
 
 REC_BYTES = 1040
+HDR_ID_OFF, HDR_N_OFF, HDR_TAG_OFF = 0, 1032, 1036
 
 
 def shard_sequences(n_sequences, world, rank):
@@ -24,14 +33,77 @@ def pick_keyframes(n_frames, n_key):
     return np.linspace(0, n_frames - 1, n_key).astype(np.int64)
 
 
-def gather_keyframe_maps(dist, torch, recs_u8, nlines, ids):
-    """recs_u8 [K, line_cap*1040] uint8, nlines [K] int32, ids [K] int64 on this rank's device (or CPU for gloo).
-    Returns the concatenation over ranks (rank-major) -- ONE all-gather per array, fixed stride."""
-    world = dist.get_world_size()
-    all_r = torch.empty((world * recs_u8.shape[0], recs_u8.shape[1]), dtype=torch.uint8, device=recs_u8.device)
-    all_n = torch.empty(world * nlines.shape[0], dtype=torch.int32, device=nlines.device)
-    all_i = torch.empty(world * ids.shape[0], dtype=torch.int64, device=ids.device)
-    dist.all_gather_into_tensor(all_r, recs_u8.contiguous())
-    dist.all_gather_into_tensor(all_n, nlines.contiguous())
-    dist.all_gather_into_tensor(all_i, ids.contiguous())
-    return all_r, all_n, all_i
+def loop_closure_pairs(n_lc, query_slot, world, n_kf):
+    """The loop-closure candidates of one step: the rank's newest frame (slot `query_slot`) against the gathered key-frame
+    slots, round robin over ALL ranks' key frames.  Returns (query slots, train slots of the gathered map)."""
+    q = np.full(n_lc, query_slot, np.int32)
+    t = (np.arange(n_lc) % (world * n_kf)).astype(np.int32)
+    return q, t
+
+
+def slot_owner(slot, n_kf):
+    """(rank, key-frame index) of a slot of the gathered map."""
+    return int(slot) // n_kf, int(slot) % n_kf
+
+
+def pack_keyframes(torch, recs_u8, nlines, ids, sel, id_offset, line_cap):
+    """recs_u8 [B, line_cap*1040] uint8, nlines [B] int32, ids [B] int64; sel [K] int64 key-frame slots.
+    Returns the send blob [K, (line_cap+1)*1040] uint8 (header row + record rows per key frame)."""
+    K = sel.shape[0]
+    blob = torch.zeros((K, (line_cap + 1) * REC_BYTES), dtype=torch.uint8, device=recs_u8.device)
+    blob[:, REC_BYTES:] = recs_u8[sel]
+    hdr_id = (ids[sel].to(torch.int64) + int(id_offset)).contiguous()
+    hdr_n = nlines[sel].to(torch.int32).contiguous()
+    blob[:, HDR_ID_OFF:HDR_ID_OFF + 8] = hdr_id.view(torch.uint8).reshape(K, 8)
+    blob[:, HDR_N_OFF:HDR_N_OFF + 4] = hdr_n.view(torch.uint8).reshape(K, 4)
+    blob[:, HDR_TAG_OFF:HDR_TAG_OFF + 4] = torch.tensor([0x46, 0x4B, 0, 0], dtype=torch.uint8, device=blob.device)   # 'KF'
+    return blob
+
+
+def unpack_headers(torch, gathered):
+    """gathered [S, (line_cap+1)*1040] uint8 -> (nlines [S] int32, ids [S] int64) read from the header rows."""
+    n = gathered[:, HDR_N_OFF:HDR_N_OFF + 4].contiguous().view(torch.int32).reshape(-1)
+    i = gathered[:, HDR_ID_OFF:HDR_ID_OFF + 8].contiguous().view(torch.int64).reshape(-1)
+    return n, i
+
+
+def gather_keyframe_maps(dist, torch, blob, group=None):
+    """ONE collective: every rank's blob [K, row_bytes] -> [world*K, row_bytes] (rank-major)."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world * blob.shape[0], blob.shape[1]), dtype=torch.uint8, device=blob.device)
+    dist.all_gather_into_tensor(out, blob.contiguous(), group=group)
+    return out
+
+
+class KeyframeExchange:
+    """Per-context state of the key-frame exchange of bench.py / the tests.
+
+    exchange() returns (recs_ptr, nlines_ptr, ids_ptr, n_slots, ext_line_cap) -- the arguments of
+    Context.match_external_device / line_matching_device(ext=...) -- after issuing the ONE all-gather of this step."""
+
+    def __init__(self, ctx, torch, dist, world, rank, kf_slots, id_offset, carrier="lib", comm_owner=None, unique_id=None):
+        self.ctx, self.torch, self.dist = ctx, torch, dist
+        self.world, self.rank = world, rank
+        self.kf = np.ascontiguousarray(kf_slots, np.int32)
+        self.id_offset = int(id_offset)
+        self.carrier = carrier
+        self._keep = None
+        if carrier == "lib":
+            if comm_owner is not None:
+                ctx.comm_attach(comm_owner)
+            else:
+                ctx.comm_init(world, rank, unique_id, max_keyframes=len(self.kf))
+        else:
+            self.views = ctx.device_records(torch)
+            self.sel = torch.from_numpy(self.kf.astype(np.int64)).to(self.views[0].device)
+
+    def exchange(self):
+        if self.carrier == "lib":
+            return self.ctx.allgather_keyframes(self.kf, self.id_offset)
+        torch = self.torch
+        recs_t, nl_t, ids_t = self.views
+        blob = pack_keyframes(torch, recs_t, nl_t, ids_t, self.sel, self.id_offset, self.ctx.line_cap)
+        allb = gather_keyframe_maps(self.dist, torch, blob)
+        n, i = unpack_headers(torch, allb)
+        self._keep = (allb, n, i)                       # alive until the next exchange of this context
+        return allb.data_ptr() + REC_BYTES, n.data_ptr(), i.data_ptr(), allb.shape[0], self.ctx.line_cap + 1
