@@ -112,13 +112,20 @@ def cpu_baseline(gray, depth, P, n_frames):
         os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")   # idle OpenMP threads sleep (read by libgomp when it is loaded)
         omp = O.oracle_lib("omp")
         omp.oracle_omp_threads.restype = int
-        nth = omp.oracle_omp_threads(ncpu)
-        m2 = min(n, 40)
-        sequential(2, "omp")      # thread pool start-up outside the timed part
-        v2 = sequential(m2, "omp")
-        variants["reference_shaped"] = {"value": v2, "cores": nth,
-                                        "sample": "%d frames, one after the other, OpenMP (%d threads) where the reference has it "
-                                                  "(lineslam.cpp:246,344, node.cpp:1644), LSD / RANSAC / LM serial" % (m2, nth)}
+        # the reference would run with OpenMP's default (every logical CPU); on a box whose container owns only a share of
+        # them that default is pathologically slow (256 threads: 2.7 frames/s), so the team size is swept and the BEST
+        # figure is the baseline -- the most favourable reading for the CPU
+        m2, best, sweep = min(n, 16), None, {}
+        for nth in [t for t in (4, 8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]:
+            omp.oracle_omp_threads(nth)
+            sequential(2, "omp")      # thread pool start-up outside the timed part
+            v = sequential(m2, "omp")
+            sweep[str(nth)] = v
+            if best is None or v > best[0]:
+                best = (v, nth)
+        variants["reference_shaped"] = {"value": best[0], "cores": best[1], "team_size_sweep_frames_per_s": sweep,
+                                        "sample": "%d frames, one after the other, OpenMP (best of the team sizes tried: %d threads) where "
+                                                  "the reference has it (lineslam.cpp:246,344, node.cpp:1644), LSD / RANSAC / LM serial" % (m2, best[1])}
     except (OSError, AttributeError):
         variants["reference_shaped"] = None
     t0 = time.perf_counter()

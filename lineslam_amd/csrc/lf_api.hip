@@ -1363,6 +1363,7 @@ static int comm_buffers(lf_ctx *c, int world, int max_kf) {
   ALLOC(c, c->d_xnlines, (size_t)world * max_kf);
   ALLOC(c, c->d_xids, (size_t)world * max_kf);
   ALLOC(c, c->d_xslots, (size_t)max_kf);
+  HIPCHK(c, hipMemsetAsync(c->d_xsend, 0, (size_t)max_kf * rows * sizeof(lf_line_record), c->stream));   // header rows: unused bytes are zero
   c->comm_max_kf = max_kf;
   return LF_OK;
 }
