@@ -195,7 +195,7 @@ def main():
                 mq=torch.zeros((F, NK), dtype=torch.int32, device="cuda"), mt=torch.zeros((F, NK), dtype=torch.int32, device="cuda"),
                 md=torch.zeros((F, NK), dtype=torch.float32, device="cuda"), nm=torch.zeros(F, dtype=torch.int32, device="cuda")))
 
-    n_lc = 64   # loop-closure queries per step on every rank (config 4 style: local frames vs all keyframes)
+    n_lc = min(64, F)   # loop-closure queries per step on every rank (config 4 style: local frames vs all keyframes)
     lc_q, lc_t = parallel.loop_closure_pairs(n_lc, F - 1, world, len(kf)) if dist_on else (None, None)
     exch, carrier = {}, a.exchange
     if dist_on:
@@ -314,6 +314,7 @@ def main():
                 traffic = None
         algo = ALGO_BYTES_PER_FRAME * F
         achieved = algo / (sw * 1e-3) / 1e9
+        n_over = int(sum(1 for r in res if r.overflow))
         out = {
             "metric": "RGB-D frames/sec (detect+match+pose) at 640\u00d7480; ATE vs reference", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
@@ -339,7 +340,7 @@ def main():
             "stage_ms": {"lsd_data_parallel": float(np.mean(pre_ms)), "lsd_sweep": sw,
                          "lines3d_msld_mle": float(np.mean(front_ms)), "match_pose": float(np.mean(pair_ms))},
             "serial": serial, "points": point_stats,
-            "quality": {"valid_pairs": int(valid.sum()), "pairs": int(len(valid)),
+            "quality": {"valid_pairs": int(valid.sum()), "pairs": int(len(valid)), "pairs_over_a_capacity": n_over,
                         "ate_rmse_m_vs_ground_truth": ate.ate_rmse(est[:, :3, 3], gt[:, :3, 3])},
         }
         if not a.no_cpu:

@@ -360,6 +360,28 @@ LF_API int lf_project_keypoints_device(lf_ctx *ctx, const float *d_depth, size_t
                                        const int32_t *d_nkp, int kp_cap, const double K[9], double depth_scaling,
                                        int max_keypoints, float *d_points_out, int32_t *d_npts_out,
                                        int32_t *d_kept_out);
+/* The ORB extractor: the ORB branch of Node::Node (src/node.cpp:222-290) for a batch of frames --
+ *   detector->detect      = AorbFeatureDetector(10000, 1.2, 8, 31, 0, 2, HARRIS_SCORE, 31, fast_threshold)
+ *                           (src/feature_adjuster.cpp:86-89 with the DetectorAdjuster's start threshold 20, src/features.cpp:75-76;
+ *                           src/aorb.cpp:727-940: 8-level pyramid, FAST-9/16 + non-maximum suppression, border filter,
+ *                           retainBest, Harris responses, intensity-centroid angle)
+ *   removeDepthless + KeyPointsFilter::retainBest(max_keypoints) + resize           (node.cpp:101-125, 257-263)
+ *   extractor->compute    = OrbDescriptorExtractor (src/features.cpp:197): GaussianBlur 7x7 sigma 2 per level, rBRIEF-256
+ * d_gray / d_depth as lf_detect3d_batch_device (d_depth may be NULL: no depth filter).  Outputs (DEVICE, rows of kp_cap):
+ * d_kp_xy [n][kp_cap][2] cv::KeyPoint::pt, d_kp_meta [n][kp_cap][4] (response, angle in degrees, octave, size; may be NULL),
+ * d_desc [n][kp_cap][32], d_nkp [n]: exactly what lf_project_keypoints_device and lf_feature_match_pairs_device take.
+ * max_keypoints <= 1024.  Asynchronous.  KeyPointsFilter::retainBest leaves its survivors in std::nth_element's order
+ * (implementation-defined) and Node cuts that order at max_keypoints; here ties are ordered by detection order. */
+LF_API int lf_orb_extract_device(lf_ctx *ctx, const uint8_t *d_gray, size_t gray_frame_stride, int gray_row_stride,
+                                 const float *d_depth, size_t depth_frame_stride, int depth_row_stride, int n_frames,
+                                 int fast_threshold, int max_keypoints, float *d_kp_xy, float *d_kp_meta, uint8_t *d_desc,
+                                 int32_t *d_nkp, int kp_cap);
+/* LF_ERR_CAPACITY if a frame of the last lf_orb_extract_device call had more corners than the extractor can rank
+ * (16384 after non-maximum suppression) or more key points than kp_cap; LF_OK otherwise.  Synchronises. */
+LF_API int lf_orb_check(lf_ctx *ctx);
+/* Pyramid level / blurred level `level` (0..7) of frame `frame` of the last call, for parity tests: *w x *h bytes. */
+LF_API int lf_orb_get_level(lf_ctx *ctx, int frame, int level, int blurred, uint8_t *out, size_t cap_bytes, int *w, int *h);
+
 /* Node::featureMatching, BRUTEFORCE / ORB branch (src/node.cpp:606-641): for every pair (newer = query_frames[i],
  * older = train_frames[i], slots of the last batch -- their node ids key the random distance offset) the two
  * nearest Hamming neighbours of every query descriptor (256-bit ORB, 32 bytes), the ratio test

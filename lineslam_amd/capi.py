@@ -102,6 +102,9 @@ SYMBOLS = {
     "lf_solve_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, _vp, _i, C.c_uint64, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
                                 _vp, _vp]),
     "lf_mle_lines": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "lf_orb_extract_device": (_i, [_vp, _vp, C.c_size_t, _i, _vp, C.c_size_t, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i]),
+    "lf_orb_check": (_i, [_vp]),
+    "lf_orb_get_level": (_i, [_vp, _i, _i, _i, _vp, C.c_size_t, _pi, _pi]),
     "lf_comm_unique_id": (_i, [_vp]),
     "lf_comm_init": (_i, [_vp, _i, _i, _vp, _i]),
     "lf_comm_attach": (_i, [_vp, _vp]),
@@ -354,6 +357,27 @@ class Context:
         """loadRawData pixel conversions on the device: RGB + 16-bit depth -> grey u8 + depth in metres (async)."""
         self._chk(lib().lf_ingest_tum_device(self._h, int(d_rgb_ptr), int(d_depth16_ptr), n_frames, float(depth_factor),
                                              int(d_gray_ptr), int(d_depth_ptr)), "lf_ingest_tum_device")
+
+    def orb_extract_device(self, d_gray_ptr, d_depth_ptr, n_frames, d_kp_xy_ptr, d_desc_ptr, d_nkp_ptr, kp_cap, d_kp_meta_ptr=0,
+                           fast_threshold=20, max_keypoints=600):
+        """The ORB branch of Node::Node for a batch of device-resident frames (async): AORB detection, removeDepthless,
+        retainBest(max_keypoints), ORB descriptors.  d_depth_ptr may be 0 (no depth filter)."""
+        w, h = self.width, self.height
+        self._chk(lib().lf_orb_extract_device(self._h, _vp(d_gray_ptr), w * h, w, _vp(d_depth_ptr) if d_depth_ptr else None, w * h, w,
+                                              n_frames, int(fast_threshold), int(max_keypoints), _vp(d_kp_xy_ptr),
+                                              _vp(d_kp_meta_ptr) if d_kp_meta_ptr else None, _vp(d_desc_ptr), _vp(d_nkp_ptr), int(kp_cap)),
+                  "lf_orb_extract_device")
+
+    def orb_check(self):
+        self._chk(lib().lf_orb_check(self._h), "lf_orb_check")
+
+    def orb_level(self, frame, level, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        self._chk(lib().lf_orb_get_level(self._h, frame, level, int(blurred), None, 0, C.byref(w), C.byref(h)), "lf_orb_get_level")
+        out = np.zeros((h.value, w.value), np.uint8)
+        self._chk(lib().lf_orb_get_level(self._h, frame, level, int(blurred), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h)),
+                  "lf_orb_get_level")
+        return out
 
     def project_keypoints_device(self, d_depth_ptr, n_frames, d_kp_ptr, d_nkp_ptr, kp_cap, K, d_points_ptr, d_npts_ptr,
                                  d_kept_ptr=0, depth_scaling=1.0, max_keypoints=600):

@@ -9,6 +9,7 @@
 #include "lf_front.h"
 #include "lf_pair.h"
 #include "lf_points.h"
+#include "lf_orb.h"
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -54,6 +55,12 @@ struct lf_ctx {
   PairBuffers last_pb;               // the buffers of the last pair launch (train side may be an external map)
   unsigned char *d_adjacent = nullptr;   // [maxB] adjacentFrame flags of lf_line_matching_device
   double *d_descdiff = nullptr;      // lf_pair_get_descdiff scratch (line_cap^2 doubles), allocated on first use
+  // ---- ORB extractor (buffers allocated on first use)
+  bool orb_ready = false;
+  OrbConsts oc;
+  OrbBuffers ob;
+  int *d_orb_nkp = nullptr;
+  int orb_last = 0;
   // ---- key-frame exchange over RCCL
   ncclComm_t comm = nullptr;
   bool comm_owner = false;
@@ -1415,6 +1422,109 @@ int lf_allgather_keyframes(lf_ctx *c, const int32_t *kf_slots, int n_kf, uint64_
   HIPCHK(c, hipGetLastError());
   *d_recs = c->d_xrecv + 1;                 // the records of slot s start one (header) row into its block
   *d_nlines = c->d_xnlines; *d_ids = c->d_xids; *n_frames = ns; *ext_line_cap = L + 1;
+  return LF_OK;
+}
+
+
+// ---- ORB extractor ---------------------------------------------------------------------------------------------------
+static int orb_prepare(lf_ctx *c) {
+  OrbConsts &o = c->oc;
+  memset(&o, 0, sizeof o);
+  o.W = c->W; o.H = c->H;
+  int off = 0;
+  for (int l = 0; l < LF_ORB_LEVELS; l++) {
+    const float sf = (float)pow((double)1.2f, (double)l);          // getScale (aorb.cpp:555-558), float scaleFactor member
+    const float inv = 1 / sf;
+    o.sf[l] = sf; o.inv_sf[l] = inv;
+    o.lw[l] = (int)nearbyint((double)((float)c->W * inv));          // Size(cvRound(cols * scale), cvRound(rows * scale))
+    o.lh[l] = (int)nearbyint((double)((float)c->H * inv));
+    if (o.lw[l] < 1 || o.lh[l] < 1 || o.lw[l] > 1023 || o.lh[l] > 511) return LF_ERR_UNSUPPORTED;   // key layout: x 10 bits, y 9 bits
+    o.loff[l] = off;
+    off += o.lw[l] * o.lh[l];
+    if (l > 0) { o.scale_x[l] = 1. / ((double)o.lw[l] / o.lw[l - 1]); o.scale_y[l] = 1. / ((double)o.lh[l] / o.lh[l - 1]); }
+  }
+  o.total = off;
+  {   // nfeaturesPerLevel (aorb.cpp:612-624) for nfeatures = 10000
+    const int nfeatures = 10000;
+    float factor = (float)(1.0 / (double)1.2f);
+    float nd = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)LF_ORB_LEVELS));
+    int sum = 0;
+    for (int l = 0; l < LF_ORB_LEVELS - 1; l++) { o.nper[l] = (int)nearbyint((double)nd); sum += o.nper[l]; nd *= factor; }
+    o.nper[LF_ORB_LEVELS - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+  }
+  {   // umax (aorb.cpp:632-647)
+    int v, v0, vmax = (int)floor(LF_ORB_HALF * sqrt(2.f) / 2 + 1), vmin = (int)ceil(LF_ORB_HALF * sqrt(2.f) / 2);
+    for (v = 0; v <= vmax; ++v) o.umax[v] = (int)nearbyint(sqrt((double)LF_ORB_HALF * LF_ORB_HALF - v * v));
+    for (v = LF_ORB_HALF, v0 = 0; v >= vmin; --v) {
+      while (o.umax[v0] == o.umax[v0 + 1]) ++v0;
+      o.umax[v] = v0;
+      ++v0;
+    }
+  }
+  {   // cv::getGaussianKernel(7, 2, CV_32F) -> 8-bit fixed point (filter.cpp): host libm exp, as the reference's CPU does
+    double s2 = -0.5 / (2.0 * 2.0), sum = 0;
+    float cf[7];
+    for (int i = 0; i < 7; i++) { double x = i - 3.0, t = exp(s2 * x * x); cf[i] = (float)t; sum += cf[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < 7; i++) { cf[i] = (float)(cf[i] * sum); o.blur_k[i] = (int)nearbyint((double)(cf[i] * 256.f)); }
+  }
+  const size_t B = (size_t)c->maxB;
+  OrbBuffers &b = c->ob;
+  memset(&b, 0, sizeof b);
+  ALLOC(c, b.pyr, B * o.total); ALLOC(c, b.blur, B * o.total); ALLOC(c, b.score, B * o.total);
+  ALLOC(c, b.cand, B * LF_ORB_CAND_CAP); ALLOC(c, b.ncand, B); ALLOC(c, b.hist, B * LF_ORB_LEVELS * 256);
+  ALLOC(c, b.sel, B * LF_ORB_KP_MAX * 4); ALLOC(c, b.nsel, B);
+  ALLOC(c, c->d_orb_nkp, 2 * B);
+  c->orb_ready = true;
+  return LF_OK;
+}
+
+int lf_orb_extract_device(lf_ctx *c, const uint8_t *d_gray, size_t gray_frame_stride, int gray_row_stride, const float *d_depth,
+                          size_t depth_frame_stride, int depth_row_stride, int n_frames, int fast_threshold, int max_keypoints,
+                          float *d_kp_xy, float *d_kp_meta, uint8_t *d_desc, int32_t *d_nkp, int kp_cap) {
+  if (!c || !d_gray || !d_kp_xy || !d_desc || !d_nkp || n_frames < 1 || gray_row_stride < c->W || kp_cap < 1 || max_keypoints < 1 ||
+      (d_depth && depth_row_stride < c->W))
+    return LF_ERR_INVALID;
+  if (n_frames > c->maxB) return LF_ERR_CAPACITY;
+  if (max_keypoints > LF_ORB_KP_MAX) return LF_ERR_UNSUPPORTED;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->orb_ready) { int r = orb_prepare(c); if (r != LF_OK) return r; }
+  OrbConsts oc = c->oc;
+  oc.fast_threshold = fast_threshold; oc.max_keypoints = max_keypoints; oc.kp_cap = kp_cap;
+  OrbBuffers ob = c->ob;
+  ob.gray = d_gray; ob.gray_frame_stride = gray_frame_stride; ob.gray_row_stride = gray_row_stride;
+  ob.depth = d_depth; ob.depth_frame_stride = depth_frame_stride; ob.depth_row_stride = depth_row_stride;
+  ob.kp_xy = d_kp_xy; ob.kp_meta = d_kp_meta; ob.desc = d_desc; ob.nkp = c->d_orb_nkp;
+  lf_orb_launch(oc, ob, n_frames, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(d_nkp, c->ob.nsel, sizeof(int) * (size_t)n_frames, hipMemcpyDeviceToDevice, c->stream));
+  c->orb_last = n_frames;
+  return LF_OK;
+}
+
+int lf_orb_check(lf_ctx *c) {
+  if (!c || !c->orb_ready || c->orb_last < 1) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<int> h((size_t)2 * c->orb_last), ns((size_t)c->orb_last);
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->d_orb_nkp, sizeof(int) * h.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(ns.data(), c->ob.nsel, sizeof(int) * ns.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int f = 0; f < c->orb_last; f++)
+    if (h[(size_t)c->orb_last + f] != 0 || h[f] > ns[f]) { c->err = "ORB: more corners / key points in a frame than the buffers hold"; return LF_ERR_CAPACITY; }
+  return LF_OK;
+}
+
+int lf_orb_get_level(lf_ctx *c, int frame, int level, int blurred, uint8_t *out, size_t cap_bytes, int *w, int *h) {
+  if (!c || !c->orb_ready || frame < 0 || frame >= c->orb_last || level < 0 || level >= LF_ORB_LEVELS) return LF_ERR_INVALID;
+  if (w) *w = c->oc.lw[level];
+  if (h) *h = c->oc.lh[level];
+  const size_t bytes = (size_t)c->oc.lw[level] * c->oc.lh[level];
+  if (!out) return LF_OK;
+  if (cap_bytes < bytes) return LF_ERR_CAPACITY;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint8_t *src = (blurred ? c->ob.blur : c->ob.pyr) + (size_t)frame * c->oc.total + c->oc.loff[level];
+  HIPCHK(c, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return LF_OK;
 }
 

@@ -287,3 +287,36 @@ def mle_points_oracle(pts, A0, B0, params, focal=525.0, flavour="lf"):
                                 C.c_void_p(AB.ctypes.data), C.c_void_p(cA.ctypes.data), C.c_void_p(cB.ctypes.data),
                                 C.c_void_p(info.ctypes.data))
     return AB[:3].copy(), AB[3:].copy(), cA.reshape(3, 3), cB.reshape(3, 3), nit, info
+
+
+def orb_oracle(gray_u8, depth_f32=None, fast_threshold=20, nfeatures=10000, max_keypoints=600, flavour="lf", debug=False):
+    """oracle_orb_extract: the ORB branch of Node::Node (AORB detect, removeDepthless, retainBest, ORB descriptors).
+    Returns (kp_xy [n,2] f32, kp_meta [n,4] f32 (response, angle deg, octave, size), desc [n,32] u8[, levels, blurred])."""
+    lib = oracle_lib(flavour)
+    g = np.ascontiguousarray(gray_u8, np.uint8)
+    h, w = g.shape
+    d = None if depth_f32 is None else np.ascontiguousarray(depth_f32, np.float32)
+    xy, meta = np.zeros((max_keypoints, 2), np.float32), np.zeros((max_keypoints, 4), np.float32)
+    desc = np.zeros((max_keypoints, 32), np.uint8)
+    tot = 0
+    sizes = []
+    for l in range(8):
+        lw, lh = C.c_int(), C.c_int()
+        lib.oracle_orb_level_size(C.c_int(w), C.c_int(h), C.c_int(l), C.byref(lw), C.byref(lh))
+        sizes.append((lh.value, lw.value))
+        tot += lw.value * lh.value
+    lev = np.zeros(tot, np.uint8) if debug else None
+    blr = np.zeros(tot, np.uint8) if debug else None
+    lib.oracle_orb_extract.restype = C.c_int
+    n = lib.oracle_orb_extract(C.c_void_p(g.ctypes.data), C.c_int(w), C.c_int(h), C.c_void_p(d.ctypes.data) if d is not None else None,
+                               C.c_int(d.shape[1] if d is not None else 0), C.c_int(fast_threshold), C.c_int(nfeatures),
+                               C.c_int(max_keypoints), C.c_void_p(xy.ctypes.data), C.c_void_p(meta.ctypes.data),
+                               C.c_void_p(desc.ctypes.data), C.c_void_p(lev.ctypes.data) if debug else None,
+                               C.c_void_p(blr.ctypes.data) if debug else None)
+    out = (xy[:n].copy(), meta[:n].copy(), desc[:n].copy())
+    if debug:
+        ls, bs, o = [], [], 0
+        for (hh, ww) in sizes:
+            ls.append(lev[o:o + hh * ww].reshape(hh, ww)); bs.append(blr[o:o + hh * ww].reshape(hh, ww)); o += hh * ww
+        out = out + (ls, bs)
+    return out

@@ -1,0 +1,100 @@
+"""GPU parity of the ORB extractor (run with -m gpu): lf_orb_extract_device vs oracle/orb_oracle.c, bit for bit -- pyramid levels
+(cv::resize fixed point), blurred levels, key points (position, Harris response, angle, octave) and the 32-byte descriptors -- and
+the chain ORB -> projectTo3D -> Hamming matching -> hybrid pose on the device (BASELINE.json config 3 without caller key points)."""
+import numpy as np
+import pytest
+
+import _oracle as O
+from lineslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+NF = 4
+
+
+@pytest.fixture(scope="module")
+def orb():
+    import torch
+    from lineslam_amd import capi
+    g, d, poses = synth.sequence(NF, seed=21)
+    P = capi.default_params(launch=True)
+    ctx = capi.Context(640, 480, max_batch=NF, params=P)
+    dg, dd = torch.from_numpy(g).cuda(), torch.from_numpy(d).cuda()
+    cap = 600
+    xy = torch.zeros((NF, cap, 2), dtype=torch.float32, device="cuda")
+    meta = torch.zeros((NF, cap, 4), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((NF, cap, 32), dtype=torch.uint8, device="cuda")
+    nkp = torch.zeros(NF, dtype=torch.int32, device="cuda")
+    ctx.orb_extract_device(dg.data_ptr(), dd.data_ptr(), NF, xy.data_ptr(), desc.data_ptr(), nkp.data_ptr(), cap, meta.data_ptr())
+    ctx.orb_check()
+    yield ctx, g, d, poses, P, (dg, dd), (xy, meta, desc, nkp)
+    ctx.close()
+
+
+def test_pyramid_and_blur_bit_exact(built_lib, orb):
+    ctx, g, d, _, _, _, _ = orb
+    for f in (0, NF - 1):
+        _, _, _, lev, blr = O.orb_oracle(g[f], d[f], debug=True)
+        for l in range(8):
+            assert np.array_equal(ctx.orb_level(f, l), lev[l]), (f, l)
+            assert np.array_equal(ctx.orb_level(f, l, blurred=True), blr[l]), (f, l)
+
+
+def test_keypoints_and_descriptors_bit_exact(built_lib, orb):
+    ctx, g, d, _, _, _, (xy, meta, desc, nkp) = orb
+    n = nkp.cpu().numpy()
+    for f in range(NF):
+        oxy, ometa, odesc = O.orb_oracle(g[f], d[f])
+        assert n[f] == len(oxy) and 300 < n[f] <= 600, (f, n[f], len(oxy))
+        assert np.array_equal(xy[f, :n[f]].cpu().numpy(), oxy), f
+        assert np.array_equal(meta[f, :n[f]].cpu().numpy(), ometa), f
+        assert np.array_equal(desc[f, :n[f]].cpu().numpy(), odesc), f
+        assert len(np.unique(ometa[:, 2])) >= 5                      # key points on most pyramid levels
+
+
+def test_no_depth_filter_and_other_threshold(built_lib, orb):
+    import torch
+    ctx, g, d, _, _, (dg, dd), _ = orb
+    cap = 400
+    xy = torch.zeros((NF, cap, 2), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((NF, cap, 32), dtype=torch.uint8, device="cuda")
+    nkp = torch.zeros(NF, dtype=torch.int32, device="cuda")
+    ctx.orb_extract_device(dg.data_ptr(), 0, NF, xy.data_ptr(), desc.data_ptr(), nkp.data_ptr(), cap, fast_threshold=35, max_keypoints=400)
+    ctx.orb_check()                                   # (synchronises the context's own stream)
+    n = nkp.cpu().numpy()
+    for f in (0, 2):
+        oxy, ometa, odesc = O.orb_oracle(g[f], None, fast_threshold=35, max_keypoints=400)
+        assert n[f] == len(oxy)
+        assert np.array_equal(xy[f, :n[f]].cpu().numpy(), oxy) and np.array_equal(desc[f, :n[f]].cpu().numpy(), odesc)
+
+
+def test_orb_feeds_the_hybrid_solver_on_the_device(built_lib, orb):
+    """ORB key points -> projectTo3D -> Hamming matching -> points + lines pose, nothing leaves the device."""
+    import torch
+    ctx, g, d, poses, P, (dg, dd), _ = orb
+    K = synth.K_TUM
+    xy = torch.zeros((NF, 600, 2), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((NF, 600, 32), dtype=torch.uint8, device="cuda")
+    nkp = torch.zeros(NF, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.orb_extract_device(dg.data_ptr(), dd.data_ptr(), NF, xy.data_ptr(), desc.data_ptr(), nkp.data_ptr(), 600)
+    ctx.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), NF, K, np.arange(NF, dtype=np.uint64))
+    cap = 600
+    pts = torch.zeros((NF, cap, 4), dtype=torch.float32, device="cuda")
+    npts = torch.zeros(NF, dtype=torch.int32, device="cuda")
+    kept = torch.zeros((NF, cap), dtype=torch.int32, device="cuda")
+    ctx.project_keypoints_device(dd.data_ptr(), NF, xy.data_ptr(), nkp.data_ptr(), cap, K, pts.data_ptr(), npts.data_ptr(), kept.data_ptr())
+    ctx.synchronize()                                 # the context runs on its own stream here; the gather below on torch's
+    dsel = torch.gather(desc, 1, kept.long().clamp_(0, cap - 1).unsqueeze(-1).expand(-1, -1, 32)).contiguous()
+    torch.cuda.synchronize()
+    q, t = np.arange(1, NF, dtype=np.int32), np.arange(0, NF - 1, dtype=np.int32)
+    mq = torch.zeros((NF, cap), dtype=torch.int32, device="cuda"); mt = torch.zeros_like(mq)
+    md = torch.zeros((NF, cap), dtype=torch.float32, device="cuda"); nm = torch.zeros(NF, dtype=torch.int32, device="cuda")
+    ctx.feature_match_pairs_device(dsel.data_ptr(), npts.data_ptr(), cap, q, t, mq.data_ptr(), mt.data_ptr(), md.data_ptr(), nm.data_ptr(),
+                                   nn_distance_ratio=0.75)
+    ctx.match_pairs_hybrid_device_pm(q, t, pts.data_ptr(), cap, mq.data_ptr(), mt.data_ptr(), nm.data_ptr(), cap, K)
+    for i in range(NF - 1):
+        r = ctx.pair_result(i)
+        assert r.valid and r.n_point_matches > 60 and r.n_point_inliers > 40, (i, r.n_point_matches, r.n_point_inliers)
+        T = np.array(list(r.T), np.float64).reshape(4, 4)
+        Tgt = np.linalg.inv(poses[i]) @ poses[i + 1]
+        assert np.linalg.norm(T[:3, 3] - Tgt[:3, 3]) < 0.03
