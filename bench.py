@@ -57,8 +57,8 @@ def parse():
                          "or the same payload through torch.distributed (lineslam_amd/parallel.py)")
     ap.add_argument("--points", action="store_true",
                     help="BASELINE configs[2] instead of configs[1]: fused point + line odometry -- projectTo3D, Hamming "
-                         "feature matching and the hybrid RANSAC / LM solver on synthetic key points (the ORB extractor "
-                         "is outside the accelerated path); not the headline workload")
+                         "feature matching and the hybrid RANSAC / LM solver on the key points of the HIP ORB extractor; "
+                         "not the headline workload")
     ap.add_argument("--default-params", action="store_true",
                     help="ParameterServer defaults (lsd_angle_thres 22.5, min_matches 20) instead of the shipped "
                          "launch/lineslam.launch values (40, 10), which are what the reference actually runs with")
@@ -183,13 +183,12 @@ def main():
 
     pts_state = None
     if a.points:
-        NK = 640
-        kp, desc = synth.keypoints(depth, poses, n_own=NK // 2, seed=2 + rank)
-        d_kp, d_desc = torch.from_numpy(kp).cuda(), torch.from_numpy(desc).cuda()
-        d_nkp = torch.full((F,), NK, dtype=torch.int32, device="cuda")
+        NK = 600          # max_keypoints (launch/lineslam.launch:14); key points and descriptors come from the ORB extractor
         pts_state = []
         for _ in range(nfl):
             pts_state.append(dict(
+                kp=torch.zeros((F, NK, 2), dtype=torch.float32, device="cuda"), desc=torch.zeros((F, NK, 32), dtype=torch.uint8, device="cuda"),
+                nkp=torch.zeros(F, dtype=torch.int32, device="cuda"),
                 pts=torch.zeros((F, NK, 4), dtype=torch.float32, device="cuda"), npts=torch.zeros(F, dtype=torch.int32, device="cuda"),
                 kept=torch.zeros((F, NK), dtype=torch.int32, device="cuda"),
                 mq=torch.zeros((F, NK), dtype=torch.int32, device="cuda"), mt=torch.zeros((F, NK), dtype=torch.int32, device="cuda"),
@@ -225,13 +224,16 @@ def main():
         ctx.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), F, K, ids)
         if a.points:
             st = pts_state[ctxs.index(ctx)]
-            ctx.project_keypoints_device(dd.data_ptr(), F, d_kp.data_ptr(), d_nkp.data_ptr(), NK, K, st["pts"].data_ptr(),
-                                         st["npts"].data_ptr(), st["kept"].data_ptr(), max_keypoints=600)
+            # Node::Node, ORB branch: AORB detection + removeDepthless + retainBest(600) + ORB descriptors, on the device
+            ctx.orb_extract_device(dg.data_ptr(), dd.data_ptr(), F, st["kp"].data_ptr(), st["desc"].data_ptr(), st["nkp"].data_ptr(), NK,
+                                   fast_threshold=20, max_keypoints=NK)
+            ctx.project_keypoints_device(dd.data_ptr(), F, st["kp"].data_ptr(), st["nkp"].data_ptr(), NK, K, st["pts"].data_ptr(),
+                                         st["npts"].data_ptr(), st["kept"].data_ptr(), max_keypoints=NK)
             # descriptors follow the surviving key points (device gather, stream-ordered)
-            dsel = torch.gather(d_desc, 1, st["kept"].long().clamp_(0, NK - 1).unsqueeze(-1).expand(-1, -1, 32)).contiguous()
+            dsel = torch.gather(st["desc"], 1, st["kept"].long().clamp_(0, NK - 1).unsqueeze(-1).expand(-1, -1, 32)).contiguous()
             st["dsel"] = dsel
             ctx.feature_match_pairs_device(dsel.data_ptr(), st["npts"].data_ptr(), NK, pq, pt, st["mq"].data_ptr(),
-                                           st["mt"].data_ptr(), st["md"].data_ptr(), st["nm"].data_ptr())
+                                           st["mt"].data_ptr(), st["md"].data_ptr(), st["nm"].data_ptr(), nn_distance_ratio=0.75)
             ctx.match_pairs_hybrid_device_pm(pq, pt, st["pts"].data_ptr(), NK, st["mq"].data_ptr(), st["mt"].data_ptr(),
                                              st["nm"].data_ptr(), NK, K)
         else:
@@ -320,7 +322,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("fused point + line odometry (BASELINE configs[2]) on a %d-frame 640x480 sequence: front end as "
-                                    "below + projectTo3D, Hamming feature matching, hybrid RANSAC / LM; synthetic key points" % F)
+                                    "below + ORB extraction (600 key points), projectTo3D, Hamming feature matching, hybrid RANSAC / LM" % F)
                        if a.points else
                                    "TUM fr3/cabinet-length sequence (%d frames, 640x480), lines-only odometry: "
                                    "LSD + 3D line fit + MSLD + MLE per frame, line matching + 3-line RANSAC + LM "

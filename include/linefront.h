@@ -473,6 +473,67 @@ LF_API int lf_candidate_targets(const lf_graph_view *graph, int predecessor_id, 
                                 int geodesic_targets, int sampled_targets, int geodesic_depth,
                                 int include_predecessor, uint64_t rng_seed, uint64_t rng_stream, int32_t *out_ids,
                                 int out_cap, int *n_out);
+/* ---- GraphManager::nodeComparisons (src/graph_manager.cpp:419-708) around ONE batched solve, and the edges it hands to
+ * GraphManager::addEdgeToG2O (:928-1014).  The pose graph itself (g2o optimizer) stays with the caller; this is the
+ * decision logic that chooses the comparisons, judges their results and produces the edge records.
+ * lf_compare_params: the ParameterServer options the function reads (src/parameter_server.cpp:91-103,147-148;
+ * lf_compare_params_init_launch applies launch/lineslam.launch:15-16,23,34-36). */
+typedef struct lf_compare_params {
+  double min_translation_meter;   /* 0.0   (launch: 0.01) */
+  double min_rotation_degree;     /* 0.0   (launch: 0.1)  */
+  double max_translation_meter;   /* 1e10 */
+  int32_t max_rotation_degree;    /* 360  */
+  int32_t predecessor_candidates; /* 2     (launch: 1) */
+  int32_t neighbor_candidates;    /* 2     (launch: 0) */
+  int32_t min_sampled_candidates; /* 2     (launch: 0) */
+  int32_t geodesic_depth;         /* 3    */
+  int32_t keep_all_nodes;         /* 0     (launch: 1) */
+  int32_t keep_good_nodes;        /* 0    */
+  int32_t min_matches;            /* 20    (launch: 10): "min_matches" of the ParameterServer */
+} lf_compare_params;
+LF_API void lf_compare_params_init(lf_compare_params *p);
+LF_API void lf_compare_params_init_launch(lf_compare_params *p);
+/* One call of addEdgeToG2O(edge, n1, n2, largeEdge, set_estimate, motion_estimate), in the order nodeComparisons makes them. */
+typedef struct lf_edge {
+  int32_t id1, id2;               /* LoadedEdge3D::id1 (older), id2 (the new node)                          */
+  double transform[16];           /* LoadedEdge3D::transform, row-major, v2 = v1 * transform                 */
+  double information[36];         /* LoadedEdge3D::informationMatrix                                          */
+  int32_t large_edge;             /* the largeEdge argument (isBigTrafo)                                      */
+  int32_t set_estimate;           /* the set_estimate argument                                                */
+  int32_t kind;                   /* 0 visual edge, 1 constant-position edge (:659-682)                       */
+  int32_t n_point_inliers;        /* mr.inlier_matches.size(), what ranks the candidates (:568,577,608)       */
+  int32_t n_line_inliers;
+  int32_t accepted;               /* addEdgeToG2O returned true (an edge to a NEW vertex must be large, :941-946) */
+} lf_edge;
+typedef struct lf_comparison {
+  int32_t added;                  /* the function's return value: a camera-camera edge was added              */
+  int32_t n_edges;                /* addEdgeToG2O calls recorded in `edges`                                   */
+  int32_t edge_to_keyframe;
+  int32_t out_of_bounds;          /* the predecessor transform was too small / too fast: node dropped (:478-492) */
+  int32_t best_id1;               /* curr_best_result_.edge.id1 (-1: none)                                    */
+  int32_t valid_tf_estimate;      /* 0 if only the constant-position edge holds the node                      */
+  int32_t n_candidates;
+  int32_t predecessor_matched;
+  double pose_new[16];            /* motion_estimate: the new vertex's estimate v1 * transform (identity if none) */
+} lf_comparison;
+/* The decisions alone (HOST, no device work), given the comparison results: pred = matchNodePair(new, predecessor) of the
+ * initial comparison (NULL if it was not run: both minimum-motion parameters <= 0), cand_ids / cand_results = the
+ * candidates of the main loop in the order compared.  graph / poses (row-major 4x4 vertex estimates per node) / stamps
+ * (seconds per node) describe the graph before the new node; the new node gets id graph->n_nodes. */
+LF_API int lf_node_comparisons_decide(const lf_graph_view *graph, const double *poses, const double *stamps, double stamp_new,
+                                      const lf_compare_params *cp, const lf_pair_result *pred, const int32_t *cand_ids,
+                                      const lf_pair_result *cand_results, int n_cand, int n_features_new, lf_edge *edges,
+                                      int edge_cap, lf_comparison *out);
+/* GraphManager::nodeComparisons for the frames of the last batch: node i of the graph = frame slot i, the new node = frame
+ * slot graph->n_nodes.  Runs the initial comparison with the predecessor (if the minimum-motion parameters ask for it),
+ * draws the candidates (lf_candidate_targets; prev_best_id as :533-535, -1: none), solves ALL of them in ONE batched launch
+ * (the reference fans them out over a QThreadPool, :555) and applies the decisions above.  n_features_new = the new node's
+ * feature_locations_2d_.size() (point features; pass min_matches or more when only lines are used with keep_all_nodes).
+ * Synchronous. */
+LF_API int lf_node_comparisons(lf_ctx *ctx, const lf_graph_view *graph, const double *poses, const double *stamps,
+                               double stamp_new, const lf_compare_params *cp, uint64_t rng_seed, int prev_best_id,
+                               int n_features_new, lf_edge *edges, int edge_cap, lf_comparison *out);
+
 /* Node::vel as GraphManager::addNode sets it (src/graph_manager.cpp:764-784): translation difference of the two
  * row-major 4x4 double poses (the node itself and the node five ids before it) over |dt|, cast to float. */
 LF_API int lf_instant_velocity(const double *T_new, const double *T_old, double dt, float *vel3);

@@ -93,6 +93,10 @@ SYMBOLS = {
     "lf_candidate_targets": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.c_uint64, C.c_uint64, _vp, _i, _pi]),
     "lf_instant_velocity": (_i, [_vp, _vp, _d, _vp]),
     "lf_const_velocity_transform": (_i, [_vp, _vp, _d, _vp]),
+    "lf_compare_params_init": (None, [_vp]),
+    "lf_compare_params_init_launch": (None, [_vp]),
+    "lf_node_comparisons_decide": (_i, [_vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "lf_node_comparisons": (_i, [_vp, _vp, _vp, _vp, _d, _vp, C.c_uint64, _i, _i, _vp, _i, _vp]),
     "lf_caps_init": (None, [_vp]),
     "lf_ctx_create_caps": (_i, [C.POINTER(_vp), _i, _vp, _i, _i, _i, C.POINTER(LfParams), _vp]),
     "lf_ctx_get_caps": (_i, [_vp, _vp]),
@@ -625,6 +629,79 @@ def comm_unique_id():
     if r != LF_OK:
         raise LinefrontError(r, "lf_comm_unique_id")
     return uid.tobytes()
+
+
+class LfCompareParams(C.Structure):
+    """struct lf_compare_params: the ParameterServer options GraphManager::nodeComparisons reads."""
+    _fields_ = [("min_translation_meter", C.c_double), ("min_rotation_degree", C.c_double), ("max_translation_meter", C.c_double),
+                ("max_rotation_degree", C.c_int32), ("predecessor_candidates", C.c_int32), ("neighbor_candidates", C.c_int32),
+                ("min_sampled_candidates", C.c_int32), ("geodesic_depth", C.c_int32), ("keep_all_nodes", C.c_int32),
+                ("keep_good_nodes", C.c_int32), ("min_matches", C.c_int32)]
+
+
+class LfEdge(C.Structure):
+    """struct lf_edge: one addEdgeToG2O call."""
+    _fields_ = [("id1", C.c_int32), ("id2", C.c_int32), ("transform", C.c_double * 16), ("information", C.c_double * 36),
+                ("large_edge", C.c_int32), ("set_estimate", C.c_int32), ("kind", C.c_int32), ("n_point_inliers", C.c_int32),
+                ("n_line_inliers", C.c_int32), ("accepted", C.c_int32)]
+
+
+class LfComparison(C.Structure):
+    _fields_ = [("added", C.c_int32), ("n_edges", C.c_int32), ("edge_to_keyframe", C.c_int32), ("out_of_bounds", C.c_int32),
+                ("best_id1", C.c_int32), ("valid_tf_estimate", C.c_int32), ("n_candidates", C.c_int32),
+                ("predecessor_matched", C.c_int32), ("pose_new", C.c_double * 16)]
+
+
+def compare_params(launch=False):
+    p = LfCompareParams()
+    (lib().lf_compare_params_init_launch if launch else lib().lf_compare_params_init)(C.byref(p))
+    return p
+
+
+def _graph_view(n_nodes, edges, matchable, keyframes):
+    e = np.ascontiguousarray(np.asarray(edges, np.int32).reshape(-1, 2))
+    ef, et = np.ascontiguousarray(e[:, 0]), np.ascontiguousarray(e[:, 1])
+    kf = np.ascontiguousarray(keyframes, np.int32)
+    mt = None if matchable is None else np.ascontiguousarray(matchable, np.uint8)
+    g = LfGraphView(int(n_nodes), None if mt is None else mt.ctypes.data, len(ef), ef.ctypes.data if len(ef) else None,
+                    et.ctypes.data if len(et) else None, len(kf), kf.ctypes.data if len(kf) else None)
+    return g, (ef, et, kf, mt)
+
+
+def node_comparisons_decide(n_nodes, edges, keyframes, poses, stamps, stamp_new, cp, pred, cand_ids, cand_results, n_features_new,
+                            matchable=None, edge_cap=64):
+    """lf_node_comparisons_decide (host only): returns (LfComparison, [LfEdge])."""
+    g, keep = _graph_view(n_nodes, edges, matchable, keyframes)
+    P = np.ascontiguousarray(poses, np.float64).reshape(n_nodes, 16)
+    S = np.ascontiguousarray(stamps, np.float64)
+    ids = np.ascontiguousarray(cand_ids, np.int32)
+    res = (LfPairResult * max(len(cand_results), 1))(*cand_results)
+    ed = (LfEdge * edge_cap)()
+    out = LfComparison()
+    r = lib().lf_node_comparisons_decide(C.byref(g), P.ctypes.data, S.ctypes.data, C.c_double(stamp_new), C.byref(cp),
+                                         C.byref(pred) if pred is not None else None, ids.ctypes.data if len(ids) else None,
+                                         C.cast(res, C.c_void_p) if len(cand_results) else None, len(cand_results), int(n_features_new),
+                                         C.cast(ed, C.c_void_p), edge_cap, C.byref(out))
+    if r != LF_OK:
+        raise LinefrontError(r, "lf_node_comparisons_decide")
+    return out, [ed[i] for i in range(out.n_edges)]
+
+
+def node_comparisons(ctx, n_nodes, edges, keyframes, poses, stamps, stamp_new, cp, rng_seed=0, prev_best_id=-1, n_features_new=1000,
+                     matchable=None, edge_cap=64):
+    """lf_node_comparisons: GraphManager::nodeComparisons for the frames of ctx's last batch (node i = slot i, new node =
+    slot n_nodes): candidates, ONE batched solve, decisions.  Returns (LfComparison, [LfEdge])."""
+    g, keep = _graph_view(n_nodes, edges, matchable, keyframes)
+    P = np.ascontiguousarray(poses, np.float64).reshape(n_nodes, 16)
+    S = np.ascontiguousarray(stamps, np.float64)
+    ed = (LfEdge * edge_cap)()
+    out = LfComparison()
+    r = lib().lf_node_comparisons(ctx._h, C.byref(g), P.ctypes.data, S.ctypes.data, C.c_double(stamp_new), C.byref(cp),
+                                  C.c_uint64(rng_seed), int(prev_best_id), int(n_features_new), C.cast(ed, C.c_void_p), edge_cap,
+                                  C.byref(out))
+    if r != LF_OK:
+        raise LinefrontError(r, "lf_node_comparisons", lib().lf_last_error(ctx._h).decode())
+    return out, [ed[i] for i in range(out.n_edges)]
 
 
 def candidate_targets(n_nodes, edges, matchable=None, keyframes=(), predecessor_id=-1, sequential_targets=1,

@@ -88,3 +88,89 @@ def const_velocity_transform(pose_older, vel, dt):
     for i in range(3):
         T[i, 3] = np.float32(np.float32(R[0, i] * v[0]) + np.float32(R[1, i] * v[1])) + np.float32(R[2, i] * v[2])
     return T
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GraphManager::nodeComparisons (src/graph_manager.cpp:419-708) as far as its decisions go, restated independently of
+# lineslam_amd/csrc/lf_graph.hip: a list of per-comparison results in, the addEdgeToG2O calls (:928-1014) out.
+def trafo_size(T):
+    """trafoSize (src/misc.cpp:254-258): (angle in degrees from the trace, translation norm)"""
+    T = np.asarray(T, np.float64)
+    return float(np.degrees(np.arccos((np.trace(T[:3, :3]) - 1) / 2))), float(np.linalg.norm(T[:3, 3]))
+
+
+def is_big_trafo(T, cp):
+    a, d = trafo_size(T)
+    return d > cp["min_translation_meter"] or a > cp["min_rotation_degree"]
+
+
+def is_small_trafo(T, seconds, cp):
+    if seconds <= 0.0:
+        return True
+    a, d = trafo_size(T)
+    return d / seconds < cp["max_translation_meter"] and a / seconds < cp["max_rotation_degree"]
+
+
+def node_comparisons_decide(n_nodes, keyframes, poses, stamps, stamp_new, cp, pred, cands, n_features_new):
+    """pred / cands: dicts(valid, id_older, T [4,4], information_scale, n_point_inliers, n_line_inliers) (pred may be None).
+    Returns dict(added, edges=[dict(id1, id2, transform, information, large_edge, set_estimate, kind, accepted)], edge_to_keyframe,
+    out_of_bounds, best_id1, valid_tf_estimate, pose_new)."""
+    out = dict(added=False, edges=[], edge_to_keyframe=False, out_of_bounds=False, best_id1=-1, valid_tf_estimate=True,
+               pose_new=np.eye(4), predecessor_matched=False)
+    id_new, prev = n_nodes, n_nodes - 1
+    if n_features_new < cp["min_matches"] and not cp["keep_all_nodes"]:
+        return out
+    state = dict(vertex=False, cam_edges=0)
+
+    def add_edge(e, pose_v1):
+        ok = state["vertex"] or e["large_edge"]
+        if ok:
+            if not state["vertex"] or e["set_estimate"]:
+                out["pose_new"] = np.asarray(pose_v1, np.float64) @ e["transform"]
+            state["vertex"] = True
+            state["cam_edges"] += 1
+        e["accepted"] = bool(ok)
+        out["edges"].append(e)
+        return ok
+
+    def edge_of(r):
+        return dict(id1=r["id_older"], id2=id_new, transform=np.asarray(r["T"], np.float32).astype(np.float64).reshape(4, 4),
+                    information=np.eye(6) * r["information_scale"], kind=0, n_point_inliers=r["n_point_inliers"])
+
+    best_inl = 0
+    if pred is not None and (cp["min_translation_meter"] > 0.0 or cp["min_rotation_degree"] > 0.0):
+        if pred["valid"] and pred["id_older"] >= 0:
+            e = edge_of(pred)
+            if not is_big_trafo(e["transform"], cp) or not is_small_trafo(e["transform"], stamp_new - stamps[prev], cp):
+                out["out_of_bounds"] = True
+                out["pose_new"] = np.asarray(poses[prev], np.float64) @ e["transform"]
+                out["best_id1"] = pred["id_older"]
+                return out
+            e["large_edge"], e["set_estimate"] = True, True
+            add_edge(e, poses[prev])
+            out["edge_to_keyframe"] = pred["id_older"] in keyframes
+            out["best_id1"], best_inl = pred["id_older"], pred["n_point_inliers"]
+            out["predecessor_matched"] = True
+    for r in cands:
+        if not (r["valid"] and r["id_older"] >= 0):
+            continue
+        e = edge_of(r)
+        if not is_small_trafo(e["transform"], stamp_new - stamps[r["id_older"]], cp):
+            continue
+        e["large_edge"] = is_big_trafo(e["transform"], cp)
+        e["set_estimate"] = r["n_point_inliers"] > best_inl
+        if add_edge(e, poses[r["id_older"]]):
+            if r["n_point_inliers"] > best_inl:
+                best_inl, out["best_id1"] = r["n_point_inliers"], r["id_older"]
+            if r["id_older"] in keyframes:
+                out["edge_to_keyframe"] = True
+    found = state["cam_edges"] > 0
+    keep_anyway = cp["keep_all_nodes"] or (n_features_new > cp["min_matches"] and cp["keep_good_nodes"])
+    if not found and keep_anyway:
+        info = np.diag([1.0, 1.0, 1.0, 1e-100, 1e-100, 1e-100])
+        add_edge(dict(id1=prev, id2=id_new, transform=np.eye(4), information=info, large_edge=True, set_estimate=True, kind=1,
+                      n_point_inliers=0), poses[prev])
+        out["valid_tf_estimate"] = False
+        out["best_id1"] = prev
+    out["added"] = state["cam_edges"] > 0
+    return out

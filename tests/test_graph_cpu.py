@@ -79,3 +79,73 @@ def test_constant_velocity_model(built_lib):
         T = capi.const_velocity_transform(pose, v, 0.033)
         assert np.array_equal(T, G.const_velocity_transform(pose, v, 0.033))
         assert np.array_equal(T[:3, :3], np.eye(3, dtype=np.float32)) and T[3].tolist() == [0, 0, 0, 1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _rand_result(rs, n_nodes, id_older, valid=None):
+    from lineslam_amd import capi
+    r = capi.LfPairResult()
+    ang = rs.uniform(0, 0.2) * (rs.rand() < 0.8)
+    ax = rs.randn(3); ax /= np.linalg.norm(ax)
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = rs.randn(3) * rs.choice([0.0, 0.003, 0.05, 3.0])
+    for i, v in enumerate(T.astype(np.float32).ravel()):
+        r.T[i] = float(v)
+    r.valid = int(rs.rand() < 0.7) if valid is None else int(valid)
+    r.id_older = id_older if r.valid else -1
+    r.id_newer = n_nodes if r.valid else -1
+    r.n_point_inliers = int(rs.randint(0, 40))
+    r.n_inliers = int(rs.randint(0, 80))
+    r.information_scale = float(rs.uniform(1, 1e4))
+    r.rmse = 1.0
+    return r
+
+
+def _as_dict(r):
+    return dict(valid=bool(r.valid), id_older=r.id_older, T=np.array(list(r.T), np.float32).reshape(4, 4),
+                information_scale=r.information_scale, n_point_inliers=r.n_point_inliers, n_line_inliers=r.n_inliers)
+
+
+def test_node_comparisons_decisions_vs_independent_restatement(built_lib):
+    """lf_node_comparisons_decide (the decision logic of GraphManager::nodeComparisons + the addEdgeToG2O contract) against the
+    independent Python restatement, over random comparison outcomes and both parameter sets."""
+    from lineslam_amd import capi
+    rs = np.random.RandomState(5)
+    seen = dict(oob=0, const=0, refused=0, multi=0)
+    for trial in range(300):
+        cp = capi.compare_params(launch=bool(trial % 2))
+        if trial % 5 == 0:
+            cp.max_translation_meter, cp.max_rotation_degree = 2.0, 90
+        if trial % 7 == 0:
+            cp.keep_all_nodes = 0
+            cp.keep_good_nodes = int(rs.rand() < 0.5)
+        n = int(rs.randint(1, 12))
+        poses = np.stack([np.eye(4) for _ in range(n)])
+        for k in range(n):
+            poses[k, :3, 3] = rs.randn(3)
+        stamps = np.cumsum(rs.uniform(0.02, 0.05, n))
+        stamp_new = stamps[-1] + rs.uniform(-0.01, 0.05)
+        kfs = sorted(set(rs.randint(0, n, rs.randint(0, 3)).tolist()))
+        use_pred = cp.min_translation_meter > 0 or cp.min_rotation_degree > 0
+        pred = _rand_result(rs, n, n - 1) if use_pred else None
+        ncand = int(rs.randint(0, 5))
+        ids = rs.randint(0, n, ncand).astype(np.int32)
+        res = [_rand_result(rs, n, int(i)) for i in ids]
+        nfeat = int(rs.choice([0, 5, 15, 30, 500]))
+        o, ed = capi.node_comparisons_decide(n, [], kfs, poses, stamps, stamp_new, cp, pred, ids, res, nfeat)
+        cpd = {f: getattr(cp, f) for f, _ in cp._fields_}
+        w = G.node_comparisons_decide(n, kfs, poses, stamps, stamp_new, cpd, _as_dict(pred) if pred is not None else None,
+                                       [_as_dict(r) for r in res], nfeat)
+        assert bool(o.added) == w["added"] and bool(o.out_of_bounds) == w["out_of_bounds"] and o.best_id1 == w["best_id1"], trial
+        assert bool(o.edge_to_keyframe) == w["edge_to_keyframe"] and bool(o.valid_tf_estimate) == w["valid_tf_estimate"], trial
+        assert o.n_edges == len(w["edges"]) == len(ed), trial
+        assert np.allclose(np.array(list(o.pose_new)).reshape(4, 4), w["pose_new"], rtol=0, atol=1e-12), trial
+        for a, b in zip(ed, w["edges"]):
+            assert (a.id1, a.id2, bool(a.large_edge), bool(a.set_estimate), a.kind, bool(a.accepted)) == \
+                   (b["id1"], b["id2"], bool(b["large_edge"]), bool(b["set_estimate"]), b["kind"], b["accepted"]), trial
+            assert np.array_equal(np.array(list(a.transform)).reshape(4, 4), b["transform"])
+            assert np.array_equal(np.array(list(a.information)).reshape(6, 6), b["information"])
+        seen["oob"] += bool(o.out_of_bounds); seen["const"] += any(e.kind == 1 for e in ed)
+        seen["refused"] += any(not e.accepted for e in ed); seen["multi"] += sum(1 for e in ed if e.accepted) > 1
+    assert all(v > 0 for v in seen.values()), seen        # every branch of the decision logic was exercised
