@@ -61,8 +61,11 @@ def test_node_comparisons_equals_the_steps_done_by_hand(built_lib, seq, launch):
     for a, b in zip(ed, w["edges"]):
         assert (a.id1, a.id2, bool(a.large_edge), bool(a.set_estimate), bool(a.accepted)) == (b["id1"], b["id2"], bool(b["large_edge"]), bool(b["set_estimate"]), b["accepted"])
         assert np.array_equal(np.array(list(a.transform)).reshape(4, 4), b["transform"])
-    assert o.added and o.n_edges >= 1
-    # the new vertex's estimate chains the first accepted edge on its older node's pose: close to the true pose
+    assert bool(o.out_of_bounds) == w["out_of_bounds"]
+    # either an edge was added, or the predecessor transform was below the minimum motion and the node is dropped (:478-492;
+    # a frame-to-frame step of this sequence can be under 1 cm / 0.1 degree)
+    assert (o.added and o.n_edges >= 1) or o.out_of_bounds
+    # the new vertex's estimate chains the edge on its older node's pose: close to the true pose
     Tn = np.array(list(o.pose_new)).reshape(4, 4)
     assert np.linalg.norm(Tn[:3, 3] - gt[n][:3, 3]) < 0.03
     if not launch:
