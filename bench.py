@@ -37,8 +37,18 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_FRAME = 25_128_960 + 200 * 1040     # compulsory traffic + ~0.2 MB of output records
+ALGO_BYTES_PER_FRAME = 25_128_960 + 200 * 1040     # compulsory traffic of the WHOLE front end + ~0.2 MB of records
+# the sweep kernel's own share of that table: `angles`, `modgrad` read once in region growing / NFA (2 x 1 572 864) and
+# `used` read + written (2 x 196 608)
+SWEEP_BYTES_PER_FRAME = 2 * 1_572_864 + 2 * 196_608
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def _latest_profile(suffix):
+    """newest committed profiles/r??<x>_<suffix> (rocprofv3 summaries are committed per round; the newest one describes this code)"""
+    d = os.path.join(ROOT, "profiles")
+    c = sorted(f for f in os.listdir(d) if f.endswith(suffix)) if os.path.isdir(d) else []
+    return os.path.join(d, c[-1]) if c else None
 
 
 def parse():
@@ -305,17 +315,28 @@ def main():
                        "line_inliers_per_pair": float(np.mean([r.n_inliers for r in res]))} if a.points else None
         sw = float(np.mean(sweep_ms))
         nlines = int(np.mean([len(ctx.frame_lines(k)) for k in range(0, F, max(1, F // 16))]))
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_sweep_pmc.json")
-        if os.path.exists(tpath):
+        traffic, traffic_src, valu = None, None, None
+        tpath = _latest_profile("_sweep_pmc.json")
+        if tpath:
             try:
                 tj = json.load(open(tpath))
                 if tj.get("frames") == F:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(tpath, ROOT)
             except Exception:
                 traffic = None
-        algo = ALGO_BYTES_PER_FRAME * F
+        vpath = _latest_profile("_valu_utilisation.json")
+        if vpath:
+            try:
+                vj = json.load(open(vpath))["kernels"]
+                valu = {"source": os.path.relpath(vpath, ROOT),
+                        "valu_busy_chip": {k: round(v["valu_busy_chip"], 3) for k, v in vj.items() if k.startswith(("k_lsd_sweep", "k_mle", "k_pose", "k_line3d", "k_describe", "k_match"))},
+                        "wave_wait_frac": {k: round(v["wave_wait_frac"], 3) for k, v in vj.items() if k.startswith(("k_lsd_sweep", "k_mle", "k_pose"))}}
+            except Exception:
+                valu = None
+        algo = SWEEP_BYTES_PER_FRAME * F
         achieved = algo / (sw * 1e-3) / 1e9
+        fe_bytes = ALGO_BYTES_PER_FRAME * F
+        fe_ms = (serial["stage_ms"]["lsd_data_parallel"] + serial["stage_ms"]["lsd_sweep"] + serial["stage_ms"]["lines3d_msld_mle"]) if serial else None
         n_over = int(sum(1 for r in res if r.overflow))
         out = {
             "metric": "RGB-D frames/sec (detect+match+pose) at 640\u00d7480; ATE vs reference", "value": value, "unit": "frames/s",
@@ -333,12 +354,19 @@ def main():
                        "per segment (3D fit), per pair (pose); %d passes in flight on separate HIP streams" % nfl +
                        ("; %d ranks, 1 sequence each, 1 all-gather of %d key-frame maps per step (%s carrier)" % (world, len(kf), carrier) if dist_on else "")},
             "roofline": {"bound": "hbm", "kernel": "k_lsd_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": sw, "algorithmic_bytes_per_launch": algo,
                          "kernel_ms_one_pass_in_flight": (serial or {}).get("stage_ms", {}).get("lsd_sweep"),
                          "frac_one_pass_in_flight": (algo / ((serial["stage_ms"]["lsd_sweep"]) * 1e-3) / 1e9 / HBM_PEAK_GBS) if serial else None,
-                         "note": "instruction-latency-bound sweep, one wavefront per frame; kernel_ms is its HIP-event duration in "
-                                 "the timed region, where it shares the chip with the other pass in flight; see DESIGN.md section 4"},
+                         # the whole front end (LSD data-parallel + sweep + 3D lines / MSLD / MLE) against SURVEY 8(d)'s 25.3 MB per frame
+                         "front_end": ({"algorithmic_bytes_per_pass": fe_bytes, "ms_one_pass_in_flight": fe_ms,
+                                        "achieved": fe_bytes / (fe_ms * 1e-3) / 1e9, "frac": fe_bytes / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                       if fe_ms else None),
+                         "valu": valu,
+                         "note": "the sweep is charged its OWN algorithmic bytes (angles + modgrad read once, used read + written: 3.54 MB per "
+                                 "frame); it is a dependent chain per frame, bound by the latency of its gathers (56 % of its wave cycles "
+                                 "wait on memory, SQ_WAIT_ANY), so the HBM fraction is small by construction; kernel_ms is its HIP-event "
+                                 "duration in the timed region, where it shares the chip with the other passes in flight"},
             "stage_ms": {"lsd_data_parallel": float(np.mean(pre_ms)), "lsd_sweep": sw,
                          "lines3d_msld_mle": float(np.mean(front_ms)), "match_pose": float(np.mean(pair_ms))},
             "serial": serial, "points": point_stats,

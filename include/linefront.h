@@ -91,7 +91,12 @@ typedef struct lf_params {
   /* lines-only RANSAC computeRelativeMotion_Ransac (src/line/motion.cpp:367-526) */
   double pt2line3d_dist_relmotion;    /* 0.05 m  3d_pt2line_dst_relmot_m (parameter_server.cpp:188) */
   double line3d_angle_relmotion;      /* 10 deg  3d_line_angle_relmot_deg (:189) */
+  /* the `algorithm` argument of Node::detect3DLines (src/line/lineslam.cpp:200-235) */
+  int32_t line_detector;              /* LF_DETECTOR_LSD (0, default) or LF_DETECTOR_EDLINES (1) */
+  int32_t reserved_;
 } lf_params;
+#define LF_DETECTOR_LSD 0
+#define LF_DETECTOR_EDLINES 1
 
 /* One 3D line of a frame: the flat, fixed-stride form of the reference's FrameLine /
  * RandomLine3d / RandomPoint3d objects (src/line/lineslam.h:41-151) -- 129 doubles + 2 ints =
@@ -173,11 +178,22 @@ LF_API int lf_lsd_get_debug(lf_ctx *ctx, int frame, int which, void *out, size_t
 LF_API int lf_lsd(lf_ctx *ctx, const uint8_t *gray, int row_stride, int width, int height,
                   double *segs, int cap, int *n_out, uint16_t *labels_or_null);
 
+/* ---- EDLines -----------------------------------------------------------------------------
+ * Replaces  LS* callEDLines(const cv::Mat& im_uchar, int* numLines)  (src/line/utils.cpp:1829-1853) ->
+ * DetectLinesByED(srcImg, width, height, &noLines) of external/EDLines/libEDLines.a for a batch of frames.  The reference has
+ * that detector as a BINARY only; what runs here is the detector of the papers it implements (Edge Drawing, JVCIR 2012;
+ * EDLines, PRL 2011) -- Gaussian 5x5 sigma 1, Sobel gradient >= 36, anchors >= 8 strongest first, smart routing, least-squares
+ * line fitting with a 1 px tolerance, Helmholtz validation with p = 1/8 -- so its output approximates the binary's and is
+ * not pinned to it (tests/test_oracle_edlines.py measures the agreement on the reference's house.pgm example).  Results:
+ * lf_lsd_get_segments (rows sx, sy, ex, ey, 0).  lf_detect3d_batch_device runs this detector instead of LSD when
+ * lf_params::line_detector == LF_DETECTOR_EDLINES (the `algorithm == "EDLINES"` branch of Node::detect3DLines).  Asynchronous. */
+LF_API int lf_edlines_batch_device(lf_ctx *ctx, const uint8_t *d_gray, size_t frame_stride, int row_stride, int n_frames);
+
 /* ---- a9-a18: the rest of the per-frame front end --------------------------------------------
  * Replaces  void Node::detect3DLines(const cv::Mat& gray_uchar, const cv::Mat& depth_float,
  *                double line2d_len_thres, const cv::Mat& K, double ratio_of_collinear_pts,
  *                double line_3d_len_thres_m, double depth_scaling, std::string algorithm)
- * (src/node.h:286-287, src/line/lineslam.cpp:200-357) with algorithm == "LSD"; the scalar
+ * (src/node.h:286-287, src/line/lineslam.cpp:200-357); `algorithm` is lf_params::line_detector, the scalar
  * arguments live in lf_params (line_segment_len_thresh, ratio_of_collinear_pts,
  * line3d_length_thresh, depth_scaling).  The result is Node::lines (only lines with depth, lid =
  * index) as lf_line_record rows.

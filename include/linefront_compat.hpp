@@ -64,8 +64,9 @@ class Node {
                      int width, int height, double line2d_len_thres, const double K[9],
                      double ratio_of_collinear_pts, double line_3d_len_thres_m, double depth_scaling,
                      const std::string& algorithm) {
-    if (algorithm != "LSD") throw Error(LF_ERR_UNSUPPORTED, "detect3DLines: only \"LSD\" (EDLines is binary-only in the reference)");
+    if (algorithm != "LSD" && algorithm != "EDLINES") throw Error(LF_ERR_UNSUPPORTED, "detect3DLines: algorithm must be \"LSD\" or \"EDLINES\"");
     lf_params p = ctx->params;
+    p.line_detector = algorithm == "EDLINES" ? LF_DETECTOR_EDLINES : LF_DETECTOR_LSD;   // (EDLINES: paper-level, see linefront.h)
     p.line_segment_len_thresh = line2d_len_thres; p.ratio_of_collinear_pts = ratio_of_collinear_pts;
     p.line3d_length_thresh = line_3d_len_thres_m; p.depth_scaling = depth_scaling;
     check(lf_ctx_set_params(ctx->h, &p), "lf_ctx_set_params");   // (cheap: the LSD tables are rebuilt only when an lsd_* member changes)

@@ -35,6 +35,7 @@ class LfParams(C.Structure):
         ("g2o_line_error_weight", C.c_double), ("g2o_BA_use_kernel", C.c_int),
         ("g2o_BA_kernel_delta", C.c_double), ("rng_seed", C.c_uint64),
         ("pt2line3d_dist_relmotion", C.c_double), ("line3d_angle_relmotion", C.c_double),
+        ("line_detector", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -106,6 +107,7 @@ SYMBOLS = {
     "lf_solve_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, _vp, _i, C.c_uint64, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
                                 _vp, _vp]),
     "lf_mle_lines": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "lf_edlines_batch_device": (_i, [_vp, _vp, C.c_size_t, _i, _i]),
     "lf_orb_extract_device": (_i, [_vp, _vp, C.c_size_t, _i, _vp, C.c_size_t, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i]),
     "lf_orb_check": (_i, [_vp]),
     "lf_orb_get_level": (_i, [_vp, _i, _i, _i, _vp, C.c_size_t, _pi, _pi]),
@@ -235,6 +237,12 @@ class Context:
         fs = frame_stride or rs * self.height
         self._chk(lib().lf_lsd_batch_device(self._h, _vp(d_gray_ptr), fs, rs, n_frames),
                   "lf_lsd_batch_device")
+
+    def edlines_batch_device(self, d_gray_ptr, n_frames, frame_stride=None, row_stride=None):
+        """Launch EDLines on n_frames u8 images resident in device memory (async); results: lsd_segments(frame)[:, :4]."""
+        rs = row_stride or self.width
+        fs = frame_stride or rs * self.height
+        self._chk(lib().lf_edlines_batch_device(self._h, _vp(d_gray_ptr), fs, rs, n_frames), "lf_edlines_batch_device")
 
     def lsd_segments(self, frame, cap=4096):
         segs = np.zeros((cap, 5), np.float64)

@@ -10,6 +10,7 @@
 #include "lf_pair.h"
 #include "lf_points.h"
 #include "lf_orb.h"
+#include "lf_edlines.h"
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -55,6 +56,10 @@ struct lf_ctx {
   PairBuffers last_pb;               // the buffers of the last pair launch (train side may be an external map)
   unsigned char *d_adjacent = nullptr;   // [maxB] adjacentFrame flags of lf_line_matching_device
   double *d_descdiff = nullptr;      // lf_pair_get_descdiff scratch (line_cap^2 doubles), allocated on first use
+  // ---- EDLines (buffers allocated on first use)
+  bool ed_ready = false;
+  EdConsts ec;
+  EdBuffers eb;
   // ---- ORB extractor (buffers allocated on first use)
   bool orb_ready = false;
   OrbConsts oc;
@@ -150,6 +155,7 @@ void lf_params_init(lf_params *p) {
   p->rng_seed = 0;
   p->pt2line3d_dist_relmotion = 0.05;     // :188
   p->line3d_angle_relmotion = 10;         // :189
+  p->line_detector = LF_DETECTOR_LSD;     // Node::Node passes "LSD" (src/node.cpp:214)
 }
 void lf_caps_init(lf_caps *k) {
   if (!k) return;
@@ -598,7 +604,9 @@ int lf_detect3d_batch_device(lf_ctx *c, const uint8_t *d_gray, size_t gray_frame
     return LF_ERR_INVALID;
   if (n_frames > c->maxB) return LF_ERR_CAPACITY;
   if (c->params.line_sample_max_num + 1 > LF_MAX_SAMPLES) return LF_ERR_UNSUPPORTED;
-  int r = lf_lsd_batch_device(c, d_gray, gray_frame_stride, gray_row_stride, n_frames);
+  if (c->params.line_detector != LF_DETECTOR_LSD && c->params.line_detector != LF_DETECTOR_EDLINES) return LF_ERR_UNSUPPORTED;
+  int r = c->params.line_detector == LF_DETECTOR_EDLINES ? lf_edlines_batch_device(c, d_gray, gray_frame_stride, gray_row_stride, n_frames)
+                                                         : lf_lsd_batch_device(c, d_gray, gray_frame_stride, gray_row_stride, n_frames);
   if (r != LF_OK) return r;
   {   // node ids through the pinned staging area (no host synchronisation)
     if (c->stage_ids_pending) HIPCHK(c, hipEventSynchronize(c->ev_stage_ids));
@@ -1525,6 +1533,71 @@ int lf_orb_get_level(lf_ctx *c, int frame, int level, int blurred, uint8_t *out,
   const uint8_t *src = (blurred ? c->ob.blur : c->ob.pyr) + (size_t)frame * c->oc.total + c->oc.loff[level];
   HIPCHK(c, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LF_OK;
+}
+
+
+// ---- EDLines ---------------------------------------------------------------------------------------------------------
+static int ed_prepare(lf_ctx *c) {
+  EdConsts &e = c->ec;
+  memset(&e, 0, sizeof e);
+  e.W = c->W; e.H = c->H;
+  if ((size_t)c->W * c->H > (1u << 19) || c->W > 65535 || c->H > 65535) return LF_ERR_UNSUPPORTED;   // anchor keys: 19-bit pixel index
+  {   // getGaussianKernel(5, 1, CV_32F) in 8-bit fixed point (host libm exp)
+    double s2 = -0.5, sum = 0;
+    float cf[5];
+    for (int i = 0; i < 5; i++) { double x = i - 2.0, t = exp(s2 * x * x); cf[i] = (float)t; sum += cf[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < 5; i++) { cf[i] = (float)(cf[i] * sum); e.sk[i] = (int)nearbyint((double)(cf[i] * 256.f)); }
+  }
+  {
+    int n = (int)nearbyint(-2.0 * (log10((double)c->W) + log10((double)c->H)) / log10(0.125) * 0.5);
+    e.min_len = n < 9 ? 9 : n;
+  }
+  e.nmax = 2 * (c->W + c->H);
+  e.seg_cap = c->lc.seg_cap;
+  e.chain_cap = 2 * (c->W + c->H) * 8;
+  std::vector<int> kmin((size_t)e.nmax + 1);
+  {   // minimal aligned-pixel count per line length: (w h)^2 B(n, k, 1/8) <= 1 (host libm lgamma / exp / log10)
+    const double p = 0.125, logNT = 2.0 * (log10((double)c->W) + log10((double)c->H));
+    for (int n = 0; n <= e.nmax; n++) {
+      double tail = 0;
+      kmin[(size_t)n] = n + 1;
+      for (int k = n; k >= 0; k--) {
+        tail += exp(lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0) + k * log(p) + (n - k) * log(1 - p));
+        if (log10(tail) + logNT <= 0.0) kmin[(size_t)n] = k; else break;
+      }
+    }
+  }
+  const size_t B = (size_t)c->maxB, HW = (size_t)c->W * c->H;
+  EdBuffers &b = c->eb;
+  memset(&b, 0, sizeof b);
+  int *d_kmin = nullptr;
+  ALLOC(c, b.smooth, B * HW); ALLOC(c, b.D, B * HW); ALLOC(c, b.E, B * HW); ALLOC(c, b.G, B * HW);
+  ALLOC(c, b.akeys, B * LF_ED_ANCHOR_CAP); ALLOC(c, b.nanch, B);
+  ALLOC(c, b.chain, B * 2 * (size_t)e.chain_cap);
+  ALLOC(c, d_kmin, kmin.size());
+  HIPCHK(c, hipMemcpyAsync(d_kmin, kmin.data(), kmin.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  b.kmin = d_kmin;
+  b.segs = c->lb.segs; b.nsegs = c->lb.nsegs;
+  c->ed_ready = true;
+  return LF_OK;
+}
+
+int lf_edlines_batch_device(lf_ctx *c, const uint8_t *d_gray, size_t frame_stride, int row_stride, int n_frames) {
+  if (!c || !d_gray || n_frames < 1 || row_stride < c->W) return LF_ERR_INVALID;
+  if (n_frames > c->maxB) return LF_ERR_CAPACITY;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->ed_ready) { int r = ed_prepare(c); if (r != LF_OK) return r; }
+  EdBuffers b = c->eb;
+  b.gray = d_gray; b.gray_frame_stride = frame_stride; b.gray_row_stride = row_stride;
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  lf_edlines_launch(c->ec, b, n_frames, c->stream);
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));        // (stage timers: the whole detector counts as stage 0, stage 1 is empty)
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  HIPCHK(c, hipGetLastError());
+  c->last_batch = n_frames;
   return LF_OK;
 }
 

@@ -58,9 +58,10 @@ class Node:
 
     def detect3DLines(self, gray_uchar, depth_float, line2d_len_thres, K, ratio_of_collinear_pts,
                       line_3d_len_thres_m, depth_scaling, algorithm="LSD"):
-        if algorithm != "LSD":
+        if algorithm not in ("LSD", "EDLINES"):
             raise capi.LinefrontError(capi.LF_ERR_UNSUPPORTED, "detect3DLines(algorithm=%r)" % algorithm)
         p = self.params
+        p.line_detector = 1 if algorithm == "EDLINES" else 0
         p.line_segment_len_thresh, p.ratio_of_collinear_pts = line2d_len_thres, ratio_of_collinear_pts
         p.line3d_length_thresh, p.depth_scaling = line_3d_len_thres_m, depth_scaling
         self._ctx.set_params(p)

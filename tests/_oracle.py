@@ -320,3 +320,21 @@ def orb_oracle(gray_u8, depth_f32=None, fast_threshold=20, nfeatures=10000, max_
             ls.append(lev[o:o + hh * ww].reshape(hh, ww)); bs.append(blr[o:o + hh * ww].reshape(hh, ww)); o += hh * ww
         out = out + (ls, bs)
     return out
+
+
+def edlines_oracle(gray_u8, flavour="ref", cap=4096, debug=False):
+    """oracle_edlines: the paper-level EDLines statement.  Returns segments [n,4] (sx, sy, ex, ey)[, smooth, G, D, E]."""
+    lib = oracle_lib(flavour)
+    g = np.ascontiguousarray(gray_u8, np.uint8)
+    h, w = g.shape
+    segs = np.zeros((cap, 4), np.float64)
+    S = np.zeros((h, w), np.uint8) if debug else None
+    G = np.zeros((h, w), np.int16) if debug else None
+    D = np.zeros((h, w), np.uint8) if debug else None
+    E = np.zeros((h, w), np.uint8) if debug else None
+    lib.oracle_edlines.restype = C.c_int
+    n = lib.oracle_edlines(C.c_void_p(g.ctypes.data), C.c_int(w), C.c_int(h), C.c_void_p(segs.ctypes.data), C.c_int(cap),
+                           *(C.c_void_p(a.ctypes.data) if debug else None for a in (S, G, D, E))) if debug else \
+        lib.oracle_edlines(C.c_void_p(g.ctypes.data), C.c_int(w), C.c_int(h), C.c_void_p(segs.ctypes.data), C.c_int(cap), None, None, None, None)
+    out = segs[:min(n, cap)].copy()
+    return (out, S, G, D, E) if debug else out
