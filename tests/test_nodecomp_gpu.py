@@ -1,10 +1,14 @@
 """GraphManager::nodeComparisons on the device (run with -m gpu): lf_node_comparisons = candidate draw + ONE batched solve +
 the decision logic, against the same steps done by hand (lf_candidate_targets, lf_match_pairs_device, the independent Python
 restatement of the decisions in oracle/graph_oracle.py)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
-import graph_oracle as GO
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import graph_oracle as GO   # noqa: E402
 from lineslam_amd import ate, synth
 
 pytestmark = pytest.mark.gpu
