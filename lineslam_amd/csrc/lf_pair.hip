@@ -16,6 +16,7 @@
 #include "lf_pose.h"
 #include <float.h>
 #include "lf_pose_wg.h"
+#include "lf_pose_res.h"
 
 // ------------------------------------------------------------------------------ k_match
 __device__ __forceinline__ double m_pt_line2d(const double *p, const double *l) {   // utils.cpp:1250-1264
@@ -260,27 +261,27 @@ struct PoseShared {
   int idx[LF_MAX_MATCHES];
   unsigned char smp[LF_RANSAC_MAX_ITERS * 3];
   int set[LF_MAX_MATCHES];        // current inlier list (indices into the match list)
-  LmShared lm;
+  ResShared rs;
 };
 
 // getTransformFromHybridMatchesG2O (transformation_estimation.cpp:218-461), line edges only; the
-// sequential twin is oracle_refine_g2o.  set[0..n) = match indices (LDS).
-__device__ void p_refine(LmShared &S, const PoseCtx &pc, const int *set, int n, float *tf, int iterations) {
+// sequential twin is oracle_refine_g2o.  set[0..n) = match indices (LDS); cm = the pair's compact measurements.
+__device__ void r_refine(ResShared &S, const double *cm, const lf_params &P, const int *set, int n, float *tf, int iterations) {
   const int tid = threadIdx.x;
-  const double wgt = pc.P.g2o_line_error_weight, hd = pc.P.g2o_BA_kernel_delta;
-  const int hub = pc.P.g2o_BA_use_kernel;
-  lf_se3 X, Xn;
+  const double wgt = P.g2o_line_error_weight, hd = P.g2o_BA_kernel_delta;
+  const int hub = P.g2o_BA_use_kernel;
+  ResRegs R;
   double lambda = 0, ni = 2, currentChi = 0;
-  lf_tf_to_older_pose(tf, &X);
+  int cur = 0;                                 // S.L[cur], S.X[cur]: the current state; the other set takes the trial step
+  if (tid == 0) { lf_se3 X0; lf_tf_to_older_pose(tf, &X0); S.X[0] = X0; }
   if (tid < n) {
-    const lf_line_record *q = &pc.query[pc.mq[set[tid]]];
-    for (int k = 0; k < 3; k++) { pc.wsL[6 * tid + k] = q->A[k]; pc.wsL[6 * tid + 3 + k] = q->B[k]; }
+    const double *c = cm + (size_t)set[tid] * R_CM;    // nA | nB: the landmark starts at the newer camera's measurement
+    for (int k = 0; k < 6; k++) S.L[0][6 * tid + k] = c[k];
   }
-  p_pad_published(S, n);
+  if (tid < 8) { S.red[0][n + tid] = 0.0; S.red[1][n + tid] = 0.0; }
   __syncthreads();
-  int slot = 0;                                // error record of the current (X, L); the other one takes the trial step
   if (n > 0 && iterations > 0) {
-    p_errchi(pc, set, n, X, pc.wsL, slot, wgt, hd, hub, S.red[0]);
+    r_errchi(cm, set, n, &S.X[0], S.L[0], wgt, hd, hub, S.red[0]);
     __syncthreads();
     currentChi = p_sum_published(S.red[0], n, 0.0);
   }
@@ -289,15 +290,12 @@ __device__ void p_refine(LmShared &S, const PoseCtx &pc, const int *set, int n, 
     int qmax = 0;
     double mxl = 0;
     PT(0);
-    p_perturbed_poses(S, X);
+    r_perturbed_poses(S, &S.X[cur]);
     __syncthreads();
-    p_blocks(S, pc, set, n, X, slot, &mxl);
-    __syncthreads();
+    r_blocks(S, cm, set, n, &S.X[cur], S.L[cur], R, wgt, hd, hub, &mxl);
     PT(5);
-    // Hpp | bp: accumulator lane a (< 42) walks the matches in order and keeps entry a
-    if (tid < 42) S.hb[tid] = p_walk<false>(pc.wsB + 78 + tid, 120, n, 0.0);
     if (it == 0) {   // computeLambdaInit: tau * max |diagonal entry|
-      double mx = p_block_max(S, mxl);           // (barrier inside: hb visible)
+      double mx = r_block_max(S, mxl);           // (barrier inside: hb visible)
 #pragma unroll
       for (int i = 0; i < 6; i++) if (lf_fabs(S.hb[7 * i]) > mx) mx = lf_fabs(S.hb[7 * i]);
       lambda = 1e-5 * mx;
@@ -307,15 +305,8 @@ __device__ void p_refine(LmShared &S, const PoseCtx &pc, const int *set, int n, 
     do {
       double dp[6], scale = 0;
       // the oracle stops eliminating at the first failing match; any failure rejects the step
-      int ok2 = __syncthreads_or(p_eliminate(S, pc, n, lambda)) ? 0 : 1;
+      int ok2 = __syncthreads_or(r_eliminate(S, n, lambda, R)) ? 0 : 1;   // (barrier: S.sg visible)
       PT(7);
-      if (tid < 42) {
-        double acc = S.hb[tid];
-        if (tid < 36 && tid % 7 == 0) acc = acc + lambda;             // S = Hpp + lambda I ; g = bp
-        S.sg[tid] = p_walk<true>(pc.wsTU + tid, 42, n, acc);
-      }
-      __syncthreads();
-      PT(8);
       if (ok2) {
         double A[36];
 #pragma unroll
@@ -327,12 +318,12 @@ __device__ void p_refine(LmShared &S, const PoseCtx &pc, const int *set, int n, 
       PT(9);
       tempChi = DBL_MAX;
       if (ok2) {
-        lf_se3_oplus(&X, dp, &Xn);
+        if (tid == 0) { lf_se3 Xn; lf_se3_oplus(&S.X[cur], dp, &Xn); S.X[cur ^ 1] = Xn; }
 #pragma unroll
         for (int i = 0; i < 6; i++) scale += dp[i] * (lambda * dp[i] + S.hb[36 + i]);
-        p_backsub(pc, n, dp, lambda, S.red[0]);
-        __syncthreads();                       // the new landmarks are in wsLn
-        p_errchi(pc, set, n, Xn, pc.wsLn, slot ^ 1, wgt, hd, hub, S.red[1]);
+        r_backsub(S, n, dp, lambda, S.L[cur], S.L[cur ^ 1], R, S.red[0]);
+        __syncthreads();                       // the trial landmarks are complete
+        r_errchi(cm, set, n, &S.X[cur ^ 1], S.L[cur ^ 1], wgt, hd, hub, S.red[1]);
         __syncthreads();
         scale = p_sum_published(S.red[0], n, scale);
         tempChi = p_sum_published(S.red[1], n, 0.0);
@@ -348,9 +339,7 @@ __device__ void p_refine(LmShared &S, const PoseCtx &pc, const int *set, int n, 
         lambda *= sf;
         ni = 2;
         currentChi = tempChi;
-        X = Xn;
-        slot ^= 1;
-        for (int k = tid; k < 6 * n; k += PT_N) pc.wsL[k] = pc.wsLn[k];
+        cur ^= 1;
       } else {
         lambda *= ni;
         ni *= 2;
@@ -361,19 +350,20 @@ __device__ void p_refine(LmShared &S, const PoseCtx &pc, const int *set, int n, 
     } while (rho < 0 && qmax < 10);
     if (qmax == 10 || rho == 0) break;
   }
-  lf_older_pose_to_tf(&X, tf);
+  lf_older_pose_to_tf(&S.X[cur], tf);
+  __syncthreads();                             // (the next refinement overwrites S.X)
 }
 
 // inlier scan of all matches with tf; returns count, fills set[] (ascending) and the float sse the
 // reference accumulates (motion.cpp:688-699 / 795-812)
-__device__ int p_score(LmShared &S, const PoseCtx &pc, int nLn, const float *tf, double thr, int *set, float *sse_out,
+__device__ int r_score(ResShared &S, const double *cm, int nLn, const float *tf, double thr, int *set, float *sse_out,
                        double *sse_d_out) {
   const int tid = threadIdx.x, w = tid >> 6;
   bool in = false;
   double add = 0;
   if (tid < nLn) {
-    const lf_line_record *q = &pc.query[pc.mq[tid]], *t = &pc.train[pc.mt[tid]];
-    in = lf_line_inlier(tf, q->A, q->B, t->A, t->B, t->DUa, t->DUb, thr, &add);
+    const double *c = cm + (size_t)tid * R_CM;
+    in = lf_line_inlier(tf, c, c + 3, c + 24, c + 27, c + 30, c + 39, thr, &add);
   }
   const u64 msk = __ballot(in);
   if (p_lane() == 0) S.wcnt[w] = __popcll(msk);
@@ -381,7 +371,7 @@ __device__ int p_score(LmShared &S, const PoseCtx &pc, int nLn, const float *tf,
   __syncthreads();
   int base = 0, cnt = 0;
 #pragma unroll
-  for (int k = 0; k < PW_N; k++) { int c = S.wcnt[k]; if (k < w) base += c; cnt += c; }
+  for (int k = 0; k < RW_N; k++) { int c = S.wcnt[k]; if (k < w) base += c; cnt += c; }
   if (in) set[base + __popcll(msk & p_lt())] = tid;
   float sse = 0;      // `float sse` of the RANSAC loop (motion.cpp:666)
   double sse_d = 0;   // `double tmp_sse` of the re-scoring loop (motion.cpp:778)
@@ -399,20 +389,27 @@ __device__ int p_score(LmShared &S, const PoseCtx &pc, int nLn, const float *tf,
   return cnt;
 }
 
-__global__ void __launch_bounds__(PT_N, 2) k_pose(PairConsts c, PairBuffers b) {
+// the three-line model of RANSAC iteration `it` (sample table in LDS) as the float matrix the reference scores with
+__device__ __forceinline__ int r_model(const PoseShared &S, const double *cm, int it, float *tf) {
+  double la[18], lb[18], R[9], t[3];
+  for (int s = 0; s < 3; s++) {
+    const double *c = cm + (size_t)S.smp[3 * it + s] * R_CM;
+    for (int cc = 0; cc < 3; cc++) { la[6 * s + cc] = c[cc]; la[6 * s + 3 + cc] = c[3 + cc]; lb[6 * s + cc] = c[24 + cc]; lb[6 * s + 3 + cc] = c[27 + cc]; }
+  }
+  if (!lf_rel_motion_lines(la, lb, 3, R, t)) return 0;
+  for (int i = 0; i < 3; i++) { for (int cc = 0; cc < 3; cc++) tf[4 * i + cc] = (float)R[3 * i + cc]; tf[4 * i + 3] = (float)t[i]; }
+  tf[12] = tf[13] = tf[14] = 0.0f; tf[15] = 1.0f;
+  return 1;
+}
+
+__global__ void __launch_bounds__(RT_N) k_pose(PairConsts c, PairBuffers b) {
   __shared__ PoseShared S;
   const int pr = blockIdx.x, tid = threadIdx.x, lane = p_lane();
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];
   lf_pair_result *res = b.results + pr;
-  PoseCtx pc;
-  pc.train = b.recs_t + (size_t)ft * b.line_cap_t;
-  pc.query = b.recs + (size_t)fq * c.line_cap;
-  pc.mq = b.match_q + (size_t)pr * c.match_cap;
-  pc.mt = b.match_t + (size_t)pr * c.match_cap;
-  double *ws = b.ws + (size_t)pr * LF_PAIR_WS_DOUBLES;
-  pc.wsB = ws; pc.wsVi = ws + LF_MAX_MATCHES * 120; pc.wsTU = pc.wsVi + LF_MAX_MATCHES * 36;
-  pc.wsL = pc.wsTU + LF_MAX_MATCHES * 42; pc.wsLn = pc.wsL + LF_MAX_MATCHES * 6; pc.wsE = pc.wsLn + LF_MAX_MATCHES * 6;
-  pc.P = c.P;
+  const lf_line_record *train = b.recs_t + (size_t)ft * b.line_cap_t, *query = b.recs + (size_t)fq * c.line_cap;
+  const int *mq = b.match_q + (size_t)pr * c.match_cap, *mt = b.match_t + (size_t)pr * c.match_cap;
+  double *cm = b.ws + (size_t)pr * LF_PAIR_WS_DOUBLES;      // [nLn][R_CM]: the only workspace of the pair
   const lf_params &P = c.P;
   int nLn = b.nmatches[pr];
   const int n_all = nLn;
@@ -435,8 +432,16 @@ __global__ void __launch_bounds__(PT_N, 2) k_pose(PairConsts c, PairBuffers b) {
   { long long d = id_t - id_q; if (d < 0) d = -d; if (d > 50) min_inlier = P.min_matches_loopclose; }   // :631-633
   if (nLn < 3) go = false;
   if (go) {
+    // ---- the measurements of the matched lines, 48 contiguous doubles per match (read by every later phase)
+    for (int e = tid; e < nLn * 2; e += RT_N) {
+      const int k = e >> 1, h = e & 1;
+      const lf_line_record *r = h ? &train[mt[k]] : &query[mq[k]];
+      double *o = cm + (size_t)k * R_CM + 24 * h;
+      for (int j = 0; j < 3; j++) { o[j] = r->A[j]; o[3 + j] = r->B[j]; }
+      for (int j = 0; j < 9; j++) { o[6 + j] = r->DUa[j]; o[15 + j] = r->DUb[j]; }
+    }
     // ---- sample sequence (serial; partial Fisher-Yates state carries over, :635-658)
-    for (int i = tid; i < nLn; i += PT_N) S.idx[i] = i;
+    for (int i = tid; i < nLn; i += RT_N) S.idx[i] = i;
     __syncthreads();
     if (tid == 0) {
       const uint64_t stream = LF_STREAM_PAIR((uint64_t)id_q, (uint64_t)id_t);
@@ -451,63 +456,47 @@ __global__ void __launch_bounds__(PT_N, 2) k_pose(PairConsts c, PairBuffers b) {
         S.smp[3 * it] = (unsigned char)S.idx[0]; S.smp[3 * it + 1] = (unsigned char)S.idx[1]; S.smp[3 * it + 2] = (unsigned char)S.idx[2];
       }
     }
+    __threadfence_block();
     __syncthreads();
     // ---- one hypothesis per thread
     int my_cnt = -1, my_it = 1 << 30;
-    for (int it = tid; it < maxIter; it += PT_N) {
-      double la[18], lb[18], R[9], t[3];
+    for (int it = tid; it < maxIter; it += RT_N) {
       float tf[16];
-      for (int s = 0; s < 3; s++) {
-        int k = S.smp[3 * it + s];
-        const lf_line_record *q = &pc.query[pc.mq[k]], *tr = &pc.train[pc.mt[k]];
-        for (int cc = 0; cc < 3; cc++) { la[6 * s + cc] = q->A[cc]; la[6 * s + 3 + cc] = q->B[cc]; lb[6 * s + cc] = tr->A[cc]; lb[6 * s + 3 + cc] = tr->B[cc]; }
-      }
-      if (!lf_rel_motion_lines(la, lb, 3, R, t)) continue;
-      for (int i = 0; i < 3; i++) { for (int cc = 0; cc < 3; cc++) tf[4 * i + cc] = (float)R[3 * i + cc]; tf[4 * i + 3] = (float)t[i]; }
-      tf[12] = tf[13] = tf[14] = 0.0f; tf[15] = 1.0f;
+      if (!r_model(S, cm, it, tf)) continue;
       int nc = 0;
       for (int i = 0; i < nLn; ++i) {
         double add;
-        const lf_line_record *q = &pc.query[pc.mq[i]], *tr = &pc.train[pc.mt[i]];
-        nc += lf_line_inlier(tf, q->A, q->B, tr->A, tr->B, tr->DUa, tr->DUb, thr, &add);
+        const double *m = cm + (size_t)i * R_CM;
+        nc += lf_line_inlier(tf, m, m + 3, m + 24, m + 27, m + 30, m + 39, thr, &add);
       }
       if (nc > my_cnt) { my_cnt = nc; my_it = it; }   // strictly greater: earliest iteration wins inside a thread
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {   // arg-max: count desc, iteration asc -- wavefront, then the four wavefronts
+    for (int o = 32; o > 0; o >>= 1) {   // arg-max: count desc, iteration asc -- wavefront, then the wavefronts
       int oc = __shfl_xor(my_cnt, o, 64), oi = __shfl_xor(my_it, o, 64);
       if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
     }
-    if (lane == 0) { S.lm.wcnt[tid >> 6] = my_cnt; S.lm.wit[tid >> 6] = my_it; }
+    if (lane == 0) { S.rs.wcnt[tid >> 6] = my_cnt; S.rs.wit[tid >> 6] = my_it; }
     __syncthreads();
-    my_cnt = S.lm.wcnt[0]; my_it = S.lm.wit[0];
+    my_cnt = S.rs.wcnt[0]; my_it = S.rs.wit[0];
 #pragma unroll
-    for (int w = 1; w < PW_N; w++) {
-      int oc = S.lm.wcnt[w], oi = S.lm.wit[w];
+    for (int w = 1; w < RW_N; w++) {
+      int oc = S.rs.wcnt[w], oi = S.rs.wit[w];
       if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
     }
     __syncthreads();
     int nbest = my_cnt > 0 ? my_cnt : 0;
     best_iter = (my_cnt > 0) ? my_it : -1;
     if (0 + nbest >= 3) {                                                                    // :725-728
-      // recompute the winning model (uniform) and its inlier list / sse
-      double la[18], lb[18], R[9], t[3];
       float tf_best[16], sse_best = 0;
-      for (int s = 0; s < 3; s++) {
-        int k = S.smp[3 * best_iter + s];
-        const lf_line_record *q = &pc.query[pc.mq[k]], *tr = &pc.train[pc.mt[k]];
-        for (int cc = 0; cc < 3; cc++) { la[6 * s + cc] = q->A[cc]; la[6 * s + 3 + cc] = q->B[cc]; lb[6 * s + cc] = tr->A[cc]; lb[6 * s + 3 + cc] = tr->B[cc]; }
-      }
-      lf_rel_motion_lines(la, lb, 3, R, t);
-      for (int i = 0; i < 3; i++) { for (int cc = 0; cc < 3; cc++) tf_best[4 * i + cc] = (float)R[3 * i + cc]; tf_best[4 * i + 3] = (float)t[i]; }
-      tf_best[12] = tf_best[13] = tf_best[14] = 0.0f; tf_best[15] = 1.0f;
+      r_model(S, cm, best_iter, tf_best);      // recompute the winning model (uniform) and its inlier list / sse
       double sse_unused;
-      int nb = p_score(S.lm, pc, nLn, tf_best, thr, S.set, &sse_best, &sse_unused);
+      int nb = r_score(S.rs, cm, nLn, tf_best, thr, S.set, &sse_best, &sse_unused);
       float refined_tf[16];
 #pragma unroll
       for (int i = 0; i < 16; i++) refined_tf[i] = tf_best[i];
       PT(12);
-      p_refine(S.lm, pc, S.set, nb, refined_tf, 25);                                            // :730
+      r_refine(S.rs, cm, P, S.set, nb, refined_tf, 25);                                      // :730
       double refined_rmse = lf_sqrt(sse_best / (0 + nb));                                    // :731
       int nref = 0;
       for (int iter = 0; iter < 20; ++iter) {                                                // :775-839
@@ -516,13 +505,13 @@ __global__ void __launch_bounds__(PT_N, 2) k_pose(PairConsts c, PairBuffers b) {
         int *inl = b.inliers + (size_t)pr * LF_MAX_MATCHES;
         // score into a scratch list first (kept only if it improves)
         __syncthreads();
-        int ncur = p_score(S.lm, pc, nLn, refined_tf, thr, S.idx, &tmp_sse_f, &tmp_sse);
+        int ncur = r_score(S.rs, cm, nLn, refined_tf, thr, S.idx, &tmp_sse_f, &tmp_sse);
         if (0 + ncur * lw > 0 + nref * lw) {
-          for (int i = tid; i < ncur; i += PT_N) { S.set[i] = S.idx[i]; inl[i] = S.idx[i]; }
+          for (int i = tid; i < ncur; i += RT_N) { S.set[i] = S.idx[i]; inl[i] = S.idx[i]; }
           __syncthreads();
           nref = ncur;
           refined_rmse = lf_sqrt(tmp_sse / (0 + ncur));
-          p_refine(S.lm, pc, S.set, nref, refined_tf, 20);
+          r_refine(S.rs, cm, P, S.set, nref, refined_tf, 20);
           rounds++;
         } else break;
       }
@@ -536,8 +525,8 @@ __global__ void __launch_bounds__(PT_N, 2) k_pose(PairConsts c, PairBuffers b) {
 #ifdef LF_POSE_PROFILE
   PT(13);
   if (blockIdx.x == 7 && tid == 0) {
-    printf("k_pose prof (kticks) n=%d: pre-blocks %.1f stage0 %.1f A0 %.1f A1 %.1f A2 %.1f B %.1f walk+lambda %.1f elim %.1f walkTU %.1f solve %.1f backsub+chi %.1f accept %.1f | ransac %.1f rescoring/other %.1f\n", nLn,
-           g_pprof[0] / 1e3, g_pprof[1] / 1e3, g_pprof[2] / 1e3, g_pprof[3] / 1e3, g_pprof[4] / 1e3, g_pprof[5] / 1e3, g_pprof[6] / 1e3, g_pprof[7] / 1e3, g_pprof[8] / 1e3, g_pprof[9] / 1e3, g_pprof[10] / 1e3, g_pprof[11] / 1e3, g_pprof[12] / 1e3, g_pprof[13] / 1e3);
+    printf("k_pose prof (kticks) n=%d: pre-blocks %.1f blocks %.1f lambda %.1f elim %.1f solve %.1f backsub+chi %.1f accept %.1f | ransac %.1f rescoring/other %.1f\n", nLn,
+           g_pprof[0] / 1e3, g_pprof[5] / 1e3, g_pprof[6] / 1e3, g_pprof[7] / 1e3, g_pprof[9] / 1e3, g_pprof[10] / 1e3, g_pprof[11] / 1e3, g_pprof[12] / 1e3, g_pprof[13] / 1e3);
     for (int i = 0; i < 16; i++) g_pprof[i] = 0;
   }
 #endif
@@ -566,5 +555,5 @@ void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipS
   if (solver == LF_SOLVER_NONE) return;
   if (solver == LF_SOLVER_HYBRID) lf_pair_hybrid_launch(c, b, n_pairs, st);
   else if (solver == LF_SOLVER_RELMOTION) lf_pair_relmotion_launch(c, b, n_pairs, st);
-  else hipLaunchKernelGGL(k_pose, dim3(n_pairs), dim3(PT_N), 0, st, c, b);
+  else hipLaunchKernelGGL(k_pose, dim3(n_pairs), dim3(RT_N), 0, st, c, b);
 }
