@@ -567,27 +567,28 @@ __device__ __forceinline__ void f_mle_cost(const MState &S, const MleGroup &g, i
     out[h] = r;
   }
 }
-// sum of v[i]^2 over the rows i = 0..n-1 in that order (row i lives in group lane i % G, slot i / G)
+// levmar's LEVMAR_L2NRMXMY (misc_core.c; called at lm_core.c:555 / :743): the sum of v[i]^2 over the rows with FOUR running
+// sums -- blocks of eight from the top of the vector downwards (rows 8b+7-c and 8b+3-c go to sum c), then the remainder
+// through the fall-through switch (row blockn + t of a remainder of r rows goes to sum (7 - r + t) mod 4) -- returned as
+// sum0+sum1+sum2+sum3.  Group lane l runs chain l mod 4 from the squares published in LDS; every lane then adds the four.
 template <int G, int RW>
 __device__ __forceinline__ double f_ordered_sumsq(const MState &S, const double *v, const MleGroup &g, int n) {
+#pragma unroll
+  for (int h = 0; h < MleCfgT<G, RW>::SLOTS; h++) { int i = g.glane + G * h; if (i < n) S.scr[i] = v[h] * v[h]; }
+  g_order<G>();
+  const int c = g.glane & 3, nb = n >> 3, r = n & 7, blockn = nb << 3;
   double s = 0.0;
-  {                          // the squares are published in LDS, every lane adds them in row order (cheaper than
-                             // readlane / shuffle pairs also for one line per wavefront)
-#pragma unroll
-    for (int h = 0; h < MleCfgT<G, RW>::SLOTS; h++) { int i = g.glane + G * h; if (i < n) S.scr[i] = v[h] * v[h]; }
-    g_order<G>();
-    const int n8 = (n + 7) & ~7;   // rows n .. n8-1 of scr are zero (f_levmar6)
-    int l = 0;
-    for (; l + 8 <= n8; l += 8) {  // eight loads in flight, the additions stay in row order
-      double q[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) q[k] = S.scr[l + k];
-#pragma unroll
-      for (int k = 0; k < 8; k++) s += q[k];
-    }
-    g_order<G>();
+  for (int b = nb - 1; b >= 0; --b) {
+    const double q0 = S.scr[8 * b + 7 - c], q1 = S.scr[8 * b + 3 - c];
+    s += q0;
+    s += q1;
   }
-  return s;
+  const int t0 = (c - (7 - r)) & 3;
+  if (t0 < r) s += S.scr[blockn + t0];
+  if (t0 + 4 < r) s += S.scr[blockn + t0 + 4];
+  g_order<G>();
+  const double s0 = g_get<G>(s, g, 0), s1 = g_get<G>(s, g, 1), s2 = g_get<G>(s, g, 2), s3 = g_get<G>(s, g, 3);
+  return s0 + s1 + s2 + s3;
 }
 
 #ifdef LF_MLE_PROFILE   // LF_EXTRA_CFLAGS=-DLF_MLE_PROFILE: s_memtime per LM phase of line 7 of frame 0, printed

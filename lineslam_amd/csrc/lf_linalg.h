@@ -97,6 +97,31 @@ LF_HD uint32_t lf_rand31(uint64_t seed, uint64_t stream, uint64_t counter) {
 LF_DEFINE_JACOBI(lf_jacobi3, 3)
 LF_DEFINE_JACOBI(lf_jacobi4, 4)
 
+/* levmar's LEVMAR_L2NRMXMY (external/levmar-2.6/misc_core.c) for an error vector that is already formed: four running
+ * sums over blocks of eight from the top downwards, the remainder by the fall-through switch, sum0+sum1+sum2+sum3. */
+LF_HD double lf_l2nrm_sq(const double *e, int n) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const int blockn = (n >> 3) << 3;
+  int i;
+  for (i = blockn - 1; i > 0; i -= 8) {
+    s0 += e[i] * e[i]; s1 += e[i - 1] * e[i - 1]; s2 += e[i - 2] * e[i - 2]; s3 += e[i - 3] * e[i - 3];
+    s0 += e[i - 4] * e[i - 4]; s1 += e[i - 5] * e[i - 5]; s2 += e[i - 6] * e[i - 6]; s3 += e[i - 7] * e[i - 7];
+  }
+  i = blockn;
+  if (i < n) {
+    switch (n - i) {
+      case 7: s0 += e[i] * e[i]; ++i; /* fall through */
+      case 6: s1 += e[i] * e[i]; ++i; /* fall through */
+      case 5: s2 += e[i] * e[i]; ++i; /* fall through */
+      case 4: s3 += e[i] * e[i]; ++i; /* fall through */
+      case 3: s0 += e[i] * e[i]; ++i; /* fall through */
+      case 2: s1 += e[i] * e[i]; ++i; /* fall through */
+      case 1: s2 += e[i] * e[i];
+    }
+  }
+  return s0 + s1 + s2 + s3;
+}
+
 /* ---------------------------------------------------------------- linear solve
  * Gaussian elimination with partial pivoting on the n x n row-major matrix A (overwritten) and the
  * n x m right-hand side B (row-major, overwritten with the solution).  Returns 0 if singular. */

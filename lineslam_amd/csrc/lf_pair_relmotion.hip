@@ -63,8 +63,7 @@ __device__ int r_levmar7(RShared &S, const RCtx &pc, const int *list, int n, dou
   r_cost(pc, list, n, p, S.hx);
   for (int i = lane; i < n; i += 64) S.e[i] = 0.0 - S.hx[i];
   __syncthreads();
-  p_eL2 = 0.0;
-  for (int i = 0; i < n; ++i) { tmp = S.e[i]; p_eL2 += tmp * tmp; }
+  p_eL2 = lf_l2nrm_sq(S.e, n);
   if (!(lf_fabs(p_eL2) <= DBL_MAX)) stop = 7;
   nu = 20;
   for (k = 0; k < itmax && !stop; ++k) {
@@ -134,8 +133,7 @@ __device__ int r_levmar7(RShared &S, const RCtx &pc, const int *list, int n, dou
       r_cost(pc, list, n, pDp, S.wrk);
       for (int i = lane; i < n; i += 64) S.wrk2[i] = 0.0 - S.wrk[i];
       __syncthreads();
-      pDp_eL2 = 0.0;
-      for (int i = 0; i < n; ++i) { tmp = S.wrk2[i]; pDp_eL2 += tmp * tmp; }
+      pDp_eL2 = lf_l2nrm_sq(S.wrk2, n);
       if (!(lf_fabs(pDp_eL2) <= DBL_MAX)) { stop = 7; break; }
       dF = p_eL2 - pDp_eL2;
       if (updp || dF > 0) {                       // Broyden rank-one update, row-parallel

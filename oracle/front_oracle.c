@@ -386,6 +386,37 @@ int oracle_msld(const double *xG, const double *yG, int width, int height, const
  * EPSILON 1e-12, ONE_THIRD 0.3333333334).  Measurement vector x == 0 as in the reference's calls.
  * Linear solver: LU with partial pivoting (AX_EQ_B_LU).  m <= 7.                               */
 typedef void (*o_lm_func)(const double *p, double *hx, int m, int n, void *adata);
+/* dlevmar_L2nrmxmy with x == 0 values (misc_core.c, LEVMAR_L2NRMXMY; lm_core.c:555 and :743 call it, the plain loops
+ * there are compiled out): e = 0 - y and ||e||^2 with FOUR running sums over blocks of eight taken from the top of the
+ * vector downwards, then the remainder by the fall-through switch, returned as sum0+sum1+sum2+sum3.                  */
+static double o_l2nrmxmy(double *e, const double *y, int n) {
+  double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0, sum3 = 0.0;
+  const int blockn = (n >> 3) << 3;
+  int i;
+  for (i = blockn - 1; i > 0; i -= 8) {
+    e[i] = 0.0 - y[i]; sum0 += e[i] * e[i];
+    e[i - 1] = 0.0 - y[i - 1]; sum1 += e[i - 1] * e[i - 1];
+    e[i - 2] = 0.0 - y[i - 2]; sum2 += e[i - 2] * e[i - 2];
+    e[i - 3] = 0.0 - y[i - 3]; sum3 += e[i - 3] * e[i - 3];
+    e[i - 4] = 0.0 - y[i - 4]; sum0 += e[i - 4] * e[i - 4];
+    e[i - 5] = 0.0 - y[i - 5]; sum1 += e[i - 5] * e[i - 5];
+    e[i - 6] = 0.0 - y[i - 6]; sum2 += e[i - 6] * e[i - 6];
+    e[i - 7] = 0.0 - y[i - 7]; sum3 += e[i - 7] * e[i - 7];
+  }
+  i = blockn;
+  if (i < n) {
+    switch (n - i) {
+      case 7: e[i] = 0.0 - y[i]; sum0 += e[i] * e[i]; ++i; /* fall through */
+      case 6: e[i] = 0.0 - y[i]; sum1 += e[i] * e[i]; ++i; /* fall through */
+      case 5: e[i] = 0.0 - y[i]; sum2 += e[i] * e[i]; ++i; /* fall through */
+      case 4: e[i] = 0.0 - y[i]; sum3 += e[i] * e[i]; ++i; /* fall through */
+      case 3: e[i] = 0.0 - y[i]; sum0 += e[i] * e[i]; ++i; /* fall through */
+      case 2: e[i] = 0.0 - y[i]; sum1 += e[i] * e[i]; ++i; /* fall through */
+      case 1: e[i] = 0.0 - y[i]; sum2 += e[i] * e[i];
+    }
+  }
+  return sum0 + sum1 + sum2 + sum3;
+}
 int oracle_levmar_dif(o_lm_func func, double *p, int m, int n, int itmax, const double opts[5],
                       double info[10], void *adata) {
   double *e = (double *)malloc(sizeof(double) * (size_t)n * (4 + m));
@@ -397,7 +428,7 @@ int oracle_levmar_dif(o_lm_func func, double *p, int m, int n, int itmax, const 
   int nu, nu2, stop = 0, nfev, njap = 0, nlss = 0, K = (m >= 10) ? m : 10, updjac = 0, updp = 1, newjac = 0;
   int i, j, k, l, issolved;
   func(p, hx, m, n, adata); nfev = 1;
-  for (i = 0, p_eL2 = 0.0; i < n; ++i) { e[i] = tmp = 0.0 - hx[i]; p_eL2 += tmp * tmp; }
+  p_eL2 = o_l2nrmxmy(e, hx, n);
   init_p_eL2 = p_eL2;
   if (!isfinite(p_eL2)) stop = 7;
   nu = 20;
@@ -455,7 +486,7 @@ int oracle_levmar_dif(o_lm_func func, double *p, int m, int n, int itmax, const 
       if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
       if (Dp_L2 >= (p_L2 + eps2) / (1E-12 * 1E-12)) { stop = 4; break; }
       func(pDp, wrk, m, n, adata); ++nfev;
-      for (i = 0, pDp_eL2 = 0.0; i < n; ++i) { wrk2[i] = tmp = 0.0 - wrk[i]; pDp_eL2 += tmp * tmp; }
+      pDp_eL2 = o_l2nrmxmy(wrk2, wrk, n);
       if (!isfinite(pDp_eL2)) { stop = 7; break; }
       dF = p_eL2 - pDp_eL2;
       if (updp || dF > 0) { /* Broyden rank-one update */

@@ -65,4 +65,4 @@ def test_mle_line_vs_independent_vectors():
             n_same += (nit == c["levmar_meta"][0] and int(info[6]) == c["levmar_meta"][1])
             assert np.abs(cA - c["levmar_covA"]).max() < 5e-3 * np.abs(cA).max(), k
             assert np.abs(cB - c["levmar_covB"]).max() < 5e-3 * np.abs(cB).max(), k
-    assert n_lev == 0 or n_same >= n_lev // 2
+    assert n_lev == 0 or n_same >= (7 * n_lev) // 10   # measured: 30 of 40

@@ -61,11 +61,11 @@ def test_levmar_restatement_matches_reference_levmar():
         lib.oracle_levmar_dif.restype = C.c_int
         rb = lib.oracle_levmar_dif(cb, pb.ctypes.data_as(C.POINTER(C.c_double)), 6, n, 100, opts, ib, None)
         same_path += (ra == rb and int(ia[6]) == int(ib[6]) and int(ia[7]) == int(ib[7]))
-        assert np.allclose(pa, pb, rtol=0, atol=5e-6), (trial, np.abs(pa - pb).max())   # dif-LM resolution
+        assert np.allclose(pa, pb, rtol=0, atol=5e-7), (trial, np.abs(pa - pb).max())   # measured: <= 3.5e-8
         assert abs(ia[1] - ib[1]) <= 1e-9 * max(1.0, ia[1])
-    # identical iteration count / stop reason / #function evaluations unless the noise-driven tail of
-    # the forward-difference LM (eps2 = eps3 = 1e-20) takes a different number of rejected steps
-    assert same_path >= 5, same_path
+    # identical iteration count / stop reason / #function evaluations (8 of 8 since the error norm follows levmar's
+    # LEVMAR_L2NRMXMY summation order; the linear solver stays a restatement: LAPACK's LU differs in rounding)
+    assert same_path >= 7, same_path
 
 
 def test_jacobi_and_solve_vs_numpy():
