@@ -608,7 +608,7 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
   constexpr int SL = MleCfgT<G, RW>::SLOTS;
   const int m = 6, lane = g.glane;
   const double tau = 1E-03, eps1 = 1E-10, eps2 = 1E-20, eps2_sq = 1E-20 * 1E-20, eps3 = 1E-20, delta = 1E-06;
-  double jacTe[6], jacTjac[36], Dp[6], diag[6], pDp[6];
+  double jacTe[6], Dp[6], diag[6], pDp[6];
   double hx[SL], ev[SL], wrk[SL], wrk2[SL];
   double mu = 0, tmp, p_eL2, jacTe_inf = 0, pDp_eL2, p_L2 = 0, Dp_L2 = DBL_MAX, dF, dL;
   int nu, nu2, stop = 0, K = 10, updjac = 0, updp = 1, newjac = 0, k;
@@ -686,23 +686,18 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
         }
       }
       MT(2);
-      {   // the accumulator lanes publish their entries, every lane of the group reads all 27
+      {   // the accumulator lanes publish their entries; J^T J stays in LDS (read where the system is set up), the
+          // group keeps J^T e and the diagonal in registers
 #pragma unroll
         for (int q = 0; q < NACC; q++) { int a = lane + G * q; if (a < 27) S.accs[a] = acc[q]; }
         g_order<G>();
 #pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-          for (int j = 0; j <= i; j++) { double v = S.accs[i * (i + 1) / 2 + j]; jacTjac[i * m + j] = v; jacTjac[j * m + i] = v; }
-#pragma unroll
-        for (int i = 0; i < 6; i++) jacTe[i] = S.accs[21 + i];
-        g_order<G>();
+        for (int i = 0; i < 6; i++) { diag[i] = S.accs[i * (i + 1) / 2 + i]; jacTe[i] = S.accs[21 + i]; }
       }
       p_L2 = jacTe_inf = 0.0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         if (jacTe_inf < (tmp = lf_fabs(jacTe[i]))) jacTe_inf = tmp;
-        diag[i] = jacTjac[i * m + i];
         p_L2 += p[i] * p[i];
       }
     }
@@ -714,13 +709,13 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
       for (int i = 0; i < 6; ++i) if (diag[i] > tmp) tmp = diag[i];
       mu = tau * tmp;
     }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) jacTjac[i * m + i] += mu;
     int issolved;
-    {
+    {   // the augmented normal equations (J^T J + mu I) Dp = J^T e: symmetric fill from the 21 published sums
       double A[36], Bv[6];
 #pragma unroll
-      for (int i = 0; i < 36; i++) A[i] = jacTjac[i];
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) { double v = S.accs[i * (i + 1) / 2 + j]; if (i == j) v += mu; A[i * m + j] = v; A[j * m + i] = v; }
 #pragma unroll
       for (int i = 0; i < 6; i++) Bv[i] = jacTe[i];
       if constexpr (G == 64) issolved = lf_solve6_u(A, Bv, 1);   // one system per wavefront: scalar pivot branches
@@ -780,9 +775,7 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
     mu *= nu;
     nu2 = nu << 1;
     if (nu2 <= nu) { stop = 5; break; }
-    nu = nu2;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) jacTjac[i * m + i] = diag[i];
+    nu = nu2;                                   // (the diagonal is set up again from the sums: nothing to restore)
   }
   if (k >= itmax) stop = 3;
   *stop_out = stop;
@@ -862,7 +855,7 @@ __device__ __forceinline__ void f_mle_line(const FrontConsts &c, const FrontBuff
   // ---- MleLine3dCov (utils.cpp:1138-1159): H = J^T J in point order, cov = H^-1.  Every lane forms the 3x6 Jacobian
   // of its own rows, the rows are published in LDS (over pos / DU, which are dead by then), and 21 accumulator lanes
   // walk them in the reference's order (point by point, residual row by row); H is symmetric term by term.
-  double H[36], I6[36];
+  double covA[9], covB[9];
   {
     constexpr int SL = Cfg::SLOTS;
     double J[SL][18];
@@ -916,31 +909,46 @@ __device__ __forceinline__ void f_mle_line(const FrontConsts &c, const FrontBuff
       }
     }
     g_order<G>();
+  }
+  // cov = H^-1 by elimination with the identity as right-hand sides; the record keeps its upper-left and lower-right
+  // 3x3 blocks only (covA, covB), and the columns of an inverse are independent: two eliminations with three columns
+  // each (the same operations on the columns that are kept) instead of one with six -- a third fewer live registers.
+  int inv_ok = 1;
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    double Hm[36], Bm[18];
 #pragma unroll
     for (int k = 0; k < 6; k++)
 #pragma unroll
-      for (int l = 0; l <= k; l++) { double v = S.accs[k * (k + 1) / 2 + l]; H[k * 6 + l] = v; H[l * 6 + k] = v; }
-    g_order<G>();
-  }
+      for (int l = 0; l <= k; l++) { double v = S.accs[k * (k + 1) / 2 + l]; Hm[k * 6 + l] = v; Hm[l * 6 + k] = v; }
 #pragma unroll
-  for (int i = 0; i < 36; i++) I6[i] = (i % 7 == 0) ? 1.0 : 0.0;
-  int inv_ok;
-  if constexpr (G == 64) inv_ok = lf_solve6_u(H, I6, 6);   // one line per wavefront: scalar pivot branches
-  else inv_ok = lf_solve6(H, I6, 6);
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) Bm[i * 3 + j] = (i == j + 3 * half) ? 1.0 : 0.0;
+    int ok;
+    if constexpr (G == 64) ok = lf_solve6_u(Hm, Bm, 3);   // one line per wavefront: scalar pivot branches
+    else ok = lf_solve6(Hm, Bm, 3);
+    if (!ok) inv_ok = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int q = 0; q < 3; q++) { if (half == 0) covA[3 * r + q] = Bm[r * 3 + q]; else covB[3 * r + q] = Bm[(r + 3) * 3 + q]; }
+  }
+  g_order<G>();
   if (!inv_ok) {
 #pragma unroll
-    for (int i = 0; i < 36; i++) I6[i] = lf_from_bits(0x7ff8000000000000ULL);
+    for (int i = 0; i < 9; i++) { covA[i] = lf_from_bits(0x7ff8000000000000ULL); covB[i] = covA[i]; }
   }
   // ---- results: line3d.A/B, covA/covB, rndA/rndB (RandomPoint3d ctor) into the record
   if (lane == 0) {
     double cov[9], DU[9], Wsq[3];
     for (int q = 0; q < 3; q++) { R->A[q] = para[q]; R->B[q] = para[3 + q]; out[29 + q] = LA[q]; out[q] = para[q]; out[3 + q] = para[3 + q]; }
-    for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) cov[3 * r + q] = I6[r * 6 + q];
+    for (int q = 0; q < 9; q++) cov[q] = covA[q];
     for (int q = 0; q < 9; q++) { R->covA[q] = cov[q]; out[6 + q] = cov[q]; }
     f_whiten(cov, DU, Wsq);
     for (int q = 0; q < 9; q++) R->DUa[q] = DU[q];
     for (int q = 0; q < 3; q++) R->Wsa[q] = Wsq[q];
-    for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) cov[3 * r + q] = I6[(r + 3) * 6 + 3 + q];
+    for (int q = 0; q < 9; q++) cov[q] = covB[q];
     for (int q = 0; q < 9; q++) { R->covB[q] = cov[q]; out[15 + q] = cov[q]; }
     f_whiten(cov, DU, Wsq);
     for (int q = 0; q < 9; q++) R->DUb[q] = DU[q];
@@ -1135,8 +1143,10 @@ void lf_front_launch(const FrontConsts &c, const FrontBuffers &b, int B, hipStre
   hipLaunchKernelGGL(k_sobel5, dim3((c.W + 255) / 256, (c.H + SOBEL_ROWS - 1) / SOBEL_ROWS, B), dim3(256), 0, st, c, b);
   hipLaunchKernelGGL(k_line3d, dim3(c.cand_cap, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_records, dim3(B), dim3(64), 0, st, c, b);
+#ifndef LF_EXP_SKIP_MLE   // (throughput experiments only: what the step costs without this stage)
   hipLaunchKernelGGL((k_mle<32, 32, 1>), dim3((c.line_cap + 1) / 2, B), dim3(64), 0, st, c, b);   // 2 lines per wavefront
   // (pairing the 33..64-point lines as <32, 64> was measured slower: two row slots per lane, select-based pivoting)
   hipLaunchKernelGGL((k_mle<64, MLE_N, 2>), dim3(c.line_cap, B), dim3(64), 0, st, c, b);
+#endif
   hipLaunchKernelGGL(k_describe, dim3(c.line_cap, B), dim3(64), 0, st, c, b);
 }

@@ -1314,7 +1314,10 @@ void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int B, hipStream_t s
     if (c.sweep_waves >= 8) hipLaunchKernelGGL(k_lsd_sweep_mw<8>, dim3(B), dim3(8 * 64), 0, st, c, b.dconsts, b);
     else if (c.sweep_waves >= 4) hipLaunchKernelGGL(k_lsd_sweep_mw<4>, dim3(B), dim3(4 * 64), 0, st, c, b.dconsts, b);
     else hipLaunchKernelGGL(k_lsd_sweep_mw<2>, dim3(B), dim3(2 * 64), 0, st, c, b.dconsts, b);
-  } else
-  hipLaunchKernelGGL(k_lsd_sweep, dim3(B), dim3(64), 0, st, c, b.dconsts, b);
+  } else {
+#ifndef LF_EXP_SKIP_SWEEP   // (throughput experiments only)
+    hipLaunchKernelGGL(k_lsd_sweep, dim3(B), dim3(64), 0, st, c, b.dconsts, b);
+#endif
+  }
   if (b.ev_sweep1) (void)hipEventRecord(b.ev_sweep1, st);
 }

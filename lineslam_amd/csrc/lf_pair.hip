@@ -555,5 +555,9 @@ void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipS
   if (solver == LF_SOLVER_NONE) return;
   if (solver == LF_SOLVER_HYBRID) lf_pair_hybrid_launch(c, b, n_pairs, st);
   else if (solver == LF_SOLVER_RELMOTION) lf_pair_relmotion_launch(c, b, n_pairs, st);
-  else hipLaunchKernelGGL(k_pose, dim3(n_pairs), dim3(RT_N), 0, st, c, b);
+  else {
+#ifndef LF_EXP_SKIP_POSE   // (throughput experiments only)
+    hipLaunchKernelGGL(k_pose, dim3(n_pairs), dim3(RT_N), 0, st, c, b);
+#endif
+  }
 }
