@@ -6,7 +6,7 @@ import numpy as np, torch
 from lineslam_amd import capi, synth
 B = 1147
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-g, d, _ = synth.sequence(B, seed=0, n_unique=8)
+g, d, _ = synth.sequence(B, seed=int(os.environ.get("LF_SEED", "0")), n_unique=int(os.environ.get("LF_UNIQUE", "8")))
 ctx = capi.Context(640, 480, max_batch=B, params=capi.default_params(launch=True))
 dg, dd = torch.from_numpy(g).cuda(), torch.from_numpy(d).cuda()
 ctx.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), B, synth.K_TUM, np.arange(B, dtype=np.uint64))

@@ -22,3 +22,4 @@ done
 python tools/sq_summary.py $OUT $TAG
 find $OUT -name "*kernel_trace.csv" -delete
 ls -la $OUT
+python tools/valu_summary.py $OUT/${TAG}_sq_counters_by_kernel.csv $OUT/${TAG}_valu_utilisation.json
