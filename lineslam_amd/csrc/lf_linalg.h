@@ -157,7 +157,7 @@ LF_HD double lf_l2nrm_sq(const double *e, int n) {
       if (LF_ANY(piv != k))                                                                    \
         for (i = k + 1; i < N; i++)          /* row swap with constant indices */              \
           if (i == piv) {                                                                      \
-            for (j = 0; j < N; j++) { double t = A[k * N + j]; A[k * N + j] = A[i * N + j]; A[i * N + j] = t; } \
+            for (j = k; j < N; j++) { double t = A[k * N + j]; A[k * N + j] = A[i * N + j]; A[i * N + j] = t; } /* (columns < k of rows >= k are 0.0) */ \
             for (j = 0; j < m; j++) { double t = B[k * m + j]; B[k * m + j] = B[i * m + j]; B[i * m + j] = t; } \
           }                                                                                    \
       rp[k] = 1.0 / A[k * N + k];                                                              \
