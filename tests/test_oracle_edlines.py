@@ -1,7 +1,8 @@
-"""The EDLines statement (oracle/edlines_oracle.c, paper level) on the one example the reference ships for its binary-only
-detector: external/EDLines/house.pgm -> LineSegments.txt (tests/golden/edlines_fixture.npz).  PARITY UNPINNED: the numbers
-below MEASURE the agreement; they are not a claim of equality.  What is asserted is what this statement reaches today, so that
-a regression (or an improvement) of the approximation is visible."""
+"""The EDLines restatement (oracle/edlines_oracle.c: the object code of the reference's libEDLines.a, function by function)
+on the one example the reference ships for its binary-only detector: external/EDLines/house.pgm -> LineSegments.txt
+(tests/golden/edlines_fixture.npz, 166 rows with two decimals).  Every row of the binary's output is reproduced at the file's
+0.01 px resolution; the restatement keeps two more short segments (borderline in the a-contrario validation: the number of
+aligned pixels equals the minimum)."""
 import os
 
 import numpy as np
@@ -20,12 +21,14 @@ def test_house_example_agreement_is_measured():
     img, ref = z["house"], z["segments"]
     segs = O.edlines_oracle(img)
     best = np.array([min(_dist(r, s) for s in segs) for r in ref])
-    exact, px1, px3 = int((best <= 0.0101).sum()), int((best < 1.5).sum()), int((best < 3.0).sum())
-    print("EDLines statement vs the binary's example: %d segments (binary: %d); reference rows reproduced at 0.01 px: %d, "
-          "within 1.5 px: %d, within 3 px: %d" % (len(segs), len(ref), exact, px1, px3))
-    assert 60 <= len(segs) <= 400
-    assert px1 >= 20 and px3 >= 40          # the long, clean edges of the house are found within a pixel or two
-    # every detected segment is a real line: at least the minimum length, inside the image
+    exact, px1 = int((best <= 0.0101).sum()), int((best < 1.5).sum())
+    print("EDLines restatement vs the binary's example: %d segments (binary: %d); reference rows reproduced at 0.01 px: %d, "
+          "within 1.5 px: %d" % (len(segs), len(ref), exact, px1))
+    assert exact == len(ref) == 166                      # every row of LineSegments.txt, to the printed precision
+    assert len(segs) <= len(ref) + 2                     # ... and at most two segments the binary's validation rejects
+    # the common rows come in the binary's order
+    order = [int(np.argmin([_dist(r, s) for s in segs])) for r in ref]
+    assert order == sorted(order)
     ln = np.hypot(segs[:, 0] - segs[:, 2], segs[:, 1] - segs[:, 3])
     assert ln.min() >= 7.9 and segs.min() >= 0 and segs.max() <= 400
 
@@ -35,7 +38,7 @@ def test_flavours_and_simple_shapes():
     img[30:90, 40:120] = 200
     a, b = O.edlines_oracle(img, flavour="ref"), O.edlines_oracle(img, flavour="lf")
     assert len(a) == 4 and np.array_equal(a, b)
-    # the four sides of the rectangle, within a pixel
+    # the four sides of the rectangle (the 2x2 gradient operator puts an edge half a pixel up and left; the corners are cut)
     want = [(40, 29, 40, 89), (119, 29, 119, 89), (41, 30, 118, 30), (41, 89, 118, 89)]
     for wnt in want:
-        assert min(_dist(np.array(wnt, float), s) for s in a) < 1.6
+        assert min(_dist(np.array(wnt, float), s) for s in a) < 2.6
