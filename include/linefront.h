@@ -181,10 +181,13 @@ LF_API int lf_lsd(lf_ctx *ctx, const uint8_t *gray, int row_stride, int width, i
 /* ---- EDLines -----------------------------------------------------------------------------
  * Replaces  LS* callEDLines(const cv::Mat& im_uchar, int* numLines)  (src/line/utils.cpp:1829-1853) ->
  * DetectLinesByED(srcImg, width, height, &noLines) of external/EDLines/libEDLines.a for a batch of frames.  The reference has
- * that detector as a BINARY only; what runs here is the detector of the papers it implements (Edge Drawing, JVCIR 2012;
- * EDLines, PRL 2011) -- Gaussian 5x5 sigma 1, Sobel gradient >= 36, anchors >= 8 strongest first, smart routing, least-squares
- * line fitting with a 1 px tolerance, Helmholtz validation with p = 1/8 -- so its output approximates the binary's and is
- * not pinned to it (tests/test_oracle_edlines.py measures the agreement on the reference's house.pgm example).  Results:
+ * that detector as a BINARY only (x86-64 objects, not stripped); what runs here is the algorithm of its object code, restated
+ * function by function from the disassembly (oracle/edlines_oracle.c): cvSmooth 5x5 with the fixed kernel 1 4 6 4 1 / 16,
+ * ComputeGradientMapByLSD with threshold 11, anchors with threshold 3 joined strongest first through chain trees
+ * (DoDetectEdgesByED), SplitSegment2Lines, JoinCollinearLines(6.0, 1.3), ValidateLineSegments.  On the reference's own example
+ * (house.pgm -> LineSegments.txt) all 166 rows of the binary's output are reproduced at the file's 0.01 px resolution; the
+ * restatement keeps two more short segments that are borderline in the a-contrario validation.  cvSmooth itself is OpenCV's
+ * (absent here: restated from OpenCV 2.4's published algorithm, including the SSE2 column pass's rounding).  Results:
  * lf_lsd_get_segments (rows sx, sy, ex, ey, 0).  lf_detect3d_batch_device runs this detector instead of LSD when
  * lf_params::line_detector == LF_DETECTOR_EDLINES (the `algorithm == "EDLINES"` branch of Node::detect3DLines).  Asynchronous. */
 LF_API int lf_edlines_batch_device(lf_ctx *ctx, const uint8_t *d_gray, size_t frame_stride, int row_stride, int n_frames);

@@ -66,7 +66,7 @@ class Node {
                      const std::string& algorithm) {
     if (algorithm != "LSD" && algorithm != "EDLINES") throw Error(LF_ERR_UNSUPPORTED, "detect3DLines: algorithm must be \"LSD\" or \"EDLINES\"");
     lf_params p = ctx->params;
-    p.line_detector = algorithm == "EDLINES" ? LF_DETECTOR_EDLINES : LF_DETECTOR_LSD;   // (EDLINES: paper-level, see linefront.h)
+    p.line_detector = algorithm == "EDLINES" ? LF_DETECTOR_EDLINES : LF_DETECTOR_LSD;   // (EDLINES: the binary's algorithm restated, see linefront.h)
     p.line_segment_len_thresh = line2d_len_thres; p.ratio_of_collinear_pts = ratio_of_collinear_pts;
     p.line3d_length_thresh = line_3d_len_thres_m; p.depth_scaling = depth_scaling;
     check(lf_ctx_set_params(ctx->h, &p), "lf_ctx_set_params");   // (cheap: the LSD tables are rebuilt only when an lsd_* member changes)

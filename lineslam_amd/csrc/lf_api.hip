@@ -1538,48 +1538,94 @@ int lf_orb_get_level(lf_ctx *c, int frame, int level, int blurred, uint8_t *out,
 
 
 // ---- EDLines ---------------------------------------------------------------------------------------------------------
+// nfa() of the reference's libEDLines.a (NFA.o; LSD's: log-gamma by Lanczos / Windschitl, binomial tail with 10 % tolerance,
+// reciprocals of the term index) -- evaluated on the host with libm, once per image size, exactly as the binary builds its
+// NFALUT; the device sees the table only.
+static double ed_log_gamma(double x) {
+  if (x > 15.0) return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
+  static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+  double a = (x + 0.5) * log(x + 5.5) - (x + 5.5), b = 0.0;
+  for (int n = 0; n < 7; n++) { a -= log(x + (double)n); b += q[n] * pow(x, (double)n); }
+  return a + log(b);
+}
+static double ed_nfa(int n, int k, double p, double logNT) {
+  const double tolerance = 0.1;
+  if (n == 0 || k == 0) return -logNT;
+  if (n == k) return -logNT - (double)n * log10(p);
+  const double p_term = p / (1.0 - p);
+  const double log1term = ed_log_gamma((double)n + 1.0) - ed_log_gamma((double)k + 1.0) - ed_log_gamma((double)(n - k) + 1.0) + (double)k * log(p) +
+                          (double)(n - k) * log(1.0 - p);
+  double term = exp(log1term);
+  if (term == 0.0) {
+    if ((double)k > (double)n * p) return -log1term / 2.30258509299404568402 - logNT;
+    return -logNT;
+  }
+  double bin_tail = term;
+  for (int i = k + 1; i <= n; i++) {
+    const double bin_term = (double)(n - i + 1) * (1.0 / (double)i);
+    const double mult_term = bin_term * p_term;
+    term *= mult_term;
+    bin_tail += term;
+    if (bin_term < 1.0) {
+      const double err = term * ((1.0 - pow(mult_term, (double)(n - i + 1))) / (1.0 - mult_term) - 1.0);
+      if (err < tolerance * fabs(-log10(bin_tail) - logNT) * bin_tail) break;
+    }
+  }
+  return -log10(bin_tail) - logNT;
+}
 static int ed_prepare(lf_ctx *c) {
   EdConsts &e = c->ec;
   memset(&e, 0, sizeof e);
   e.W = c->W; e.H = c->H;
-  if ((size_t)c->W * c->H > (1u << 19) || c->W > 65535 || c->H > 65535) return LF_ERR_UNSUPPORTED;   // anchor keys: 19-bit pixel index
-  {   // getGaussianKernel(5, 1, CV_32F) in 8-bit fixed point (host libm exp)
-    double s2 = -0.5, sum = 0;
-    float cf[5];
-    for (int i = 0; i < 5; i++) { double x = i - 2.0, t = exp(s2 * x * x); cf[i] = (float)t; sum += cf[i]; }
-    sum = 1. / sum;
-    for (int i = 0; i < 5; i++) { cf[i] = (float)(cf[i] * sum); e.sk[i] = (int)nearbyint((double)(cf[i] * 256.f)); }
-  }
-  {
-    int n = (int)nearbyint(-2.0 * (log10((double)c->W) + log10((double)c->H)) / log10(0.125) * 0.5);
+  if (c->W > 65535 || c->H > 65535 || c->W < 8 || c->H < 8) return LF_ERR_UNSUPPORTED;   // pixels are packed as row << 16 | column
+  const double logNT = 2.0 * (log10((double)c->W) + log10((double)c->H));
+  {   // ComputeMinLineLength: Round(logNT / -log10(1/8) * 0.5), at least 9
+    const int n = (int)floor(logNT / 0.90308998699194354 * 0.5 + 0.5);
     e.min_len = n < 9 ? 9 : n;
   }
-  e.nmax = 2 * (c->W + c->H);
+  e.lut_size = (c->W + c->H) / 8;
+  e.nmax = 4 * (c->W + c->H) + 8;            // EnumerateRectPoints stops after 4 (|dx| + |dy|) pixels
   e.seg_cap = c->lc.seg_cap;
-  e.chain_cap = 2 * (c->W + c->H) * 8;
-  std::vector<int> kmin((size_t)e.nmax + 1);
-  {   // minimal aligned-pixel count per line length: (w h)^2 B(n, k, 1/8) <= 1 (host libm lgamma / exp / log10)
-    const double p = 0.125, logNT = 2.0 * (log10((double)c->W) + log10((double)c->H));
-    for (int n = 0; n <= e.nmax; n++) {
-      double tail = 0;
-      kmin[(size_t)n] = n + 1;
-      for (int k = n; k >= 0; k--) {
-        tail += exp(lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0) + k * log(p) + (n - k) * log(1 - p));
-        if (log10(tail) + logNT <= 0.0) kmin[(size_t)n] = k; else break;
+  e.anchor_cap = c->W * c->H / 2;
+  e.segtab_cap = c->W * c->H / 10 + 16;
+  std::vector<int> kmin((size_t)e.nmax);
+  {   // NFALUT(size, 0.125, logNT) of the binary for n < size; beyond it the binary evaluates nfa(n, k) >= 0 directly, which is
+      // k >= the smallest such k (the tail decreases with k)
+    const int size = e.lut_size;
+    int j = 1;
+    kmin[0] = 1;
+    for (int i = 1; i < size && i < e.nmax; i++) {
+      kmin[(size_t)i] = size + 1;
+      double ret = ed_nfa(i, j, 0.125, logNT);
+      if (ret < 0) {
+        while (j < i) { j++; ret = ed_nfa(i, j, 0.125, logNT); if (ret >= 0) break; }
+        if (ret < 0) continue;
       }
+      kmin[(size_t)i] = j;
+    }
+    for (int i = (size > 1 ? size : 1); i < e.nmax; i++) {
+      int k = 0;
+      while (k <= i && !(ed_nfa(i, k, 0.125, logNT) >= 0.0)) k++;
+      kmin[(size_t)i] = k;      // (i + 1: never)
     }
   }
-  const size_t B = (size_t)c->maxB, HW = (size_t)c->W * c->H;
+  std::vector<double> lut(1025);
+  for (int i = 0; i <= 1024; i++) lut[(size_t)i] = atan((double)i * (1.0 / 1024.0));   // myAtan2's table
+  const size_t B = (size_t)c->maxB, HW = (size_t)c->W * c->H, WH8 = (size_t)(c->W + c->H) * 8;
   EdBuffers &b = c->eb;
   memset(&b, 0, sizeof b);
   int *d_kmin = nullptr;
+  double *d_lut = nullptr;
   ALLOC(c, b.smooth, B * HW); ALLOC(c, b.D, B * HW); ALLOC(c, b.E, B * HW); ALLOC(c, b.G, B * HW);
-  ALLOC(c, b.akeys, B * LF_ED_ANCHOR_CAP); ALLOC(c, b.nanch, B);
-  ALLOC(c, b.chain, B * 2 * (size_t)e.chain_cap);
-  ALLOC(c, d_kmin, kmin.size());
+  ALLOC(c, b.hist, B * LF_ED_BINS); ALLOC(c, b.anchors, B * (size_t)e.anchor_cap); ALLOC(c, b.nanch, B);
+  ALLOC(c, b.walk, B * HW); ALLOC(c, b.stack, B * (size_t)LF_ED_STACK_CAP * 2); ALLOC(c, b.chains, B * (size_t)(LF_ED_CHAIN_CAP + 1));
+  ALLOC(c, b.chain_nos, B * WH8); ALLOC(c, b.segpix, B * HW); ALLOC(c, b.segtab, B * (size_t)e.segtab_cap * 2);
+  ALLOC(c, b.lines, B * (size_t)LF_ED_LINE_CAP); ALLOC(c, b.rect, B * WH8);
+  ALLOC(c, d_kmin, kmin.size()); ALLOC(c, d_lut, lut.size());
   HIPCHK(c, hipMemcpyAsync(d_kmin, kmin.data(), kmin.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  b.kmin = d_kmin;
+  b.kmin = d_kmin; b.atan_lut = d_lut;
   b.segs = c->lb.segs; b.nsegs = c->lb.nsegs;
   c->ed_ready = true;
   return LF_OK;

@@ -1,34 +1,45 @@
 // lf_edlines.hip -- EDLines for gfx950, batched over frames.  The reference has this detector as a
-// binary only (external/EDLines/libEDLines.a); what is implemented is the detector of the two papers it comes from (Edge
-// Drawing, JVCIR 2012; EDLines, PRL 2011) as stated in oracle/edlines_oracle.c -- parity with the binary is UNPINNED and
-// approximate (tests/test_oracle_edlines.py measures it on the one example the reference ships).
+// binary only (external/EDLines/libEDLines.a); what is implemented is the algorithm of its object code as restated in
+// oracle/edlines_oracle.c (function by function from the disassembly; all 166 rows of the reference's example output
+// reproduced at its 0.01 px resolution).  The kernels are held bit for bit against that file.
 //
-//   k_ed_smooth    cvSmooth(CV_GAUSSIAN, 5x5, sigma 1) on 8-bit: fixed-point taps, BORDER_REPLICATE, LDS tile + halo
-//   k_ed_gradient  Sobel |gx| + |gy|, threshold 36, direction map
-//   k_ed_anchor    anchors (local maxima across the edge by >= 8) -> per-frame key list (gradient descending, scan order)
-//   k_ed_sort      one 1024-thread workgroup per frame: bitonic sort of the 32-bit keys in LDS (128 KB)
-//   k_ed_link      ONE WAVEFRONT PER FRAME, frames in flight are the parallel axis (as the LSD sweep): smart routing from the
-//                  anchors in sorted order, least-squares line fitting along each chain in chain order, Helmholtz validation.
-//                  A dependent chain per frame by nature (every step reads what the previous one marked); fp64 sums in the
-//                  oracle's order.
+//   k_ed_smooth    cvSmooth(CV_GAUSSIAN, 5, 5): taps 1 4 6 4 1 / 16 in 8-bit fixed point, BORDER_REPLICATE, the column pass
+//                  rounded to nearest even except in the last W % 4 columns (OpenCV 2.4's SSE2 / scalar split); LDS tile
+//   k_ed_gradient  ComputeGradientMapByLSD: 2x2 differences, |gx| + |gy|, threshold 11, direction map
+//   k_ed_anchor    anchors (both neighbours across the edge lower by >= 3) marked in the edge map + histogram by gradient
+//   k_ed_sort      SortAnchorsByGradValue, one wavefront per frame: counting sort -- scan of the 1021 bins, then a raster
+//                  pass that ranks the anchors of every 64-pixel batch inside their bin (strongest first, raster order in
+//                  one gradient value)
+//   k_ed_link      ONE LANE PER FRAME, frames in flight are the parallel axis: the anchor walk with its explicit stack and
+//                  chain tree, the longest path as the edge segment, the leftover branches, then SplitSegment2Lines,
+//                  JoinCollinearLines and ValidateLineSegments -- a dependent chain per frame by nature (every step reads
+//                  what the previous one marked); fp64 sums in the oracle's order.
 #include "lf_edlines.h"
 #include "lf_math.h"
+#include <float.h>
 
-#define ED_GRAD_THRESH 36
-#define ED_ANCHOR_THRESH 8
-#define ED_HORIZONTAL 1
-#define ED_VERTICAL 2
+#define ED_GRAD_THRESH 11
+#define ED_ANCHOR_THRESH 3
+#define ED_VERTICAL 1
+#define ED_HORIZONTAL 2
+#define ED_ANCHOR 254
+#define ED_EDGE 255
+#define ED_MIN_PATH 10
 #define ED_LINE_ERROR 1.0
-#define ED_MAX_BAD 5
+#define ED_MAX_DIST 6.0
+#define ED_MAX_ERROR 1.3
+#define ED_PI 3.14159265358979323846
+enum { ED_LEFT = 1, ED_RIGHT = 2, ED_UP = 3, ED_DOWN = 4 };
 
 __device__ __forceinline__ int e_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ __forceinline__ int e_cvround(double v) { return (int)__builtin_rint(v); }
+__device__ __forceinline__ int e_iabs(int v) { return v < 0 ? -v : v; }
 
 #define ES_TW 64
 #define ES_TH 16
 __global__ void __launch_bounds__(256) k_ed_smooth(EdConsts c, EdBuffers b) {
   __shared__ uint8_t s_in[ES_TH + 4][ES_TW + 4];
   __shared__ int s_row[ES_TH + 4][ES_TW];
+  const int sk[5] = {16, 64, 96, 64, 16};
   const int f = blockIdx.z, W = c.W, H = c.H, tid = threadIdx.x;
   const uint8_t *src = b.gray + (size_t)f * b.gray_frame_stride;
   uint8_t *dst = b.smooth + (size_t)f * W * H;
@@ -42,18 +53,19 @@ __global__ void __launch_bounds__(256) k_ed_smooth(EdConsts c, EdBuffers b) {
     const int ty = i / ES_TW, tx = i - ty * ES_TW;
     int s = 0;
 #pragma unroll
-    for (int k = 0; k < 5; k++) s += c.sk[k] * s_in[ty][tx + k];
+    for (int k = 0; k < 5; k++) s += sk[k] * s_in[ty][tx + k];
     s_row[ty][tx] = s;
   }
   __syncthreads();
   for (int i = tid; i < ES_TH * ES_TW; i += 256) {
     const int ty = i / ES_TW, tx = i - ty * ES_TW, x = x0 + tx, y = y0 + ty;
     if (x < W && y < H) {
-      int s = 0;
+      int s = 0, v;
 #pragma unroll
-      for (int k = 0; k < 5; k++) s += c.sk[k] * s_row[ty + k][tx];
-      const int v = (s + (1 << 15)) >> 16;
-      dst[(size_t)y * W + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+      for (int k = 0; k < 5; k++) s += sk[k] * s_row[ty + k][tx];
+      if (x < (W & ~3)) { const int n = s >> 16, r = s & 65535; v = r > 32768 ? n + 1 : (r < 32768 ? n : n + (n & 1)); }
+      else v = (s + (1 << 15)) >> 16;
+      dst[(size_t)y * W + x] = (uint8_t)(v > 255 ? 255 : v);
     }
   }
 }
@@ -64,17 +76,16 @@ __global__ void __launch_bounds__(256) k_ed_gradient(EdConsts c, EdBuffers b) {
   if (i >= W * H) return;
   const int y = i / W, x = i - y * W;
   const uint8_t *s = b.smooth + (size_t)f * W * H;
-  int g = 0, d = 0;
+  int g = ED_GRAD_THRESH - 1, d = 0;
   if (y >= 1 && y < H - 1 && x >= 1 && x < W - 1) {
     const uint8_t *p = s + i;
-    const int c1 = (int)p[W + 1] - p[-W - 1], c2 = (int)p[-W + 1] - p[W - 1];
-    const int gx = abs(c1 + c2 + 2 * ((int)p[1] - p[-1])), gy = abs(c1 - c2 + 2 * ((int)p[W] - p[-W]));
-    const int gg = gx + gy;
-    if (gg >= ED_GRAD_THRESH) { g = gg; d = gx >= gy ? ED_VERTICAL : ED_HORIZONTAL; }
+    const int com1 = (int)p[W + 1] - p[0], com2 = (int)p[1] - p[W];
+    const int gx = e_iabs(com1 + com2), gy = e_iabs(com1 - com2);
+    g = gx + gy;
+    if (g >= ED_GRAD_THRESH) d = gx >= gy ? ED_VERTICAL : ED_HORIZONTAL;
   }
   b.G[(size_t)f * W * H + i] = (int16_t)g;
   b.D[(size_t)f * W * H + i] = (uint8_t)d;
-  b.E[(size_t)f * W * H + i] = 0;
 }
 
 __global__ void __launch_bounds__(256) k_ed_anchor(EdConsts c, EdBuffers b) {
@@ -82,202 +93,609 @@ __global__ void __launch_bounds__(256) k_ed_anchor(EdConsts c, EdBuffers b) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= W * H) return;
   const int y = i / W, x = i - y * W;
-  if (!(y >= 2 && y < H - 2 && x >= 2 && x < W - 2)) return;
   const int16_t *G = b.G + (size_t)f * W * H;
-  const int g = G[i];
-  if (!g) return;
-  bool a;
-  if (b.D[(size_t)f * W * H + i] == ED_VERTICAL) a = g - G[i - 1] >= ED_ANCHOR_THRESH && g - G[i + 1] >= ED_ANCHOR_THRESH;
-  else a = g - G[i - W] >= ED_ANCHOR_THRESH && g - G[i + W] >= ED_ANCHOR_THRESH;
-  if (a) {
-    const int at = atomicAdd(&b.nanch[f], 1);
-    if (at < LF_ED_ANCHOR_CAP) b.akeys[(size_t)f * LF_ED_ANCHOR_CAP + at] = ((unsigned)(4095 - g) << 19) | (unsigned)i;
+  uint8_t e = 0;
+  if (y >= 2 && y < H - 2 && x >= 2 && x < W - 2) {
+    const int g = G[i];
+    if (g >= ED_GRAD_THRESH) {
+      bool a;
+      if (b.D[(size_t)f * W * H + i] == ED_VERTICAL) a = g - G[i + 1] >= ED_ANCHOR_THRESH && g - G[i - 1] >= ED_ANCHOR_THRESH;
+      else a = g - G[i + W] >= ED_ANCHOR_THRESH && g - G[i - W] >= ED_ANCHOR_THRESH;
+      if (a) { e = ED_ANCHOR; atomicAdd(&b.hist[(size_t)f * LF_ED_BINS + g], 1); }
+    }
+  }
+  b.E[(size_t)f * W * H + i] = e;
+}
+
+// SortAnchorsByGradValue as the walk consumes it (from the last entry of the binary's ascending array down): strongest gradient
+// first, raster order inside one gradient value.  base[g] = number of anchors with a larger gradient.
+__global__ void __launch_bounds__(64) k_ed_sort(EdConsts c, EdBuffers b) {
+  __shared__ int base[LF_ED_BINS];
+  const int f = blockIdx.x, lane = threadIdx.x, W = c.W, H = c.H;
+  const int *hist = b.hist + (size_t)f * LF_ED_BINS;
+  if (lane == 0) {
+    int run = 0;
+    for (int g = LF_ED_BINS - 1; g >= 0; g--) { base[g] = run; run += hist[g]; }
+    b.nanch[f] = run;
+  }
+  __syncthreads();
+  const uint8_t *E = b.E + (size_t)f * W * H;
+  const int16_t *G = b.G + (size_t)f * W * H;
+  unsigned *out = b.anchors + (size_t)f * c.anchor_cap;
+  for (int i0 = 0; i0 < W * H; i0 += 64) {
+    const int i = i0 + lane;
+    const bool a = i < W * H && E[i] == ED_ANCHOR;
+    const int g = a ? (int)G[i] : -1;
+    unsigned long long todo = __ballot(a);
+    while (todo) {                                   // one gradient value of the batch at a time, its lanes ranked in lane order
+      const int src = __builtin_ctzll(todo);
+      const int gsel = __shfl(g, src, 64);
+      const unsigned long long m = __ballot(g == gsel);
+      if (g == gsel) {
+        const int pos = base[gsel] + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < c.anchor_cap) out[pos] = (unsigned)i;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      if (lane == src) base[gsel] += __popcll(m);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      todo &= ~m;
+    }
   }
 }
 
-__global__ void __launch_bounds__(1024) k_ed_sort(EdBuffers b) {
-  __shared__ unsigned k[LF_ED_ANCHOR_CAP];
-  const int f = blockIdx.x, tid = threadIdx.x;
-  int n = b.nanch[f];
-  if (n > LF_ED_ANCHOR_CAP) n = LF_ED_ANCHOR_CAP;
-  int n2 = 2;
-  while (n2 < n) n2 <<= 1;
-  unsigned *g = b.akeys + (size_t)f * LF_ED_ANCHOR_CAP;
-  for (int i = tid; i < n2; i += 1024) k[i] = i < n ? g[i] : 0xffffffffu;
-  for (int size = 2; size <= n2; size <<= 1)
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      __syncthreads();
-      for (int t = tid; t < n2 / 2; t += 1024) {
-        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const unsigned a = k[lo], bb = k[hi];
-        if ((a > bb) == up) { k[lo] = bb; k[hi] = a; }
+// ---------------------------------------------------------------------------------------------------- linking + lines
+struct EdFrame {
+  const int16_t *G; const uint8_t *D; uint8_t *E; const uint8_t *img; int img_stride;
+  int W, H;
+  unsigned *walk, *stack, *segpix; EdChainRec *ch; int *chain_nos, *segtab, *rect;
+  EdLine *lines;
+  const int *kmin; const double *atan_lut;
+  int lut_size, nmax;
+};
+__device__ __forceinline__ int e_pr(unsigned p) { return (int)(p >> 16); }
+__device__ __forceinline__ int e_pc(unsigned p) { return (int)(p & 0xffffu); }
+__device__ __forceinline__ unsigned e_mk(int r, int c) { return ((unsigned)r << 16) | (unsigned)c; }
+
+// LongestChain (the binary recurses; a deep tree -- an edge that changes between horizontal and vertical every few pixels --
+// would overflow a device stack): the same post-order evaluation through the parent links, the first child's result kept in
+// the chain record.  Only the chains reachable from `root` are evaluated and pruned, as in the recursion.
+__device__ int e_longest_chain(EdChainRec *ch, int root) {
+  if (root == -1 || ch[root].len == 0) return 0;
+  int cur = root, st = 0, ret = 0;
+  for (;;) {
+    if (st == 0) {
+      const int c0 = ch[cur].child0;
+      if (c0 != -1 && ch[c0].len != 0) { cur = c0; continue; }
+      ret = 0; st = 1;
+    }
+    if (st == 1) {
+      st = 2;
+      ch[cur].tmp = ret;                          // the length below the first child
+      const int c1 = ch[cur].child1;
+      if (c1 != -1 && ch[c1].len != 0) { cur = c1; st = 0; continue; }
+      ret = 0;
+    }
+    {
+      const int len0 = ch[cur].tmp, len1 = ret;
+      int mx;
+      if (len0 >= len1) { mx = len0; ch[cur].child1 = -1; }
+      else { mx = len1; ch[cur].child0 = -1; }
+      ret = ch[cur].len + mx;
+    }
+    if (cur == root) return ret;
+    const int p = ch[cur].parent;
+    st = (ch[p].child0 == cur) ? 1 : 2;     // back in the parent: after its first or its second child
+    cur = p;
+  }
+}
+__device__ int e_retrieve_chain_nos(const EdChainRec *ch, int root, int *nos, int cap) {
+  int count = 0;
+  while (root != -1) {
+    if (count >= cap) return -1;
+    nos[count++] = root;
+    if (ch[root].child0 != -1) root = ch[root].child0;
+    else root = ch[root].child1;
+  }
+  return count;
+}
+
+// pixel q of segment storage as doubles (x = column, y = row)
+__device__ __forceinline__ double e_sx(const unsigned *p, int q) { return (double)e_pc(p[q]); }
+__device__ __forceinline__ double e_sy(const unsigned *p, int q) { return (double)e_pr(p[q]); }
+
+__device__ void e_line_fit_err(const unsigned *p, int count, double *pa, double *pb, double *pe, int *pinvert) {
+  const double S = count;
+  double Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, dx = 0, dy = 0;
+  if (count < 2) return;
+  for (int i = 0; i < count; i++) { Sx += e_sx(p, i); Sy += e_sy(p, i); }
+  const double mx = Sx / count, my = Sy / count;
+  for (int i = 0; i < count; i++) { dx += (e_sx(p, i) - mx) * (e_sx(p, i) - mx); dy += (e_sy(p, i) - my) * (e_sy(p, i) - my); }
+  const int inv = dx < dy;
+  if (inv) { const double d = Sx; Sx = Sy; Sy = d; }
+  *pinvert = inv;
+  for (int i = 0; i < count; i++) { const double x = inv ? e_sy(p, i) : e_sx(p, i), y = inv ? e_sx(p, i) : e_sy(p, i); Sxx += x * x; Sxy += x * y; }
+  const double D = S * Sxx - Sx * Sx;
+  const double a = (Sxx * Sy - Sx * Sxy) / D, bb = (S * Sxy - Sx * Sy) / D;
+  *pa = a; *pb = bb;
+  if (bb == 0.0) {
+    double error = 0;
+    for (int i = 0; i < count; i++) { const double y = inv ? e_sx(p, i) : e_sy(p, i); error += lf_fabs(a - y); }
+    *pe = error / count;
+  } else {
+    double error = 0;
+    for (int i = 0; i < count; i++) {
+      const double x = inv ? e_sy(p, i) : e_sx(p, i), y = inv ? e_sx(p, i) : e_sy(p, i);
+      const double d = -1.0 / bb, cc = y - d * x;
+      const double x2 = (a - cc) / (d - bb), y2 = a + bb * x2;
+      error += (x - x2) * (x - x2) + (y - y2) * (y - y2);
+    }
+    *pe = lf_sqrt(error / count);
+  }
+}
+__device__ void e_line_fit(const unsigned *p, int count, double *pa, double *pb, int invert) {
+  const double S = count;
+  double Sx = 0, Sy = 0, Sxx = 0, Sxy = 0;
+  if (count < 2) return;
+  for (int i = 0; i < count; i++) { Sx += e_sx(p, i); Sy += e_sy(p, i); }
+  if (invert) { const double d = Sx; Sx = Sy; Sy = d; }
+  for (int i = 0; i < count; i++) { const double x = invert ? e_sy(p, i) : e_sx(p, i), y = invert ? e_sx(p, i) : e_sy(p, i); Sxx += x * x; Sxy += x * y; }
+  const double D = S * Sxx - Sx * Sx;
+  *pa = (Sxx * Sy - Sx * Sxy) / D;
+  *pb = (S * Sxy - Sx * Sy) / D;
+}
+__device__ void e_closest_point(double x1, double y1, double a, double b, int invert, double *xo, double *yo) {
+  double x2, y2;
+  if (invert == 0) {
+    if (b == 0) { x2 = x1; y2 = a; }
+    else { const double d = -1.0 / b, c = y1 - d * x1; x2 = (a - c) / (d - b); y2 = a + b * x2; }
+  } else {
+    if (b == 0) { x2 = a; y2 = y1; }
+    else { const double d = -1.0 / b, c = x1 - d * y1; y2 = (a - c) / (d - b); x2 = a + b * y2; }
+  }
+  *xo = x2; *yo = y2;
+}
+__device__ double e_min_distance(double x1, double y1, double a, double b, int invert) {
+  double x2, y2;
+  e_closest_point(x1, y1, a, b, invert, &x2, &y2);
+  return lf_sqrt((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
+}
+__device__ void e_update_line_parameters(EdLine *ls) {
+  const double dx = ls->ex - ls->sx, dy = ls->ey - ls->sy;
+  if (lf_fabs(dx) >= lf_fabs(dy)) {
+    ls->invert = 0;
+    if (lf_fabs(dy) < 1e-3) { ls->b = 0; ls->a = (ls->sy + ls->ey) / 2; }
+    else { ls->b = dy / dx; ls->a = ls->sy - ls->b * ls->sx; }
+  } else {
+    ls->invert = 1;
+    if (lf_fabs(dx) < 1e-3) { ls->b = 0; ls->a = (ls->sx + ls->ex) / 2; }
+    else { ls->b = dx / dy; ls->a = ls->sx - ls->b * ls->sy; }
+  }
+}
+__device__ double e_min_distance_between_two_lines(const EdLine *ls1, const EdLine *ls2) {
+  double dx = ls1->sx - ls2->sx, dy = ls1->sy - ls2->sy, d = lf_sqrt(dx * dx + dy * dy), mn = d;
+  dx = ls1->sx - ls2->ex; dy = ls1->sy - ls2->ey; d = lf_sqrt(dx * dx + dy * dy); if (d < mn) mn = d;
+  dx = ls1->ex - ls2->sx; dy = ls1->ey - ls2->sy; d = lf_sqrt(dx * dx + dy * dy); if (d < mn) mn = d;
+  dx = ls1->ex - ls2->ex; dy = ls1->ey - ls2->ey; d = lf_sqrt(dx * dx + dy * dy); if (d < mn) mn = d;
+  return mn;
+}
+__device__ int e_try_to_join(EdLine *ls1, EdLine *ls2, double max_dist, double max_err) {
+  double dist = e_min_distance_between_two_lines(ls1, ls2), dx, dy, d, mx;
+  const EdLine *shorter = ls1, *longer = ls2;
+  int which;
+  if (dist > max_dist) return 0;
+  dx = ls1->sx - ls1->ex; dy = ls1->sy - ls1->ey; const double prevLen = lf_sqrt(dx * dx + dy * dy);
+  dx = ls2->sx - ls2->ex; dy = ls2->sy - ls2->ey; const double nextLen = lf_sqrt(dx * dx + dy * dy);
+  if (prevLen > nextLen) { shorter = ls2; longer = ls1; }
+  dist = e_min_distance(shorter->sx, shorter->sy, longer->a, longer->b, longer->invert);
+  dist += e_min_distance((shorter->sx + shorter->ex) / 2.0, (shorter->sy + shorter->ey) / 2.0, longer->a, longer->b, longer->invert);
+  dist += e_min_distance(shorter->ex, shorter->ey, longer->a, longer->b, longer->invert);
+  dist /= 3.0;
+  if (dist > max_err) return 0;
+  dx = lf_fabs(ls1->sx - ls2->sx); dy = lf_fabs(ls1->sy - ls2->sy); d = dx + dy; mx = d; which = 1;
+  dx = lf_fabs(ls1->sx - ls2->ex); dy = lf_fabs(ls1->sy - ls2->ey); d = dx + dy; if (d > mx) { mx = d; which = 2; }
+  dx = lf_fabs(ls1->ex - ls2->sx); dy = lf_fabs(ls1->ey - ls2->sy); d = dx + dy; if (d > mx) { mx = d; which = 3; }
+  dx = lf_fabs(ls1->ex - ls2->ex); dy = lf_fabs(ls1->ey - ls2->ey); d = dx + dy; if (d > mx) { mx = d; which = 4; }
+  if (which == 1) { ls1->ex = ls2->sx; ls1->ey = ls2->sy; }
+  else if (which == 2) { ls1->ex = ls2->ex; ls1->ey = ls2->ey; }
+  else if (which == 3) { ls1->sx = ls2->sx; ls1->sy = ls2->sy; }
+  else { ls1->sx = ls1->ex; ls1->sy = ls1->ey; ls1->ex = ls2->ex; ls1->ey = ls2->ey; }
+  if (ls1->firstPixelIndex + ls1->len + 5 >= ls2->firstPixelIndex) ls1->len += ls2->len;
+  else if (ls2->len > ls1->len) { ls1->firstPixelIndex = ls2->firstPixelIndex; ls1->len = ls2->len; }
+  e_update_line_parameters(ls1);
+  return 1;
+}
+
+// ---- validation
+__device__ __forceinline__ int e_check_nfa(const EdFrame &F, int n, int k) { return n < F.nmax ? k >= F.kmin[n] : 0; }
+__device__ double e_line_angle(const EdLine *ls) {
+  double lineAngle;
+  if (ls->invert == 0) lineAngle = lf_atan2(ls->b, 1.0);
+  else lineAngle = lf_atan2(1.0 / ls->b, 1.0);
+  if (lineAngle < 0) lineAngle += ED_PI;
+  return lineAngle;
+}
+__device__ double e_my_atan2(const EdFrame &F, double yy, double xx) {
+  double ay = lf_fabs(yy), ax = lf_fabs(xx);
+  int invert = 0;
+  if (ax < 1e-10) return (ay < 1e-10) ? 0.0 : ED_PI / 2.0;
+  if (ay > ax) { const double t = ay; ay = ax; ax = t; invert = 1; }
+  const double angle = F.atan_lut[(int)(ay / ax * 1024.0)];
+  if ((xx >= 0 && yy >= 0) || (xx < 0 && yy < 0)) return invert ? ED_PI / 2.0 - angle : angle;
+  return invert ? angle + ED_PI / 2.0 : ED_PI - angle;
+}
+__device__ int e_aligned(const EdFrame &F, int r, int c, double lineAngle) {
+  const uint8_t *p = F.img + (size_t)r * F.img_stride + c;
+  const int w = F.img_stride;
+  const double prec = ED_PI / 8.0;
+  const int com1 = (int)p[w + 1] - p[-w - 1], com2 = (int)p[-w + 1] - p[w - 1];
+  const int gx = com1 + com2 + p[1] - p[-1], gy = com1 - com2 + p[w] - p[-w];
+  const double pixelAngle = e_my_atan2(F, (double)gx, (double)-gy), diff = lf_fabs(lineAngle - pixelAngle);
+  return diff <= prec || diff >= ED_PI - prec;
+}
+__device__ int e_enumerate_rect_points(double sx, double sy, double ex, double ey, int *ptsx, int *ptsy, int cap) {
+  double vxTmp[4], vyTmp[4], vx[4], vy[4];
+  const double x1 = sx, y1 = sy, x2 = ex, y2 = ey, width = 2;
+  double dx = x2 - x1, dy = y2 - y1, ys, ye;
+  const double vLen = lf_sqrt(dx * dx + dy * dy);
+  int offset, x, y, noPoints = 0;
+  int maxPoints = 4 * (int)(lf_fabs(sx - ex) + lf_fabs(sy - ey));
+  if (maxPoints > cap) maxPoints = cap;
+  dx = dx / vLen; dy = dy / vLen;
+  vxTmp[0] = x1 - dy * width / 2.0; vyTmp[0] = y1 + dx * width / 2.0;
+  vxTmp[1] = x2 - dy * width / 2.0; vyTmp[1] = y2 + dx * width / 2.0;
+  vxTmp[2] = x2 + dy * width / 2.0; vyTmp[2] = y2 - dx * width / 2.0;
+  vxTmp[3] = x1 + dy * width / 2.0; vyTmp[3] = y1 - dx * width / 2.0;
+  if (x1 < x2 && y1 <= y2) offset = 0;
+  else if (x1 >= x2 && y1 < y2) offset = 1;
+  else if (x1 > x2 && y1 >= y2) offset = 2;
+  else offset = 3;
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    double sxv = vxTmp[0], syv = vyTmp[0];
+#pragma unroll
+    for (int q = 1; q < 4; q++) if (((offset + n) & 3) == q) { sxv = vxTmp[q]; syv = vyTmp[q]; }
+    vx[n] = sxv; vy[n] = syv;
+  }
+  x = (int)__builtin_ceil(vx[0]) - 1;
+  y = (int)__builtin_ceil(vy[0]);
+  ys = ye = -DBL_MAX;
+  while (noPoints < maxPoints) {
+    y++;
+    while (y > ye && x <= vx[2]) {
+      x++;
+      if (x > vx[2]) break;
+      if ((double)x < vx[3]) {
+        if (lf_fabs(vx[0] - vx[3]) <= 0.01) {
+          if (vy[0] < vy[3]) ys = vy[0];
+          else if (vy[0] > vy[3]) ys = vy[3];
+          else ys = vy[0] + (x - vx[0]) * (vy[3] - vy[0]) / (vx[3] - vx[0]);
+        } else ys = vy[0] + (x - vx[0]) * (vy[3] - vy[0]) / (vx[3] - vx[0]);
+      } else {
+        if (lf_fabs(vx[3] - vx[2]) <= 0.01) {
+          if (vy[3] < vy[2]) ys = vy[3];
+          else if (vy[3] > vy[2]) ys = vy[2];
+          else ys = vy[3] + (x - vx[3]) * (vy[2] - vy[3]) / (vx[2] - vx[3]);
+        } else ys = vy[3] + (x - vx[3]) * (vy[2] - vy[3]) / (vx[2] - vx[3]);
+      }
+      if ((double)x < vx[1]) {
+        if (lf_fabs(vx[0] - vx[1]) <= 0.01) {
+          if (vy[0] < vy[1]) ye = vy[1];
+          else if (vy[0] > vy[1]) ye = vy[0];
+          else ye = vy[0] + (x - vx[0]) * (vy[1] - vy[0]) / (vx[1] - vx[0]);
+        } else ye = vy[0] + (x - vx[0]) * (vy[1] - vy[0]) / (vx[1] - vx[0]);
+      } else {
+        if (lf_fabs(vx[1] - vx[2]) <= 0.01) {
+          if (vy[1] < vy[2]) ye = vy[2];
+          else if (vy[1] > vy[2]) ye = vy[1];
+          else ye = vy[1] + (x - vx[1]) * (vy[2] - vy[1]) / (vx[2] - vx[1]);
+        } else ye = vy[1] + (x - vx[1]) * (vy[2] - vy[1]) / (vx[2] - vx[1]);
+      }
+      y = (int)__builtin_ceil(ys);
+    }
+    if (x > vx[2]) break;
+    ptsx[noPoints] = x; ptsy[noPoints] = y; noPoints++;
+  }
+  return noPoints;
+}
+__device__ int e_validate_rect(const EdFrame &F, const EdLine *ls) {
+  const double lineAngle = e_line_angle(ls);
+  const int cap = (F.W + F.H) * 4;
+  int *rx = F.rect, *ry = F.rect + cap;
+  const int noPoints = e_enumerate_rect_points(ls->sx, ls->sy, ls->ex, ls->ey, rx, ry, cap);
+  int count = 0, aligned = 0;
+  for (int i = 0; i < noPoints; i++) {
+    const int r = ry[i], c = rx[i];
+    if (r <= 0 || r >= F.H - 1 || c <= 0 || c >= F.W - 1) continue;
+    count++;
+    if (e_aligned(F, r, c, lineAngle)) aligned++;
+  }
+  return e_check_nfa(F, count, aligned);
+}
+
+// SplitSegment2Lines on the pixels p[0 .. noPixels) of segment segmentNo; appends to F.lines.  Returns the new line count, -1 on overflow.
+__device__ int e_split_segment(const EdFrame &F, const unsigned *p, int noPixels, int segmentNo, int min_line_len, int nlines) {
+  int firstPixelIndex = 0;
+  while (noPixels >= min_line_len) {
+    int valid = 0, lastInvert = 0, index, len;
+    double lastA = 0, lastB = 0, error = 0;
+    while (noPixels >= min_line_len) {
+      e_line_fit_err(p, min_line_len, &lastA, &lastB, &error, &lastInvert);
+      if (error <= 0.5) { valid = 1; break; }
+      noPixels -= 1; p += 1; firstPixelIndex += 1;
+    }
+    if (!valid) return nlines;
+    index = min_line_len;
+    len = min_line_len;
+    while (index < noPixels) {
+      const int startIndex = index;
+      int lastGoodIndex = index - 1, goodPixelCount = 0, badPixelCount = 0;
+      while (index < noPixels) {
+        const double d = e_min_distance(e_sx(p, index), e_sy(p, index), lastA, lastB, lastInvert);
+        if (d <= ED_LINE_ERROR) { lastGoodIndex = index; goodPixelCount++; badPixelCount = 0; }
+        else { badPixelCount++; if (badPixelCount >= 5) break; }
+        index++;
+      }
+      if (goodPixelCount >= 2) {
+        len += lastGoodIndex - startIndex + 1;
+        e_line_fit(p, len, &lastA, &lastB, lastInvert);
+        index = lastGoodIndex + 1;
+      }
+      if (goodPixelCount < 2 || index >= noPixels) {
+        EdLine l;
+        int i0 = 0, i1;
+        while (e_min_distance(e_sx(p, i0), e_sy(p, i0), lastA, lastB, lastInvert) > ED_LINE_ERROR) i0++;
+        e_closest_point(e_sx(p, i0), e_sy(p, i0), lastA, lastB, lastInvert, &l.sx, &l.sy);
+        const int noSkippedPixels = i0;
+        i1 = lastGoodIndex;
+        while (e_min_distance(e_sx(p, i1), e_sy(p, i1), lastA, lastB, lastInvert) > ED_LINE_ERROR) i1--;
+        e_closest_point(e_sx(p, i1), e_sy(p, i1), lastA, lastB, lastInvert, &l.ex, &l.ey);
+        l.a = lastA; l.b = lastB; l.invert = lastInvert; l.pad_ = 0; l.pad2_ = 0; l.segmentNo = segmentNo;
+        l.firstPixelIndex = firstPixelIndex + noSkippedPixels; l.len = i1 - noSkippedPixels + 1;
+        if (nlines >= LF_ED_LINE_CAP) return -1;
+        F.lines[nlines++] = l;
+        len = i1 + 1;
+        break;
       }
     }
-  __syncthreads();
-  for (int i = tid; i < n; i += 1024) g[i] = k[i];
+    noPixels -= len; p += len; firstPixelIndex += len;
+  }
+  return nlines;
 }
 
-// ---------------------------------------------------------------------------------------------------- linking + fitting
-struct EdView { const int16_t *G; const uint8_t *D; uint8_t *E; int W, H; };
-__device__ int e_best3(const EdView &v, int x, int y, int dx, int dy, int *nx, int *ny) {
-  int bg = -1;
-  const int order[3] = {0, -1, 1};
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const int o = order[k], cx = dx ? x + dx : x + o, cy = dy ? y + dy : y + o, g = v.G[(size_t)cy * v.W + cx];
-    if (g > bg) { bg = g; *nx = cx; *ny = cy; }
-  }
-  return bg;
-}
-__device__ int e_walk(const EdView &v, int x, int y, int dir, unsigned *chain, int cap) {
-  int n = 0;
-  while (x >= 1 && y >= 1 && x < v.W - 1 && y < v.H - 1 && v.G[(size_t)y * v.W + x] > 0 && !v.E[(size_t)y * v.W + x]) {
-    int nx = x, ny = y;
-    const int d = v.D[(size_t)y * v.W + x];
-    v.E[(size_t)y * v.W + x] = 1;
-    if (n < cap) chain[n] = ((unsigned)y << 16) | (unsigned)x;
-    n++;
-    if (d == ED_HORIZONTAL) {
-      if (dir > 1) { int ax, ay, bx, by; const int gl = e_best3(v, x, y, -1, 0, &ax, &ay), gr = e_best3(v, x, y, 1, 0, &bx, &by); dir = gr > gl ? 1 : 0; }
-      e_best3(v, x, y, dir == 0 ? -1 : 1, 0, &nx, &ny);
-    } else {
-      if (dir < 2) { int ax, ay, bx, by; const int gu = e_best3(v, x, y, 0, -1, &ax, &ay), gd = e_best3(v, x, y, 0, 1, &bx, &by); dir = gd > gu ? 3 : 2; }
-      e_best3(v, x, y, 0, dir == 2 ? -1 : 1, &nx, &ny);
-    }
-    x = nx; y = ny;
-  }
-  return n;
-}
-// pixel i of the chain reverse(walk 1) + walk 2 without the repeated anchor
-struct EdChain { const unsigned *c1, *c2; int n1; };
-__device__ __forceinline__ void e_px(const EdChain &ch, int i, double *x, double *y) {
-  const unsigned e = i < ch.n1 ? ch.c1[ch.n1 - 1 - i] : ch.c2[i - ch.n1 + 1];
-  *x = (double)(e & 0xffffu); *y = (double)(e >> 16);
-}
-__device__ void e_line_fit(const EdChain &ch, int off, int count, double *a, double *b, int *invert, double *err) {
-  double Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, dx = 0, dy = 0, e = 0;
-  for (int i = 0; i < count; i++) { double x, y; e_px(ch, off + i, &x, &y); Sx += x; Sy += y; }
-  const double mx = Sx / count, my = Sy / count;
-  for (int i = 0; i < count; i++) { double x, y; e_px(ch, off + i, &x, &y); dx += (x - mx) * (x - mx); dy += (y - my) * (y - my); }
-  const int inv = dx < dy;
-  if (inv) { const double t = Sx; Sx = Sy; Sy = t; }
-  for (int i = 0; i < count; i++) { double x, y; e_px(ch, off + i, &x, &y); const double u = inv ? y : x, v = inv ? x : y; Sxx += u * u; Sxy += u * v; }
-  const double D = count * Sxx - Sx * Sx;
-  *a = (Sxx * Sy - Sx * Sxy) / D;
-  *b = (count * Sxy - Sx * Sy) / D;
-  *invert = inv;
-  if (err) {
-    for (int i = 0; i < count; i++) { double x, y; e_px(ch, off + i, &x, &y); const double u = inv ? y : x, v = inv ? x : y; const double r = (*a + *b * u - v); e += r * r / (1 + *b * *b); }
-    *err = lf_sqrt(e / count);
-  }
-}
-__device__ __forceinline__ double e_dist(double px, double py, double a, double b, int invert) {
-  const double u = invert ? py : px, v = invert ? px : py;
-  return lf_fabs(a + b * u - v) / lf_sqrt(1 + b * b);
-}
-__device__ __forceinline__ void e_closest(double px, double py, double a, double b, int invert, double *ox, double *oy) {
-  const double u = invert ? py : px, v = invert ? px : py;
-  const double uu = (u + b * (v - a)) / (1 + b * b), vv = a + b * uu;
-  if (invert) { *ox = vv; *oy = uu; } else { *ox = uu; *oy = vv; }
-}
-__device__ int e_validate(const uint8_t *img, int stride, int w, int h, double sx, double sy, double ex, double ey, const int *kmin, int nmax) {
-  const double dx = ex - sx, dy = ey - sy, len = lf_sqrt(dx * dx + dy * dy), tol = 3.14159265358979323846 / 8;
-  const int steps = (int)(lf_fabs(dx) > lf_fabs(dy) ? lf_fabs(dx) : lf_fabs(dy));
-  int n = 0, k = 0;
-  if (len <= 0 || steps < 1) return 0;
-  const double la = lf_atan2(dy, dx);
-  for (int i = 0; i <= steps; i++) {
-    const int x = e_cvround(sx + dx * i / steps), y = e_cvround(sy + dy * i / steps);
-    if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) continue;
-    const uint8_t *p = img + (size_t)y * stride + x;
-    const int c1 = (int)p[stride + 1] - p[-stride - 1], c2 = (int)p[-stride + 1] - p[stride - 1];
-    const int gx = c1 + c2 + ((int)p[1] - p[-1]), gy = c1 - c2 + ((int)p[stride] - p[-stride]);
-    n++;
-    if (gx == 0 && gy == 0) continue;
-    const double ga = lf_atan2((double)gx, (double)-gy);
-    double d = lf_fabs(ga - la);
-    while (d > 3.14159265358979323846) d = lf_fabs(d - 2 * 3.14159265358979323846);
-    if (d > 3.14159265358979323846 / 2) d = 3.14159265358979323846 - d;
-    if (d <= tol) k++;
-  }
-  if (n > nmax) n = nmax;
-  return k >= kmin[n];
-}
+// append chain cn (forwards from startIndex, or backwards) to the segment under construction, with the clean-up of the binary
+__device__ __forceinline__ bool e_near(unsigned a, unsigned b) { return e_iabs(e_pr(a) - e_pr(b)) <= 1 && e_iabs(e_pc(a) - e_pc(b)) <= 1; }
 
 __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
   const int f = blockIdx.x;
   if ((threadIdx.x & 63u) != 0) return;          // a dependent chain per frame: one lane walks, frames in flight fill the chip
   const int W = c.W, H = c.H;
-  EdView v;
-  v.G = b.G + (size_t)f * W * H; v.D = b.D + (size_t)f * W * H; v.E = b.E + (size_t)f * W * H; v.W = W; v.H = H;
-  const uint8_t *img = b.gray + (size_t)f * b.gray_frame_stride;
-  unsigned *c1 = b.chain + (size_t)f * 2 * c.chain_cap, *c2 = c1 + c.chain_cap;
-  const unsigned *keys = b.akeys + (size_t)f * LF_ED_ANCHOR_CAP;
+  const size_t NP = (size_t)W * H;
+  EdFrame F;
+  F.G = b.G + f * NP; F.D = b.D + f * NP; F.E = b.E + f * NP; F.W = W; F.H = H;
+  F.img = b.gray + (size_t)f * b.gray_frame_stride; F.img_stride = b.gray_row_stride;
+  F.walk = b.walk + f * NP; F.stack = b.stack + (size_t)f * LF_ED_STACK_CAP * 2; F.segpix = b.segpix + f * NP;
+  F.ch = b.chains + (size_t)f * (LF_ED_CHAIN_CAP + 1); F.chain_nos = b.chain_nos + (size_t)f * (W + H) * 8;
+  F.segtab = b.segtab + (size_t)f * c.segtab_cap * 2; F.rect = b.rect + (size_t)f * (W + H) * 8;
+  F.lines = b.lines + (size_t)f * LF_ED_LINE_CAP;
+  F.kmin = b.kmin; F.atan_lut = b.atan_lut; F.lut_size = c.lut_size; F.nmax = c.nmax;
+  const int16_t *G = F.G; const uint8_t *D = F.D; uint8_t *E = F.E;
+  unsigned *pixels = F.walk, *segpix = F.segpix;
+  EdChainRec *chains = F.ch;
+  int *chainNos = F.chain_nos;
+  const unsigned *A = b.anchors + (size_t)f * c.anchor_cap;
   double *segs = b.segs + (size_t)f * c.seg_cap * 5;
-  int na = b.nanch[f];
-  if (na > LF_ED_ANCHOR_CAP) na = LF_ED_ANCHOR_CAP;
-  int nseg = 0;
-  for (int ai = 0; ai < na; ai++) {
-    const int idx = (int)(keys[ai] & 0x7ffffu), x = idx % W, y = idx / W;
-    if (v.E[idx]) continue;
-    int n1, n2;
-    if (v.D[idx] == ED_HORIZONTAL) { n1 = e_walk(v, x, y, 0, c1, c.chain_cap); v.E[idx] = 0; n2 = e_walk(v, x, y, 1, c2, c.chain_cap); }
-    else { n1 = e_walk(v, x, y, 2, c1, c.chain_cap); v.E[idx] = 0; n2 = e_walk(v, x, y, 3, c2, c.chain_cap); }
-    if (n1 > c.chain_cap) n1 = c.chain_cap;
-    if (n2 > c.chain_cap) n2 = c.chain_cap;
-    EdChain ch;
-    ch.c1 = c1; ch.c2 = c2; ch.n1 = n1;
-    const int n = n1 + (n2 > 0 ? n2 - 1 : 0);
-    int off = 0;
-    while (n - off >= c.min_len) {
-      const int left = n - off;
-      int inv = 0, len, index;
-      double a = 0, bb = 0, err = 0;
-      e_line_fit(ch, off, c.min_len, &a, &bb, &inv, &err);
-      if (err > ED_LINE_ERROR) { off++; continue; }
-      len = c.min_len; index = c.min_len;
-      bool done = false;
-      while (!done) {
-        const int start = index;
-        int last_good = index - 1, good = 0, bad = 0;
-        while (index < left) {
-          double px, py;
-          e_px(ch, off + index, &px, &py);
-          if (e_dist(px, py, a, bb, inv) <= ED_LINE_ERROR) { last_good = index; good++; bad = 0; }
-          else if (++bad >= ED_MAX_BAD) break;
-          index++;
-        }
-        if (good >= 2) {
-          len += last_good - start + 1;
-          e_line_fit(ch, off, len, &a, &bb, &inv, nullptr);
-          index = last_good + 1;
-        }
-        if (good < 2 || index >= left) {
-          double sx, sy, ex, ey, px, py;
-          int i0 = 0, i1 = len - 1;
-          for (;;) { e_px(ch, off + i0, &px, &py); if (!(i0 < len - 1 && e_dist(px, py, a, bb, inv) > ED_LINE_ERROR)) break; i0++; }
-          e_closest(px, py, a, bb, inv, &sx, &sy);
-          for (;;) { e_px(ch, off + i1, &px, &py); if (!(i1 > i0 && e_dist(px, py, a, bb, inv) > ED_LINE_ERROR)) break; i1--; }
-          e_closest(px, py, a, bb, inv, &ex, &ey);
-          if (e_validate(img, b.gray_row_stride, W, H, sx, sy, ex, ey, b.kmin, c.nmax)) {
-            if (nseg < c.seg_cap) { double *o = segs + 5 * (size_t)nseg; o[0] = sx; o[1] = sy; o[2] = ex; o[3] = ey; o[4] = 0.0; }
-            nseg++;
+  const int nos_cap = (W + H) * 8;
+  int noAnchors = b.nanch[f];
+  bool overflow = noAnchors > c.anchor_cap;
+  if (overflow) noAnchors = c.anchor_cap;
+  int nsegments = 0, nsegpix = 0;
+  // ---- join the anchors, the one with the greatest gradient first
+  for (int k = 0; k < noAnchors && !overflow; k++) {
+    const int idx = (int)A[k], i = idx / W, j = idx - i * W;
+    int noChains = 1, len = 0, duplicatePixelCount = 0, top = -1;
+    if (E[idx] != ED_ANCHOR) continue;
+    chains[0].len = 0; chains[0].parent = -1; chains[0].dir = 0; chains[0].child0 = chains[0].child1 = -1; chains[0].pix = 0;
+    if (D[idx] == ED_VERTICAL) {
+      ++top; F.stack[2 * top] = e_mk(i, j); F.stack[2 * top + 1] = (0u << 3) | ED_DOWN;
+      ++top; F.stack[2 * top] = e_mk(i, j); F.stack[2 * top + 1] = (0u << 3) | ED_UP;
+    } else {
+      ++top; F.stack[2 * top] = e_mk(i, j); F.stack[2 * top + 1] = (0u << 3) | ED_RIGHT;
+      ++top; F.stack[2 * top] = e_mk(i, j); F.stack[2 * top + 1] = (0u << 3) | ED_LEFT;
+    }
+    while (top >= 0) {
+      int r = e_pr(F.stack[2 * top]), cc = e_pc(F.stack[2 * top]), chainLen = 0;
+      const int dir = (int)(F.stack[2 * top + 1] & 7u), parent = (int)(F.stack[2 * top + 1] >> 3);
+      const bool horizontal = (dir == ED_LEFT || dir == ED_RIGHT);
+      const int step = (dir == ED_LEFT || dir == ED_UP) ? -1 : 1;
+      const bool child0 = (dir == ED_LEFT || dir == ED_UP);
+      bool ended = false;
+      top--;
+      if (noChains > LF_ED_CHAIN_CAP) { overflow = true; break; }
+      if (E[(size_t)r * W + cc] != ED_EDGE) duplicatePixelCount++;
+      chains[noChains].dir = dir; chains[noChains].parent = parent; chains[noChains].child0 = chains[noChains].child1 = -1;
+      chains[noChains].pix = len;
+      pixels[len] = e_mk(r, cc); len++; chainLen++;
+      while (D[(size_t)r * W + cc] == (horizontal ? ED_HORIZONTAL : ED_VERTICAL)) {
+        E[(size_t)r * W + cc] = ED_EDGE;
+        if (horizontal) {
+          if (E[(size_t)(r - 1) * W + cc] == ED_ANCHOR) E[(size_t)(r - 1) * W + cc] = 0;
+          if (E[(size_t)(r + 1) * W + cc] == ED_ANCHOR) E[(size_t)(r + 1) * W + cc] = 0;
+          if (E[(size_t)r * W + cc + step] >= ED_ANCHOR) { cc += step; }
+          else if (E[(size_t)(r + step) * W + cc + step] >= ED_ANCHOR) { r += step; cc += step; }
+          else if (E[(size_t)(r - step) * W + cc + step] >= ED_ANCHOR) { r -= step; cc += step; }
+          else {
+            const int Ag = G[(size_t)(r - 1) * W + cc + step], Bg = G[(size_t)r * W + cc + step], Cg = G[(size_t)(r + 1) * W + cc + step];
+            if (Ag > Bg) { if (Ag > Cg) r--; else r++; }
+            else if (Cg > Bg) r++;
+            cc += step;
           }
-          done = true;
+        } else {
+          if (E[(size_t)r * W + cc - 1] == ED_ANCHOR) E[(size_t)r * W + cc - 1] = 0;
+          if (E[(size_t)r * W + cc + 1] == ED_ANCHOR) E[(size_t)r * W + cc + 1] = 0;
+          if (E[(size_t)(r + step) * W + cc] >= ED_ANCHOR) { r += step; }
+          else if (E[(size_t)(r + step) * W + cc + step] >= ED_ANCHOR) { r += step; cc += step; }
+          else if (E[(size_t)(r + step) * W + cc - step] >= ED_ANCHOR) { r += step; cc -= step; }
+          else {
+            const int Ag = G[(size_t)(r + step) * W + cc - 1], Bg = G[(size_t)(r + step) * W + cc], Cg = G[(size_t)(r + step) * W + cc + 1];
+            if (Ag > Bg) { if (Ag > Cg) cc--; else cc++; }
+            else if (Cg > Bg) cc++;
+            r += step;
+          }
+        }
+        if (E[(size_t)r * W + cc] == ED_EDGE || G[(size_t)r * W + cc] < ED_GRAD_THRESH) {
+          if (chainLen > 0) {
+            chains[noChains].len = chainLen;
+            if (child0) chains[parent].child0 = noChains; else chains[parent].child1 = noChains;
+            noChains++;
+          }
+          ended = true;
+          break;
+        }
+        pixels[len] = e_mk(r, cc); len++; chainLen++;
+        if (len + 2 >= (int)NP) { overflow = true; break; }
+      }
+      if (overflow) break;
+      if (ended) continue;
+      if (top + 2 >= LF_ED_STACK_CAP) { overflow = true; break; }
+      if (horizontal) {
+        ++top; F.stack[2 * top] = e_mk(r, cc); F.stack[2 * top + 1] = ((unsigned)noChains << 3) | ED_DOWN;
+        ++top; F.stack[2 * top] = e_mk(r, cc); F.stack[2 * top + 1] = ((unsigned)noChains << 3) | ED_UP;
+      } else {
+        ++top; F.stack[2 * top] = e_mk(r, cc); F.stack[2 * top + 1] = ((unsigned)noChains << 3) | ED_RIGHT;
+        ++top; F.stack[2 * top] = e_mk(r, cc); F.stack[2 * top + 1] = ((unsigned)noChains << 3) | ED_LEFT;
+      }
+      len--; chainLen--;
+      chains[noChains].len = chainLen;
+      if (child0) chains[parent].child0 = noChains; else chains[parent].child1 = noChains;
+      noChains++;
+    }
+    if (overflow) break;
+    if (len - duplicatePixelCount < ED_MIN_PATH) {
+      for (int q = 0; q < len; q++) E[(size_t)e_pr(pixels[q]) * W + e_pc(pixels[q])] = 0;
+      continue;
+    }
+    if ((size_t)nsegpix + (size_t)len + 2 >= NP) { overflow = true; break; }
+    {
+      unsigned *seg = segpix + nsegpix;
+      int n = 0, totalLen, count;
+      totalLen = e_longest_chain(chains, chains[0].child1);
+      if (totalLen > 0) {
+        count = e_retrieve_chain_nos(chains, chains[0].child1, chainNos, nos_cap);
+        if (count < 0) { overflow = true; break; }
+        for (int q = count - 1; q >= 0; q--) {                 // these chains backwards
+          const int cn = chainNos[q];
+          const unsigned *cp = pixels + chains[cn].pix;
+          unsigned fp = cp[chains[cn].len - 1];
+          int index = n - 2;
+          while (index >= 0) { if (e_near(fp, seg[index])) { n--; index--; } else break; }
+          if (chains[cn].len > 1 && n > 0) { fp = cp[chains[cn].len - 2]; if (e_near(fp, seg[n - 1])) chains[cn].len--; }
+          for (int l = chains[cn].len - 1; l >= 0; l--) seg[n++] = cp[l];
+          chains[cn].len = 0;
         }
       }
-      off += len;
+      totalLen = e_longest_chain(chains, chains[0].child0);
+      if (totalLen > 1) {
+        count = e_retrieve_chain_nos(chains, chains[0].child0, chainNos, nos_cap);
+        if (count < 0) { overflow = true; break; }
+        chains[chainNos[0]].pix++; chains[chainNos[0]].len--;   // the anchor itself is already there
+        for (int q = 0; q < count; q++) {
+          const int cn = chainNos[q];
+          const unsigned *cp = pixels + chains[cn].pix;
+          int index = n - 2, startIndex = 0;
+          while (index >= 0) { if (e_near(cp[0], seg[index])) { n--; index--; } else break; }
+          if (chains[cn].len > 1 && n > 0) { if (e_near(cp[1], seg[n - 1])) startIndex = 1; }
+          for (int l = startIndex; l < chains[cn].len; l++) seg[n++] = cp[l];
+          chains[cn].len = 0;
+        }
+      }
+      if (n > 1 && e_near(seg[1], seg[n - 1])) { seg++; n--; }   // first pixel of a loop
+      if (nsegments >= c.segtab_cap) { overflow = true; break; }
+      F.segtab[2 * nsegments] = (int)(seg - segpix); F.segtab[2 * nsegments + 1] = n; nsegments++;
+      nsegpix = (int)(seg - segpix) + n;
+      for (int q = 2; q < noChains; q++) {       // the rest of the tree: every remaining path of at least ten pixels
+        if (chains[q].len < 2) continue;
+        totalLen = e_longest_chain(chains, q);
+        if (totalLen < 10) continue;
+        count = e_retrieve_chain_nos(chains, q, chainNos, nos_cap);
+        if (count < 0) { overflow = true; break; }
+        seg = segpix + nsegpix; n = 0;
+        for (int qq = 0; qq < count; qq++) {
+          const int cn = chainNos[qq];
+          const unsigned *cp = pixels + chains[cn].pix;
+          int index = n - 2, startIndex = 0;
+          while (index >= 0) { if (e_near(cp[0], seg[index])) { n--; index--; } else break; }
+          if (chains[cn].len > 1 && n > 0) { if (e_near(cp[1], seg[n - 1])) startIndex = 1; }
+          for (int l = startIndex; l < chains[cn].len; l++) seg[n++] = cp[l];
+          chains[cn].len = 0;
+        }
+        if (nsegments >= c.segtab_cap) { overflow = true; break; }
+        F.segtab[2 * nsegments] = nsegpix; F.segtab[2 * nsegments + 1] = n; nsegments++;
+        nsegpix += n;
+      }
     }
   }
-  b.nsegs[f] = nseg;
+  // ---- lines
+  int nlines = 0;
+  for (int s = 0; s < nsegments && !overflow; s++) {
+    nlines = e_split_segment(F, segpix + F.segtab[2 * s], F.segtab[2 * s + 1], s, c.min_len, nlines);
+    if (nlines < 0) { overflow = true; nlines = 0; }
+  }
+  if (!overflow) {   // JoinCollinearLines
+    EdLine *L = F.lines;
+    int lastLineIndex = -1, i = 0;
+    while (i < nlines) {
+      const int segmentNo = L[i].segmentNo;
+      int count = 1;
+      lastLineIndex++;
+      if (lastLineIndex != i) L[lastLineIndex] = L[i];
+      const int firstLineIndex = lastLineIndex;
+      for (int j = i + 1; j < nlines; j++) {
+        if (L[j].segmentNo != segmentNo) break;
+        if (!e_try_to_join(&L[lastLineIndex], &L[j], ED_MAX_DIST, ED_MAX_ERROR)) {
+          lastLineIndex++;
+          if (lastLineIndex != j) L[lastLineIndex] = L[j];
+        }
+        count++;
+      }
+      if (firstLineIndex != lastLineIndex) {
+        if (e_try_to_join(&L[firstLineIndex], &L[lastLineIndex], ED_MAX_DIST, ED_MAX_ERROR)) lastLineIndex--;
+      }
+      i += count;
+    }
+    nlines = lastLineIndex + 1;
+  }
+  int nout = 0;
+  for (int i = 0; i < nlines && !overflow; i++) {   // ValidateLineSegments
+    const EdLine *ls = &F.lines[i];
+    int valid;
+    if (ls->len >= 80) valid = 1;
+    else if (ls->len <= 25) valid = e_validate_rect(F, ls);
+    else {
+      const double lineAngle = e_line_angle(ls);
+      const unsigned *px = segpix + F.segtab[2 * ls->segmentNo] + ls->firstPixelIndex;
+      int aligned = 0, count = 0;
+      for (int q = 0; q < ls->len; q++) {
+        const int r = e_pr(px[q]), cc = e_pc(px[q]);
+        if (r <= 0 || r >= H - 1 || cc <= 0 || cc >= W - 1) continue;
+        count++;
+        if (e_aligned(F, r, cc, lineAngle)) aligned++;
+      }
+      valid = e_check_nfa(F, count, aligned);
+      if (!valid) valid = e_validate_rect(F, ls);
+    }
+    if (valid) {
+      if (nout < c.seg_cap) { double *o = segs + 5 * (size_t)nout; o[0] = ls->sx; o[1] = ls->sy; o[2] = ls->ex; o[3] = ls->ey; o[4] = 0.0; }
+      nout++;
+    }
+  }
+  b.nsegs[f] = overflow ? c.seg_cap + 1 : nout;
 }
 
 void lf_edlines_launch(const EdConsts &c, const EdBuffers &b, int B, hipStream_t st) {
-  (void)hipMemsetAsync(b.nanch, 0, sizeof(int) * (size_t)B, st);
+  (void)hipMemsetAsync(b.hist, 0, sizeof(int) * (size_t)B * LF_ED_BINS, st);
   hipLaunchKernelGGL(k_ed_smooth, dim3((c.W + ES_TW - 1) / ES_TW, (c.H + ES_TH - 1) / ES_TH, B), dim3(256), 0, st, c, b);
   hipLaunchKernelGGL(k_ed_gradient, dim3((c.W * c.H + 255) / 256, B), dim3(256), 0, st, c, b);
   hipLaunchKernelGGL(k_ed_anchor, dim3((c.W * c.H + 255) / 256, B), dim3(256), 0, st, c, b);
-  hipLaunchKernelGGL(k_ed_sort, dim3(B), dim3(1024), 0, st, b);
+  hipLaunchKernelGGL(k_ed_sort, dim3(B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_ed_link, dim3(B), dim3(64), 0, st, c, b);
 }

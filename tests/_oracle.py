@@ -323,7 +323,7 @@ def orb_oracle(gray_u8, depth_f32=None, fast_threshold=20, nfeatures=10000, max_
 
 
 def edlines_oracle(gray_u8, flavour="ref", cap=4096, debug=False):
-    """oracle_edlines: the paper-level EDLines statement.  Returns segments [n,4] (sx, sy, ex, ey)[, smooth, G, D, E]."""
+    """oracle_edlines: the restatement of libEDLines.a's object code.  Returns segments [n,4] (sx, sy, ex, ey)[, smooth, G, D, E]."""
     lib = oracle_lib(flavour)
     g = np.ascontiguousarray(gray_u8, np.uint8)
     h, w = g.shape

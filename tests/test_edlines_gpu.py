@@ -1,5 +1,5 @@
 """GPU parity of the EDLines detector (run with -m gpu): lf_edlines_batch_device vs oracle/edlines_oracle.c bit for bit (the
-oracle is a paper-level statement of the reference's binary-only detector: see there), on the reference's house.pgm example and
+oracle restates the object code of the reference's binary-only detector: see there), on the reference's house.pgm example and
 on synthetic RGB-D frames; and Node::detect3DLines(..., "EDLINES"): the 3D-line stage fed by EDLines segments."""
 import os
 
