@@ -24,6 +24,9 @@
 typedef unsigned long long u64;
 #define F_EPS 1e-10   // lineslam.h:37
 
+#ifndef LF_MLE_SMALL
+#define LF_MLE_SMALL 0           // lines with at most this many support points run four to a wavefront; 16 measured slower again in round 2 (3D stage 80.0 vs 77.3 ms: four independent LM state machines diverge), so: none
+#endif
 __device__ __forceinline__ int f_lane() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ u64 f_lt() { return (1ull << f_lane()) - 1ull; }
 __device__ __forceinline__ double f_rl64(double v, int l) {
@@ -465,7 +468,7 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
       bool kept = have && lid < c.line_cap;
       int nsup = kept ? (int)b.cand_out[((size_t)f * c.cand_cap + s) * LF_CAND_STRIDE + 26] : 0;
       // (a G = 16 variant, four lines per wavefront for <= 16 points, was measured slower: list 0 stays empty)
-      bool small = false, mid = kept && nsup <= 32, large = kept && nsup > 32;
+      bool small = kept && nsup <= LF_MLE_SMALL, mid = kept && nsup > LF_MLE_SMALL && nsup <= 32, large = kept && nsup > 32;
       u64 ms = __ballot(small), mm = __ballot(mid), ml = __ballot(large);
       if (small) list0[n0 + __popcll(ms & f_lt())] = lid;
       if (mid) list1[n1 + __popcll(mm & f_lt())] = lid;
@@ -1135,6 +1138,7 @@ __global__ void __launch_bounds__(64) k_describe(FrontConsts c, FrontBuffers b) 
 
 // ----------------------------------------------------------------------------------------------
 void lf_front_launch_mle(const FrontConsts &c, const FrontBuffers &b, int B, hipStream_t st) {
+  if (LF_MLE_SMALL > 0) hipLaunchKernelGGL((k_mle<16, 16, 0>), dim3((c.line_cap + 3) / 4, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL((k_mle<32, 32, 1>), dim3((c.line_cap + 1) / 2, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL((k_mle<64, MLE_N, 2>), dim3(c.line_cap, B), dim3(64), 0, st, c, b);
 }
@@ -1144,6 +1148,7 @@ void lf_front_launch(const FrontConsts &c, const FrontBuffers &b, int B, hipStre
   hipLaunchKernelGGL(k_line3d, dim3(c.cand_cap, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_records, dim3(B), dim3(64), 0, st, c, b);
 #ifndef LF_EXP_SKIP_MLE   // (throughput experiments only: what the step costs without this stage)
+  if (LF_MLE_SMALL > 0) hipLaunchKernelGGL((k_mle<16, 16, 0>), dim3((c.line_cap + 3) / 4, B), dim3(64), 0, st, c, b);   // 4 lines per wavefront
   hipLaunchKernelGGL((k_mle<32, 32, 1>), dim3((c.line_cap + 1) / 2, B), dim3(64), 0, st, c, b);   // 2 lines per wavefront
   // (pairing the 33..64-point lines as <32, 64> was measured slower: two row slots per lane, select-based pivoting)
   hipLaunchKernelGGL((k_mle<64, MLE_N, 2>), dim3(c.line_cap, B), dim3(64), 0, st, c, b);
