@@ -31,6 +31,29 @@ def test_house_example_bit_exact_vs_oracle(built_lib):
         ctx.close()
 
 
+def test_odd_width_row_stride_and_flat_frames(built_lib):
+    import torch
+    from lineslam_amd import capi
+    rng = np.random.default_rng(5)
+    W, H, stride = 131, 97, 160
+    frames = np.full((3, H, stride), 30, np.uint8)
+    frames[0, 20:70, 25:110] = 210
+    frames[0] = np.clip(frames[0].astype(int) + rng.integers(-6, 7, frames[0].shape), 0, 255).astype(np.uint8)
+    frames[1] = 90                                                   # flat: no segments
+    frames[2] = rng.integers(0, 256, (H, stride)).astype(np.uint8)    # noise: many anchors, short chains
+    ctx = capi.Context(W, H, max_batch=3, params=capi.default_params())
+    try:
+        dg = torch.from_numpy(frames).cuda()
+        ctx.edlines_batch_device(dg.data_ptr(), 3, frame_stride=H * stride, row_stride=stride)
+        for f in range(3):
+            want = O.edlines_oracle(np.ascontiguousarray(frames[f, :, :W]), flavour="lf")
+            got = ctx.lsd_segments(f)
+            assert len(got) == len(want) and (len(want) == 0 or np.array_equal(got[:, :4], want))
+        assert len(ctx.lsd_segments(1)) == 0 and len(ctx.lsd_segments(0)) >= 4
+    finally:
+        ctx.close()
+
+
 def test_detect3d_with_edlines(built_lib):
     import torch
     from lineslam_amd import capi

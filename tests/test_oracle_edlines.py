@@ -42,3 +42,16 @@ def test_flavours_and_simple_shapes():
     want = [(40, 29, 40, 89), (119, 29, 119, 89), (41, 30, 118, 30), (41, 89, 118, 89)]
     for wnt in want:
         assert min(_dist(np.array(wnt, float), s) for s in a) < 2.6
+
+
+def test_edge_cases_flat_small_and_odd_width():
+    assert len(O.edlines_oracle(np.full((64, 80), 90, np.uint8))) == 0          # no gradient: no anchors, no segments
+    assert len(O.edlines_oracle(np.zeros((8, 8), np.uint8))) == 0                # smaller than the anchor border
+    # a width that is not a multiple of four: the last columns take the scalar rounding of the column pass
+    rng = np.random.default_rng(5)
+    img = np.full((97, 131), 30, np.uint8)
+    img[20:70, 25:110] = 210
+    img = np.clip(img.astype(int) + rng.integers(-6, 7, img.shape), 0, 255).astype(np.uint8)
+    a, b = O.edlines_oracle(img, flavour="ref"), O.edlines_oracle(img, flavour="lf")
+    assert len(a) >= 4 and np.array_equal(a, b)
+    assert a.min() >= 0 and a[:, [0, 2]].max() <= 131 and a[:, [1, 3]].max() <= 97
