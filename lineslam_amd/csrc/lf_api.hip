@@ -58,6 +58,7 @@ struct lf_ctx {
   double *d_descdiff = nullptr;      // lf_pair_get_descdiff scratch (line_cap^2 doubles), allocated on first use
   // ---- EDLines (buffers allocated on first use)
   bool ed_ready = false;
+  std::vector<int> h_xslots;    // the key-frame slot list last uploaded for the exchange
   EdConsts ec;
   EdBuffers eb;
   // ---- ORB extractor (buffers allocated on first use)
@@ -1416,8 +1417,13 @@ int lf_allgather_keyframes(lf_ctx *c, const int32_t *kf_slots, int n_kf, uint64_
   if (n_kf > c->comm_max_kf) return LF_ERR_CAPACITY;
   for (int k = 0; k < n_kf; k++) if (kf_slots[k] < 0 || kf_slots[k] >= c->last_batch) return LF_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemcpyAsync(c->d_xslots, kf_slots, sizeof(int) * (size_t)n_kf, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));          // (the caller's slot list may be a temporary; 4 n_kf bytes)
+  if (c->h_xslots.size() != (size_t)n_kf || memcmp(c->h_xslots.data(), kf_slots, sizeof(int) * (size_t)n_kf) != 0) {
+    // a new slot list: upload it and wait (the caller's array may be a temporary).  The same list again -- the usual case,
+    // every step of a run -- costs nothing and, above all, no host synchronisation: the exchange stays asynchronous.
+    c->h_xslots.assign(kf_slots, kf_slots + n_kf);
+    HIPCHK(c, hipMemcpyAsync(c->d_xslots, c->h_xslots.data(), sizeof(int) * (size_t)n_kf, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   const int L = c->fc.line_cap;
   hipLaunchKernelGGL(k_pack_keyframes, dim3(16, n_kf), dim3(256), 0, c->stream, (const lf_line_record *)c->fb.recs, (const int *)c->fb.nlines,
                      (const uint64_t *)c->d_frame_ids, L, (const int *)c->d_xslots, id_offset, c->d_xsend);
