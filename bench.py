@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--exchange", choices=("lib", "torch"), default="lib",
                     help="carrier of the key-frame all-gather with N > 1: lf_allgather_keyframes (RCCL inside liblinefront.so) "
                          "or the same payload through torch.distributed (lineslam_amd/parallel.py)")
+    ap.add_argument("--detector", choices=("lsd", "edlines"), default="lsd",
+                    help="line_detect_algorithm of the reference: LSD (its default, the headline configuration) or EDLINES")
     ap.add_argument("--points", action="store_true",
                     help="BASELINE configs[2] instead of configs[1]: fused point + line odometry -- projectTo3D, Hamming "
                          "feature matching and the hybrid RANSAC / LM solver on the key points of the HIP ORB extractor; "
@@ -177,6 +179,8 @@ def main():
     if dist_on:
         dist.barrier()
     P = capi.default_params(launch=not a.default_params)
+    if a.detector == "edlines":
+        P.line_detector = 1
     F = a.frames
     gray, depth, poses = synth.sequence(F, seed=2 + rank, n_unique=a.unique)
     nfl = max(1, a.inflight)
@@ -313,7 +317,7 @@ def main():
         point_stats = {"point_matches_per_pair": float(np.mean([r.n_point_matches for r in res])),
                        "point_inliers_per_pair": float(np.mean([r.n_point_inliers for r in res])),
                        "line_inliers_per_pair": float(np.mean([r.n_inliers for r in res]))} if a.points else None
-        sw = float(np.mean(sweep_ms))
+        sw = max(float(np.mean(sweep_ms)), 1e-6)          # (--detector edlines: there is no sweep; the roofline object is about LSD)
         nlines = int(np.mean([len(ctx.frame_lines(k)) for k in range(0, F, max(1, F // 16))]))
         traffic, traffic_src, valu = None, None, None
         tpath = _latest_profile("_sweep_pmc.json")
@@ -346,8 +350,9 @@ def main():
                                     "below + ORB extraction (600 key points), projectTo3D, Hamming feature matching, hybrid RANSAC / LM" % F)
                        if a.points else
                                    "TUM fr3/cabinet-length sequence (%d frames, 640x480), lines-only odometry: "
-                                   "LSD + 3D line fit + MSLD + MLE per frame, line matching + 3-line RANSAC + LM "
-                                   "pose vs predecessor; synthetic seeded RGB-D (lineslam_amd/synth.py)" % F,
+                                   "%s + 3D line fit + MSLD + MLE per frame, line matching + 3-line RANSAC + LM "
+                                   "pose vs predecessor; synthetic seeded RGB-D (lineslam_amd/synth.py)" %
+                                   (F, "EDLines (line_detect_algorithm = EDLINES, not the headline configuration)" if a.detector == "edlines" else "LSD"),
                        "frames_per_gpu": F, "params": "ParameterServer defaults" if a.default_params else "launch/lineslam.launch (lsd_angle_thres 40, min_matches 10)",
                        "lines_per_frame": nlines, "passes_in_flight": nfl,
                        "parallelism": "frames in flight: one wavefront per frame (LSD sweep), "
