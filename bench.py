@@ -378,7 +378,9 @@ def main():
             "quality": {"valid_pairs": int(valid.sum()), "pairs": int(len(valid)), "pairs_over_a_capacity": n_over,
                         "ate_rmse_m_vs_ground_truth": ate.ate_rmse(est[:, :3, 3], gt[:, :3, 3])},
         }
-        if not a.no_cpu:
+        if a.detector == "edlines" and not a.no_cpu:
+            print("bench: --detector edlines: the cpu_baseline leg times the LSD configuration only; skipped", file=sys.stderr)
+        if not a.no_cpu and a.detector != "edlines":
             ncpu = a.cpu_frames or max(16, min(F, 6 * (os.cpu_count() or 1)))
             out["cpu_baseline"] = cpu_baseline(gray, depth, P, ncpu)   # (lines-only CPU path, also next to --points)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
