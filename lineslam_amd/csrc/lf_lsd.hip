@@ -34,6 +34,16 @@ typedef double lf_d2 __attribute__((ext_vector_type(2)));
 
 // ----------------------------------------------------------------------------------------------
 // small wave-level helpers (wave = 64 lanes on gfx950)
+// work counters of the sweeps (regions grown, window steps, rectangle evaluations, pixels): for tools/lsd_perf.py and
+// tools/lsd_mw_stats.py only -- build with LF_EXTRA_CFLAGS=-DLF_SWEEP_STATS=1; off, their scalar registers and adds are gone
+#ifndef LF_SWEEP_STATS
+#define LF_SWEEP_STATS 0
+#endif
+#if LF_SWEEP_STATS
+#define LF_STAT(x) x
+#else
+#define LF_STAT(x) do { } while (0)
+#endif
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 __device__ __forceinline__ double rl64(double v, int l) {   // value of lane l (l wave-uniform)
@@ -374,7 +384,7 @@ __device__ int d_region_grow(const FV &f, int sx, int sy, double prec, double co
   for (;;) {
     const int total = size * 9;
     if (cur >= total || full) break;
-    (*n_steps)++;
+    LF_STAT((*n_steps)++);
     int slot = cur + lane;
     bool act = slot < total;
     int pi = slot / 9, nb = slot - pi * 9;
@@ -770,7 +780,7 @@ template <class FV>
 __device__ double d_rect_nfa(const FV &f, const Rect &r, double logNT, u64 *n_px) {
   int pts, alg;
   d_rect_count<1>(f, r, &pts, &alg);
-  *n_px += (u64)pts;
+  LF_STAT(*n_px += (u64)pts);
   return d_nfa(f, pts, alg, r.p, r.plev, logNT);
 }
 // rect_nfa of the five rectangles r with p/2, p/4 .. p/32 (same geometry): one counting pass, the nfa values of small
@@ -779,7 +789,7 @@ template <class FV>
 __device__ void d_rect_nfa_finer5(const FV &f, const Rect &r, double logNT, u64 *n_px, double *out) {
   int pts, alg[5];
   d_rect_count<5>(f, r, &pts, alg);
-  *n_px += 5ull * (u64)pts;
+  LF_STAT(*n_px += 5ull * (u64)pts);
   if (pts < LF_NFA_TAB_N && f.nfa_tab && pts > 0) {
     const int k = f.lane < 5 ? f.lane : 4;
     int a = k == 0 ? alg[0] : (k == 1 ? alg[1] : (k == 2 ? alg[2] : (k == 3 ? alg[3] : alg[4])));
@@ -799,7 +809,7 @@ __device__ double d_rect_improve(const FV &f, Rect *rec, double logNT, double ep
   Rect r;
   const double delta = 0.5, delta_2 = delta / 2.0;
   double log_nfa, log_nfa_new;
-  ++*n_nfa;
+  LF_STAT(++*n_nfa);
   log_nfa = d_rect_nfa(f, *rec, logNT, n_px);
   if (log_nfa > eps) return log_nfa;
   r = *rec;
@@ -809,7 +819,7 @@ __device__ double d_rect_improve(const FV &f, Rect *rec, double logNT, double ep
     for (int n = 0; n < 5; n++) {   // finer precisions
       r.p /= 2.0; r.plev++;
       r.prec = r.p * LF_PI;
-      ++*n_nfa;
+      LF_STAT(++*n_nfa);
       log_nfa_new = lv[n];
       if (log_nfa_new > log_nfa) { log_nfa = log_nfa_new; *rec = r; }
     }
@@ -819,7 +829,7 @@ __device__ double d_rect_improve(const FV &f, Rect *rec, double logNT, double ep
   for (int n = 0; n < 5; n++) {   // reduce width
     if ((r.width - delta) >= 0.5) {
       r.width -= delta;
-      ++*n_nfa;
+      LF_STAT(++*n_nfa);
       log_nfa_new = d_rect_nfa(f, r, logNT, n_px);
       if (log_nfa_new > log_nfa) { *rec = r; log_nfa = log_nfa_new; }
     }
@@ -833,7 +843,7 @@ __device__ double d_rect_improve(const FV &f, Rect *rec, double logNT, double ep
       r.x2 += -r.dy * delta_2;
       r.y2 += r.dx * delta_2;
       r.width -= delta;
-      ++*n_nfa;
+      LF_STAT(++*n_nfa);
       log_nfa_new = d_rect_nfa(f, r, logNT, n_px);
       if (log_nfa_new > log_nfa) { *rec = r; log_nfa = log_nfa_new; }
     }
@@ -847,7 +857,7 @@ __device__ double d_rect_improve(const FV &f, Rect *rec, double logNT, double ep
       r.x2 -= -r.dy * delta_2;
       r.y2 -= r.dx * delta_2;
       r.width -= delta;
-      ++*n_nfa;
+      LF_STAT(++*n_nfa);
       log_nfa_new = d_rect_nfa(f, r, logNT, n_px);
       if (log_nfa_new > log_nfa) { *rec = r; log_nfa = log_nfa_new; }
     }
@@ -860,7 +870,7 @@ __device__ double d_rect_improve(const FV &f, Rect *rec, double logNT, double ep
     for (int n = 0; n < 5; n++) {   // even finer precisions
       r.p /= 2.0; r.plev++;
       r.prec = r.p * LF_PI;
-      ++*n_nfa;
+      LF_STAT(++*n_nfa);
       log_nfa_new = lv[n];
       if (log_nfa_new > log_nfa) { log_nfa = log_nfa_new; *rec = r; }
     }
@@ -1047,11 +1057,11 @@ __global__ void __launch_bounds__(64, 3) k_lsd_sweep(LsdConsts c, const LsdConst
     wlast = L;
     int sx = sa % c.N, sy = sa / c.N;
     double reg_angle;
-    ++n_grow;
+    LF_STAT(++n_grow);
     PROF(0);
     int reg_size = d_region_grow(f, sx, sy, c.prec, c.cos_prec, &reg_angle, &n_steps);
     PROF(1);
-    n_regpx += (u64)reg_size;
+    LF_STAT(n_regpx += (u64)reg_size);
     if (reg_size < c.min_reg_size) continue;
     Rect rec;
     d_region2rect(f, reg_size, reg_angle, c.prec, c.p, 0, &rec);

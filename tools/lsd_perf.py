@@ -1,4 +1,5 @@
-"""Quick LSD-stage timing on the GPU box: python tools/lsd_perf.py [B] [ang]"""
+"""Quick LSD-stage timing on the GPU box: python tools/lsd_perf.py [B] [ang]
+(the work counters printed below need a build with LF_EXTRA_CFLAGS=-DLF_SWEEP_STATS=1; -DLF_SWEEP_PROFILE adds the phase times)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
