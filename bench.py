@@ -213,6 +213,19 @@ def main():
     exch, carrier = {}, a.exchange
     if dist_on:
         # node ids of different ranks far apart (loop closures, never "adjacent"); ONE all-gather per step and context
+        if carrier == "lib" and world > 1:
+            # every rank must take the same carrier: agree first on whether the library can bind RCCL at all
+            try:
+                capi.comm_unique_id()
+                have = 1
+            except capi.LinefrontError:
+                have = 0
+            flag = torch.tensor([have], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if rank == 0:
+                    print("bench: library exchange unavailable on some rank: torch carrier", file=sys.stderr)
+                carrier = "torch"
         if carrier == "lib":
             try:
                 uid = [capi.comm_unique_id() if rank == 0 else None]
