@@ -24,6 +24,9 @@
 typedef unsigned long long u64;
 #define F_EPS 1e-10   // lineslam.h:37
 
+#ifndef LF_MLE_PAIR64
+#define LF_MLE_PAIR64 0    // 33..64-point lines two per wavefront (two rows per lane): measured slower again in round 3 (19.6 + 11.0 ms vs 20.8 ms)
+#endif
 #ifndef LF_MLE_SMALL
 #define LF_MLE_SMALL 0           // lines with at most this many support points run four to a wavefront; 16 measured slower again in round 2 (3D stage 80.0 vs 77.3 ms: four independent LM state machines diverge), so: none
 #endif
@@ -468,7 +471,11 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
       bool kept = have && lid < c.line_cap;
       int nsup = kept ? (int)b.cand_out[((size_t)f * c.cand_cap + s) * LF_CAND_STRIDE + 26] : 0;
       // (a G = 16 variant, four lines per wavefront for <= 16 points, was measured slower: list 0 stays empty)
+#if LF_MLE_PAIR64   // list 0: 33 .. 64 support points, two lines per wavefront with two rows per lane
+      bool small = kept && nsup > 32 && nsup <= 64, mid = kept && nsup <= 32, large = kept && nsup > 64;
+#else
       bool small = kept && nsup <= LF_MLE_SMALL, mid = kept && nsup > LF_MLE_SMALL && nsup <= 32, large = kept && nsup > 32;
+#endif
       u64 ms = __ballot(small), mm = __ballot(mid), ml = __ballot(large);
       if (small) list0[n0 + __popcll(ms & f_lt())] = lid;
       if (mid) list1[n1 + __popcll(mm & f_lt())] = lid;
@@ -545,6 +552,85 @@ template <int G> __device__ __forceinline__ void g_argmax(double &v, int &i) {
   }
 }
 
+// ---- 6 x 6 linear systems with ONE COLUMN PER LANE.  Group lane j < 6 holds column j of the matrix in c[0..5], group
+// lanes 6 .. 6 + NRHS - 1 one right-hand side each, the other lanes zeros.  Per elimination step the pivot column is
+// broadcast to the group (readlane for a whole wavefront, ds_bpermute for half-wavefront groups), the pivot search, the
+// reciprocal and the multipliers are then the same in every lane, and each lane applies the row operations to its own
+// column: c[i] -= f_i * c[k].  Every entry sees exactly the operations of the sequential elimination (lf_linalg.h), so the
+// results are bit-equal -- at 6 doubles of state per lane instead of the 42 (or 54) of a replicated A | B.
+//   NETLIB = true : levmar's AX_EQ_B_LU, LAPACK order (lf_lu6: dgetf2 + dgetrs -- the back-substitution walks the columns
+//                   from the last one, subtracting x_k U(i,k) from the rows above, and DIVIDES by the diagonal)
+//   NETLIB = false: cv::Mat::inv's LU (lf_solve6: row-oriented back-substitution, multiplication by the reciprocal pivot)
+// Returns 0 (uniform in the group) for a singular matrix; the solutions replace the right-hand sides.
+template <int G, int NRHS, bool NETLIB>
+__device__ __forceinline__ int f_lu6_cols(double (&c)[6], const MleGroup &g) {
+  int ok = 1;
+  double dg[6];                                  // NETLIB: the pivots; else their reciprocals
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double col[6];
+#pragma unroll
+    for (int i = k; i < 6; i++) col[i] = g_get<G>(c[i], g, k);
+    int piv = k;
+    double big = lf_fabs(col[k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const double v = lf_fabs(col[i]);
+      if (v > big) { big = v; piv = i; }
+    }
+    if constexpr (G == 64) piv = __builtin_amdgcn_readfirstlane(piv);
+    if (!(big > 0.0)) ok = 0;
+    if (LF_ANY(piv != k)) {
+#pragma unroll
+      for (int i = k + 1; i < 6; i++) {
+        const bool sw = (i == piv);
+        const double a = c[k], b2 = c[i], ca = col[k], cb = col[i];
+        c[k] = sw ? b2 : a; c[i] = sw ? a : b2;
+        col[k] = sw ? cb : ca; col[i] = sw ? ca : cb;
+      }
+    }
+    const double pv = col[k];
+    if (NETLIB && LF_ANY(!(big >= LF_LU_SFMIN))) {     // dgetf2: a pivot below sfmin divides instead (never on this path's matrices)
+      const bool tiny = !(big >= LF_LU_SFMIN);
+      const double r = 1.0 / pv;
+#pragma unroll
+      for (int i = k + 1; i < 6; i++) { const double f = tiny ? col[i] / pv : col[i] * r; c[i] -= f * c[k]; }
+      dg[k] = pv;
+    } else {
+      const double r = 1.0 / pv;
+#pragma unroll
+      for (int i = k + 1; i < 6; i++) { const double f = col[i] * r; c[i] -= f * c[k]; }
+      dg[k] = NETLIB ? pv : r;
+    }
+  }
+  if constexpr (NETLIB) {
+    // (column oriented: step k changes the rows above k -- only in the right-hand-side lanes, the matrix lanes must
+    // keep U for the steps that follow)
+    const bool rhs = g.glane >= 6;
+#pragma unroll
+    for (int k = 5; k >= 0; k--) {
+      double u[6];
+#pragma unroll
+      for (int i = 0; i < k; i++) u[i] = g_get<G>(c[i], g, k);
+      if (rhs) {
+        const double x = c[k] / dg[k];
+        c[k] = x;
+#pragma unroll
+        for (int i = 0; i < k; i++) c[i] -= x * u[i];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+      double s = c[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; k++) { const double u = g_get<G>(c[i], g, k); s -= u * c[k]; }
+      c[i] = s * dg[i];
+    }
+  }
+  return ok;
+}
+
 // costFun_MLEstimateLine3d (utils.cpp:954-978): residuals of the rows this lane owns, in registers
 template <int G, int RW>
 __device__ __forceinline__ void f_mle_cost(const MState &S, const MleGroup &g, int n, int e1, int e2, const double *ci1,
@@ -594,9 +680,9 @@ __device__ __forceinline__ double f_ordered_sumsq(const MState &S, const double 
   return s0 + s1 + s2 + s3;
 }
 
-#ifdef LF_MLE_PROFILE   // LF_EXTRA_CFLAGS=-DLF_MLE_PROFILE: s_memtime per LM phase of line 7 of frame 0, printed
+#ifdef LF_MLE_PROFILE   // LF_EXTRA_CFLAGS=-DLF_MLE_PROFILE=32 (or 64: the lane-group width): s_memtime per LM phase of work item 7 of frame 0, printed
 __device__ unsigned long long g_mprof[16];
-#define MT(k) do { unsigned long long tn = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 7 && blockIdx.y == 0 && f_lane() == 0 && G == 64) g_mprof[k] += tn - tprev; tprev = tn; } while (0)
+#define MT(k) do { unsigned long long tn = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 7 && blockIdx.y == 0 && f_lane() == 0 && G == LF_MLE_PROFILE) g_mprof[k] += tn - tprev; tprev = tn; } while (0)
 #else
 #define MT(k) do { } while (0)
 #endif
@@ -713,18 +799,21 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
       mu = tau * tmp;
     }
     int issolved;
-    {   // the augmented normal equations (J^T J + mu I) Dp = J^T e: symmetric fill from the 21 published sums
-      double A[36], Bv[6];
+    {   // the augmented normal equations (J^T J + mu I) Dp = J^T e (AX_EQ_B_LU, lm_core.c:706): group lane j < 6 takes
+        // column j from the 21 published sums (symmetric fill), group lane 6 takes J^T e
+      double cl[6];
+      const int jc = (lane < 6) ? lane : 5;
 #pragma unroll
-      for (int i = 0; i < 6; i++)
+      for (int i = 0; i < 6; i++) {
+        const int hi = (i > jc) ? i : jc, lo = (i > jc) ? jc : i;
+        double v = S.accs[hi * (hi + 1) / 2 + lo];
+        if (i == lane) v += mu;
+        if (lane >= 6) v = (lane == 6) ? jacTe[i] : 0.0;
+        cl[i] = v;
+      }
+      issolved = f_lu6_cols<G, 1, true>(cl, g);
 #pragma unroll
-        for (int j = 0; j <= i; j++) { double v = S.accs[i * (i + 1) / 2 + j]; if (i == j) v += mu; A[i * m + j] = v; A[j * m + i] = v; }
-#pragma unroll
-      for (int i = 0; i < 6; i++) Bv[i] = jacTe[i];
-      if constexpr (G == 64) issolved = lf_solve6_u(A, Bv, 1);   // one system per wavefront: scalar pivot branches
-      else issolved = lf_solve6(A, Bv, 1);
-#pragma unroll
-      for (int i = 0; i < 6; i++) Dp[i] = Bv[i];
+      for (int i = 0; i < 6; i++) Dp[i] = g_get<G>(cl[i], g, 6);
     }
     MT(4);
     if (issolved) {
@@ -784,7 +873,7 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
   *stop_out = stop;
 #ifdef LF_MLE_PROFILE
   MT(8);
-  if (blockIdx.x == 7 && blockIdx.y == 0 && lane == 0 && G == 64) {
+  if (blockIdx.x == 7 && blockIdx.y == 0 && f_lane() == 0 && G == LF_MLE_PROFILE) {
     printf("k_mle prof (kcycles) n=%d iters=%d: loop/tail %.1f fdjac %.1f acc %.1f gather %.1f solve %.1f cost %.1f sumsq %.1f broyden %.1f end %.1f\n", n, k,
            g_mprof[0] / 1e3, g_mprof[1] / 1e3, g_mprof[2] / 1e3, g_mprof[3] / 1e3, g_mprof[4] / 1e3, g_mprof[5] / 1e3, g_mprof[6] / 1e3, g_mprof[7] / 1e3, g_mprof[8] / 1e3);
     for (int i = 0; i < 16; i++) g_mprof[i] = 0;
@@ -916,26 +1005,22 @@ __device__ __forceinline__ void f_mle_line(const FrontConsts &c, const FrontBuff
   // cov = H^-1 by elimination with the identity as right-hand sides; the record keeps its upper-left and lower-right
   // 3x3 blocks only (covA, covB), and the columns of an inverse are independent: two eliminations with three columns
   // each (the same operations on the columns that are kept) instead of one with six -- a third fewer live registers.
-  int inv_ok = 1;
+  int inv_ok;
+  {   // one column per lane: H in group lanes 0..5, the six columns of the identity in lanes 6..11 (cv::Mat::inv's LU)
+    double cl[6];
+    const int jc = (lane < 6) ? lane : 5;
 #pragma unroll
-  for (int half = 0; half < 2; half++) {
-    double Hm[36], Bm[18];
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-#pragma unroll
-      for (int l = 0; l <= k; l++) { double v = S.accs[k * (k + 1) / 2 + l]; Hm[k * 6 + l] = v; Hm[l * 6 + k] = v; }
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) Bm[i * 3 + j] = (i == j + 3 * half) ? 1.0 : 0.0;
-    int ok;
-    if constexpr (G == 64) ok = lf_solve6_u(Hm, Bm, 3);   // one line per wavefront: scalar pivot branches
-    else ok = lf_solve6(Hm, Bm, 3);
-    if (!ok) inv_ok = 0;
+    for (int i = 0; i < 6; i++) {
+      const int hi = (i > jc) ? i : jc, lo = (i > jc) ? jc : i;
+      double v = S.accs[hi * (hi + 1) / 2 + lo];
+      if (lane >= 6) v = (lane - 6 == i) ? 1.0 : 0.0;
+      cl[i] = v;
+    }
+    inv_ok = f_lu6_cols<G, 6, false>(cl, g);
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
-      for (int q = 0; q < 3; q++) { if (half == 0) covA[3 * r + q] = Bm[r * 3 + q]; else covB[3 * r + q] = Bm[(r + 3) * 3 + q]; }
+      for (int q = 0; q < 3; q++) { covA[3 * r + q] = g_get<G>(cl[r], g, 6 + q); covB[3 * r + q] = g_get<G>(cl[3 + r], g, 9 + q); }
   }
   g_order<G>();
   if (!inv_ok) {
@@ -961,8 +1046,11 @@ __device__ __forceinline__ void f_mle_line(const FrontConsts &c, const FrontBuff
   }
 }
 
+#ifndef LF_MLE_WAVES
+#define LF_MLE_WAVES 3           // wavefronts per SIMD the register allocation of k_mle aims at
+#endif
 template <int G, int RW, int WHICH>
-__global__ void __launch_bounds__(64, 2) k_mle(FrontConsts c, FrontBuffers b) {
+__global__ void __launch_bounds__(64, LF_MLE_WAVES) k_mle(FrontConsts c, FrontBuffers b) {
   typedef MleCfgT<G, RW> Cfg;
   __shared__ double lds_rows[Cfg::NG][Cfg::ROWS * MLE_ROW_DOUBLES + MLE_ACC_DOUBLES];
   const int f = blockIdx.y, wl = f_lane();
@@ -1137,21 +1225,23 @@ __global__ void __launch_bounds__(64) k_describe(FrontConsts c, FrontBuffers b) 
 }
 
 // ----------------------------------------------------------------------------------------------
-void lf_front_launch_mle(const FrontConsts &c, const FrontBuffers &b, int B, hipStream_t st) {
-  if (LF_MLE_SMALL > 0) hipLaunchKernelGGL((k_mle<16, 16, 0>), dim3((c.line_cap + 3) / 4, B), dim3(64), 0, st, c, b);
-  hipLaunchKernelGGL((k_mle<32, 32, 1>), dim3((c.line_cap + 1) / 2, B), dim3(64), 0, st, c, b);
+static void launch_mle_kernels(const FrontConsts &c, const FrontBuffers &b, int B, hipStream_t st) {
+#if LF_MLE_PAIR64
+  hipLaunchKernelGGL((k_mle<32, 64, 0>), dim3((c.line_cap + 1) / 2, B), dim3(64), 0, st, c, b);   // 33..64 points: 2 lines per wavefront
+#else
+  if (LF_MLE_SMALL > 0) hipLaunchKernelGGL((k_mle<16, 16, 0>), dim3((c.line_cap + 3) / 4, B), dim3(64), 0, st, c, b);   // 4 lines per wavefront
+#endif
+  hipLaunchKernelGGL((k_mle<32, 32, 1>), dim3((c.line_cap + 1) / 2, B), dim3(64), 0, st, c, b);   // <= 32 points: 2 lines per wavefront
   hipLaunchKernelGGL((k_mle<64, MLE_N, 2>), dim3(c.line_cap, B), dim3(64), 0, st, c, b);
 }
+void lf_front_launch_mle(const FrontConsts &c, const FrontBuffers &b, int B, hipStream_t st) { launch_mle_kernels(c, b, B, st); }
 void lf_front_launch(const FrontConsts &c, const FrontBuffers &b, int B, hipStream_t st) {
   (void)hipMemsetAsync(b.pts_cnt, 0, sizeof(int) * (size_t)B, st);
   hipLaunchKernelGGL(k_sobel5, dim3((c.W + 255) / 256, (c.H + SOBEL_ROWS - 1) / SOBEL_ROWS, B), dim3(256), 0, st, c, b);
   hipLaunchKernelGGL(k_line3d, dim3(c.cand_cap, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_records, dim3(B), dim3(64), 0, st, c, b);
 #ifndef LF_EXP_SKIP_MLE   // (throughput experiments only: what the step costs without this stage)
-  if (LF_MLE_SMALL > 0) hipLaunchKernelGGL((k_mle<16, 16, 0>), dim3((c.line_cap + 3) / 4, B), dim3(64), 0, st, c, b);   // 4 lines per wavefront
-  hipLaunchKernelGGL((k_mle<32, 32, 1>), dim3((c.line_cap + 1) / 2, B), dim3(64), 0, st, c, b);   // 2 lines per wavefront
-  // (pairing the 33..64-point lines as <32, 64> was measured slower: two row slots per lane, select-based pivoting)
-  hipLaunchKernelGGL((k_mle<64, MLE_N, 2>), dim3(c.line_cap, B), dim3(64), 0, st, c, b);
+  launch_mle_kernels(c, b, B, st);
 #endif
   hipLaunchKernelGGL(k_describe, dim3(c.line_cap, B), dim3(64), 0, st, c, b);
 }

@@ -184,6 +184,57 @@ LF_DEFINE_SOLVE(lf_solve7, 7, LF_SAME_I)
 LF_DEFINE_SOLVE(lf_solve6_u, 6, LF_UNI_I)
 LF_DEFINE_SOLVE(lf_solve7_u, 7, LF_UNI_I)
 
+/* ---------------------------------------------------------------- LAPACK-order LU solve (levmar's AX_EQ_B_LU)
+ * levmar-2.6 solves its augmented normal equations with LAPACK: dgetrf + dgetrs (external/levmar-2.6/Axb_core.c:738-830,
+ * called at lm_core.c:706).  LAPACK is not part of the reference tree; this restates the published reference algorithm
+ * (netlib LAPACK 3.x; for n = 6, 7 dgetrf is the unblocked dgetf2):
+ *   dgetf2: for each column j: pivot = first maximum of |A(j:n, j)| (idamax); swap the rows; scale the sub-column by the
+ *           RECIPROCAL of the pivot (by division if |pivot| < sfmin); rank-one update of the trailing block (dger);
+ *   dgetrs: the row swaps on b; unit lower solve, column oriented; upper solve, column oriented from the LAST column
+ *           upwards with a DIVISION by the diagonal (dtrsm 'L','U','N','N').
+ * Unlike LF_DEFINE_SOLVE above (OpenCV's LU: reciprocal pivots, row-oriented back-substitution) the back-substitution
+ * subtracts in descending column order and divides.  The `if (x != 0)` shortcuts of dger / dtrsm are not restated: they
+ * skip additions of +-0 and can change the sign of an exact zero only.  Row-major A (n x n, overwritten), b (n,
+ * overwritten by x).  Returns 0 for an exactly singular matrix (dgetrf info > 0: levmar treats it as "not solved"). */
+#define LF_LU_SFMIN 2.2250738585072014e-308   /* dlamch('S') */
+#define LF_DEFINE_LU_NETLIB(NAME, N, UNI)                                                      \
+  LF_HD int NAME(double *A, double *B) {                                                       \
+    int i, j, k;                                                                               \
+    for (j = 0; j < N; j++) {                                                                  \
+      int jp = j;                                                                              \
+      double big = lf_fabs(A[j * N + j]);                                                      \
+      for (i = j + 1; i < N; i++) {                                                            \
+        double v = lf_fabs(A[i * N + j]);                                                      \
+        if (v > big) { big = v; jp = i; }                                                      \
+      }                                                                                        \
+      jp = UNI(jp);                                                                            \
+      if (UNI((int)!(big > 0.0))) return 0;                                                    \
+      if (LF_ANY(jp != j))                                                                     \
+        for (i = j + 1; i < N; i++)                                                            \
+          if (i == jp) {                                                                       \
+            for (k = 0; k < N; k++) { double t = A[j * N + k]; A[j * N + k] = A[i * N + k]; A[i * N + k] = t; } \
+            { double t = B[j]; B[j] = B[i]; B[i] = t; }                                        \
+          }                                                                                    \
+      if (UNI((int)(big >= LF_LU_SFMIN))) {                                                    \
+        double r = 1.0 / A[j * N + j];                                                         \
+        for (i = j + 1; i < N; i++) A[i * N + j] = A[i * N + j] * r;                           \
+      } else                                                                                   \
+        for (i = j + 1; i < N; i++) A[i * N + j] = A[i * N + j] / A[j * N + j];                \
+      for (i = j + 1; i < N; i++) {                                                            \
+        for (k = j + 1; k < N; k++) A[i * N + k] -= A[i * N + j] * A[j * N + k];               \
+        B[i] -= A[i * N + j] * B[j];                                                           \
+      }                                                                                        \
+    }                                                                                          \
+    for (k = N - 1; k >= 0; k--) {                                                             \
+      B[k] = B[k] / A[k * N + k];                                                              \
+      for (i = 0; i < k; i++) B[i] -= B[k] * A[i * N + k];                                     \
+    }                                                                                          \
+    return 1;                                                                                  \
+  }
+LF_DEFINE_LU_NETLIB(lf_lu6, 6, LF_SAME_I)
+LF_DEFINE_LU_NETLIB(lf_lu7, 7, LF_SAME_I)
+LF_DEFINE_LU_NETLIB(lf_lu7_u, 7, LF_UNI_I)
+
 /* inverse of a symmetric/any 3x3 (row-major) through lf_solve3; returns 0 if singular */
 LF_HD int lf_inv3(const double *A, double *Ainv) {
   double T[9], I[9];

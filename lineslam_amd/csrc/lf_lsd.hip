@@ -994,7 +994,14 @@ __device__ bool d_refine(const FV &f, int *reg_size, double reg_angle, double pr
 }
 
 // LineSegmentDetection main loop (lsd.cpp:1996-2053): one wavefront per frame.
-__global__ void __launch_bounds__(64, 3) k_lsd_sweep(LsdConsts c, const LsdConsts *dc, LsdBuffers b) {
+#ifndef LF_SWEEP_PRIO
+#define LF_SWEEP_PRIO 3     // wave issue priority (s_setprio): the sweep is one dependent chain per frame -- it goes first, the
+#endif                      // VALU-bound kernels of the other passes fill the slots it leaves
+#ifndef LF_SWEEP_WAVES
+#define LF_SWEEP_WAVES 3
+#endif
+__global__ void __launch_bounds__(64, LF_SWEEP_WAVES) k_lsd_sweep(LsdConsts c, const LsdConsts *dc, LsdBuffers b) {
+  __builtin_amdgcn_s_setprio(LF_SWEEP_PRIO);
   const int fidx = blockIdx.x, lane = lane_id();
   const size_t NM = (size_t)c.N * c.M;
   FrameView f;

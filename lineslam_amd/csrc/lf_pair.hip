@@ -402,7 +402,11 @@ __device__ __forceinline__ int r_model(const PoseShared &S, const double *cm, in
   return 1;
 }
 
+#ifndef LF_POSE_PRIO
+#define LF_POSE_PRIO 2      // wave issue priority (s_setprio): latency-bound at one wavefront per SIMD
+#endif
 __global__ void __launch_bounds__(RT_N) k_pose(PairConsts c, PairBuffers b) {
+  __builtin_amdgcn_s_setprio(LF_POSE_PRIO);
   __shared__ PoseShared S;
   const int pr = blockIdx.x, tid = threadIdx.x, lane = p_lane();
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];

@@ -120,7 +120,7 @@ __device__ int r_levmar7(RShared &S, const RCtx &pc, const int *list, int n, dou
       for (int i = 0; i < 49; i++) A[i] = jacTjac[i];
 #pragma unroll
       for (int i = 0; i < 7; i++) Bv[i] = jacTe[i];
-      issolved = lf_solve7_u(A, Bv, 1);
+      issolved = lf_lu7_u(A, Bv);   // AX_EQ_B_LU in LAPACK order (lf_linalg.h)
 #pragma unroll
       for (int i = 0; i < 7; i++) Dp[i] = Bv[i];
     }

@@ -384,8 +384,75 @@ int oracle_msld(const double *xG, const double *yG, int width, int height, const
  * dlevmar_dif restated (external/levmar-2.6/lm_core.c:438-846; forward differences
  * misc_core.c:137-171; constants levmar.h:95-100: LM_INIT_MU 1e-3, LM_DIFF_DELTA 1e-6,
  * EPSILON 1e-12, ONE_THIRD 0.3333333334).  Measurement vector x == 0 as in the reference's calls.
- * Linear solver: LU with partial pivoting (AX_EQ_B_LU).  m <= 7.                               */
+ * Linear solver: AX_EQ_B_LU in LAPACK's dgetf2 / dgetrs order (o_ax_eq_b_lu).  m <= 8.            */
 typedef void (*o_lm_func)(const double *p, double *hx, int m, int n, void *adata);
+
+/* AX_EQ_B_LU (external/levmar-2.6/Axb_core.c:738-830; the reference defines HAVE_LAPACK, levmar.h:31, so lm_core.c:706
+ * takes this one): A is copied COLUMN-major (Axb_core.c:787-793), factored by LAPACK's dgetrf and solved by dgetrs.
+ * LAPACK is a system library of the reference, not part of its tree: what follows transcribes the published reference
+ * implementation (netlib LAPACK 3.x + reference BLAS), routine by routine -- for the 6 x 6 / 7 x 7 systems of this
+ * path dgetrf takes its unblocked branch (block size 64 > n), i.e. dgetf2:
+ *   idamax  first index of the largest |value|
+ *   dswap   whole rows, all n columns
+ *   dscal   by the reciprocal of the pivot when |pivot| >= sfmin, else element-wise division
+ *   dger    A := A - x y^T, column by column, skipping columns with y(j) == 0
+ *   dlaswp  row interchanges on b; dtrsm 'L','L','N','U' then dtrsm 'L','U','N','N', both column oriented, skipping
+ *           zero b(k), the second dividing by the diagonal.
+ * (OpenBLAS / ATLAS / MKL builds of LAPACK order these sums differently)                  */
+static int o_dgetf2(int n, double *a /* column-major, lda = n */, int *ipiv) {
+  const double sfmin = DBL_MIN; /* dlamch('S') */
+  int info = 0, i, j, k;
+  for (j = 0; j < n; ++j) {
+    int jp = j;
+    double dmax = fabs(a[j + j * n]);
+    for (i = j + 1; i < n; ++i)                       /* idamax */
+      if (fabs(a[i + j * n]) > dmax) { dmax = fabs(a[i + j * n]); jp = i; }
+    ipiv[j] = jp;
+    if (a[jp + j * n] != 0.0) {
+      if (jp != j)                                     /* dswap */
+        for (k = 0; k < n; ++k) { double t = a[j + k * n]; a[j + k * n] = a[jp + k * n]; a[jp + k * n] = t; }
+      if (j < n - 1) {
+        if (fabs(a[j + j * n]) >= sfmin) {             /* dscal */
+          double r = 1.0 / a[j + j * n];
+          for (i = j + 1; i < n; ++i) a[i + j * n] = r * a[i + j * n];
+        } else
+          for (i = j + 1; i < n; ++i) a[i + j * n] = a[i + j * n] / a[j + j * n];
+      }
+    } else if (info == 0)
+      info = j + 1;
+    if (j < n - 1)                                     /* dger, alpha = -1 */
+      for (k = j + 1; k < n; ++k)
+        if (a[j + k * n] != 0.0) {
+          double temp = -1.0 * a[j + k * n];
+          for (i = j + 1; i < n; ++i) a[i + k * n] = a[i + k * n] + a[i + j * n] * temp;
+        }
+  }
+  return info;
+}
+static void o_dgetrs(int n, const double *a, const int *ipiv, double *b) {
+  int i, k;
+  for (i = 0; i < n; ++i)                              /* dlaswp, forward */
+    if (ipiv[i] != i) { double t = b[i]; b[i] = b[ipiv[i]]; b[ipiv[i]] = t; }
+  for (k = 0; k < n; ++k)                              /* dtrsm: L, unit diagonal */
+    if (b[k] != 0.0)
+      for (i = k + 1; i < n; ++i) b[i] = b[i] - b[k] * a[i + k * n];
+  for (k = n - 1; k >= 0; --k)                         /* dtrsm: U, non-unit diagonal */
+    if (b[k] != 0.0) {
+      b[k] = b[k] / a[k + k * n];
+      for (i = 0; i < k; ++i) b[i] = b[i] - b[k] * a[i + k * n];
+    }
+}
+static int o_ax_eq_b_lu(const double *A, const double *B, double *x, int m) {
+  double a[64];
+  int ipiv[8], i, j;
+  for (i = 0; i < m; i++) {
+    for (j = 0; j < m; j++) a[i + j * m] = A[i * m + j];
+    x[i] = B[i];
+  }
+  if (o_dgetf2(m, a, ipiv) != 0) return 0;             /* "singular matrix A for dgetrf" */
+  o_dgetrs(m, a, ipiv, x);
+  return 1;
+}
 /* dlevmar_L2nrmxmy with x == 0 values (misc_core.c, LEVMAR_L2NRMXMY; lm_core.c:555 and :743 call it, the plain loops
  * there are compiled out): e = 0 - y and ||e||^2 with FOUR running sums over blocks of eight taken from the top of the
  * vector downwards, then the remainder by the fall-through switch, returned as sum0+sum1+sum2+sum3.                  */
@@ -473,14 +540,7 @@ int oracle_levmar_dif(o_lm_func func, double *p, int m, int n, int itmax, const 
       mu = tau * tmp;
     }
     for (i = 0; i < m; ++i) jacTjac[i * m + i] += mu;
-    { /* AX_EQ_B_LU */
-      double A[64], B[8];
-      for (i = 0; i < m * m; i++) A[i] = jacTjac[i];
-      for (i = 0; i < m; i++) B[i] = jacTe[i];
-      issolved = (m == 6) ? lf_solve6(A, B, 1) : (m == 7 ? lf_solve7(A, B, 1) : 0);
-      for (i = 0; i < m; i++) Dp[i] = B[i];
-      ++nlss;
-    }
+    issolved = (m <= 8) ? o_ax_eq_b_lu(jacTjac, jacTe, Dp, m) : 0; ++nlss;   /* lm_core.c:706 */
     if (issolved) {
       for (i = 0, Dp_L2 = 0.0; i < m; ++i) { pDp[i] = p[i] + (tmp = Dp[i]); Dp_L2 += tmp * tmp; }
       if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
@@ -776,3 +836,15 @@ void oracle_jacobi3(const double *A, double *V, double *w) { double T[9]; int i;
 void oracle_jacobi4(const double *A, double *V, double *w) { double T[16]; int i; for (i = 0; i < 16; i++) T[i] = A[i]; lf_jacobi4(T, V, w); }
 int oracle_solve6(const double *A, const double *b, double *x) { double T[36], B[6]; int i, r; for (i = 0; i < 36; i++) T[i] = A[i]; for (i = 0; i < 6; i++) B[i] = b[i]; r = lf_solve6(T, B, 1); for (i = 0; i < 6; i++) x[i] = B[i]; return r; }
 uint32_t oracle_rand31(uint64_t seed, uint64_t stream, uint64_t ctr) { return lf_rand31(seed, stream, ctr); }
+/* the two statements of levmar's AX_EQ_B_LU: the transcription above (oracle's own) and the product's scalar form
+ * (lf_linalg.h, what k_relmotion runs and what k_mle's lane-distributed form must equal) -- tests hold them bit-equal */
+int oracle_lu_netlib(const double *A, const double *b, double *x, int m) { return o_ax_eq_b_lu(A, b, x, m); }
+int oracle_lu_product(const double *A, const double *b, double *x, int m) {
+  double T[49], B[7]; int i, r;
+  if (m != 6 && m != 7) return -1;
+  for (i = 0; i < m * m; i++) T[i] = A[i];
+  for (i = 0; i < m; i++) B[i] = b[i];
+  r = (m == 6) ? lf_lu6(T, B) : lf_lu7(T, B);
+  for (i = 0; i < m; i++) x[i] = B[i];
+  return r;
+}
