@@ -49,6 +49,25 @@
 #define E_LOG log
 #define E_EXP exp
 
+/* Precision of the intermediates of the line geometry.  The reference links the 64-bit archive (libEDLines.a, GCC 4.6,
+ * SSE2 doubles: every operation rounds to double) -- the default here and what the HIP kernels follow.  The example output
+ * the authors ship (LineSegments.txt) was written by their 32-bit test program (EDLinesTest is an i386 ELF; its archive
+ * libEDLines-32bit.a, GCC 4.3.4, contains x87 instructions only: 449 in LineSegment.o, no SSE): there, expression
+ * intermediates and values returned in st(0) carry the 64-bit mantissa of the x87 registers and round to double only when
+ * they are stored (struct fields, reference parameters, arguments pushed on the stack).  ORACLE_ED_X87 restates that:
+ * `ereal` locals / return values are long double, everything kept in memory stays double.  Distances of integer pixels to
+ * a fitted line land on the thresholds (<= 1.0, error <= 0.5) often enough that the two precisions split two short
+ * segments of the example differently (tests/test_oracle_edlines.py).                                                   */
+#ifdef ORACLE_ED_X87
+typedef long double ereal;
+#define E_SQRT sqrtl
+#define E_FABS fabsl
+#else
+typedef double ereal;
+#define E_SQRT sqrt
+#define E_FABS fabs
+#endif
+
 #define ED_GRAD_THRESH 11          /* DetectLinesByED: mov $0xb,%r9d before ComputeGradientMapByLSD / %r8d before DoDetectEdgesByED */
 #define ED_ANCHOR_THRESH 3         /* mov $0x3,%r9d */
 #define ED_VERTICAL 1              /* dirImg codes (cmpb $0x1 / $0x2) */
@@ -153,102 +172,103 @@ static int e_retrieve_chain_nos(e_chain *ch, int root, int *nos) {
 typedef struct { double a, b; int invert; double sx, sy, ex, ey; int segmentNo, firstPixelIndex, len; } e_line;
 
 static void e_line_fit_err(const double *x, const double *y, int count, double *pa, double *pb, double *pe, int *pinvert) {
-  double S = count, Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, mx, my, dx = 0, dy = 0, D, a, b;
+  ereal S = count, Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, mx, my, dx = 0, dy = 0, D, a, b;
   int i;
   if (count < 2) return;
   for (i = 0; i < count; i++) { Sx += x[i]; Sy += y[i]; }
   mx = Sx / count; my = Sy / count;
   for (i = 0; i < count; i++) { dx += (x[i] - mx) * (x[i] - mx); dy += (y[i] - my) * (y[i] - my); }
-  if (dx < dy) { const double *t = x; double d = Sx; *pinvert = 1; x = y; y = t; Sx = Sy; Sy = d; }
+  if (dx < dy) { const double *t = x; ereal d = Sx; *pinvert = 1; x = y; y = t; Sx = Sy; Sy = d; }
   else *pinvert = 0;
   for (i = 0; i < count; i++) { Sxx += x[i] * x[i]; Sxy += x[i] * y[i]; }
   D = S * Sxx - Sx * Sx;
   a = (Sxx * Sy - Sx * Sxy) / D;
   b = (S * Sxy - Sx * Sy) / D;
-  *pa = a; *pb = b;
+  *pa = (double)a; *pb = (double)b;
+  a = *pa; b = *pb;                                  /* (reference parameters: memory) */
   if (b == 0.0) {
-    double error = 0;
-    for (i = 0; i < count; i++) error += fabs(a - y[i]);
-    *pe = error / count;
+    ereal error = 0;
+    for (i = 0; i < count; i++) error += E_FABS(a - y[i]);
+    *pe = (double)(error / count);
   } else {
-    double error = 0;
+    ereal error = 0;
     for (i = 0; i < count; i++) {
-      double d = -1.0 / b, c = y[i] - d * x[i];
-      double x2 = (a - c) / (d - b), y2 = a + b * x2;
+      ereal d = -1.0 / b, c = y[i] - d * x[i];
+      ereal x2 = (a - c) / (d - b), y2 = a + b * x2;
       error += (x[i] - x2) * (x[i] - x2) + (y[i] - y2) * (y[i] - y2);
     }
-    *pe = sqrt(error / count);
+    *pe = (double)E_SQRT(error / count);
   }
 }
 static void e_line_fit(const double *x, const double *y, int count, double *pa, double *pb, int invert) {
-  double S = count, Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, D;
+  ereal S = count, Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, D;
   int i;
   if (count < 2) return;
   for (i = 0; i < count; i++) { Sx += x[i]; Sy += y[i]; }
-  if (invert) { const double *t = x; double d = Sx; x = y; y = t; Sx = Sy; Sy = d; }
+  if (invert) { const double *t = x; ereal d = Sx; x = y; y = t; Sx = Sy; Sy = d; }
   for (i = 0; i < count; i++) { Sxx += x[i] * x[i]; Sxy += x[i] * y[i]; }
   D = S * Sxx - Sx * Sx;
-  *pa = (Sxx * Sy - Sx * Sxy) / D;
-  *pb = (S * Sxy - Sx * Sy) / D;
+  *pa = (double)((Sxx * Sy - Sx * Sxy) / D);
+  *pb = (double)((S * Sxy - Sx * Sy) / D);
 }
 static void e_closest_point(double x1, double y1, double a, double b, int invert, double *xo, double *yo) {
-  double x2, y2;
+  ereal x2, y2;
   if (invert == 0) {
     if (b == 0) { x2 = x1; y2 = a; }
-    else { double d = -1.0 / b, c = y1 - d * x1; x2 = (a - c) / (d - b); y2 = a + b * x2; }
+    else { ereal d = -1.0 / b, c = y1 - d * x1; x2 = (a - c) / (d - b); y2 = a + b * x2; }
   } else {
     if (b == 0) { x2 = a; y2 = y1; }
-    else { double d = -1.0 / b, c = x1 - d * y1; y2 = (a - c) / (d - b); x2 = a + b * y2; }
+    else { ereal d = -1.0 / b, c = x1 - d * y1; y2 = (a - c) / (d - b); x2 = a + b * y2; }
   }
-  *xo = x2; *yo = y2;
+  *xo = (double)x2; *yo = (double)y2;
 }
-static double e_min_distance(double x1, double y1, double a, double b, int invert) {
+static ereal e_min_distance(double x1, double y1, double a, double b, int invert) {
   double x2, y2;
   e_closest_point(x1, y1, a, b, invert, &x2, &y2);
-  return sqrt((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
+  return E_SQRT(((ereal)x1 - x2) * ((ereal)x1 - x2) + ((ereal)y1 - y2) * ((ereal)y1 - y2));
 }
 static void e_update_line_parameters(e_line *ls) {
-  double dx = ls->ex - ls->sx, dy = ls->ey - ls->sy;
-  if (fabs(dx) >= fabs(dy)) {
+  ereal dx = (ereal)ls->ex - ls->sx, dy = (ereal)ls->ey - ls->sy;
+  if (E_FABS(dx) >= E_FABS(dy)) {
     ls->invert = 0;                                  /* y = a + b x */
-    if (fabs(dy) < 1e-3) { ls->b = 0; ls->a = (ls->sy + ls->ey) / 2; }
-    else { ls->b = dy / dx; ls->a = ls->sy - ls->b * ls->sx; }
+    if (E_FABS(dy) < 1e-3) { ls->b = 0; ls->a = (double)(((ereal)ls->sy + ls->ey) / 2); }
+    else { ls->b = (double)(dy / dx); ls->a = (double)(ls->sy - (ereal)ls->b * ls->sx); }
   } else {
     ls->invert = 1;                                  /* x = a + b y */
-    if (fabs(dx) < 1e-3) { ls->b = 0; ls->a = (ls->sx + ls->ex) / 2; }
-    else { ls->b = dx / dy; ls->a = ls->sx - ls->b * ls->sy; }
+    if (E_FABS(dx) < 1e-3) { ls->b = 0; ls->a = (double)(((ereal)ls->sx + ls->ex) / 2); }
+    else { ls->b = (double)(dx / dy); ls->a = (double)(ls->sx - (ereal)ls->b * ls->sy); }
   }
 }
-static double e_min_distance_between_two_lines(const e_line *ls1, const e_line *ls2, int *pwhich) {
-  double dx = ls1->sx - ls2->sx, dy = ls1->sy - ls2->sy, d = sqrt(dx * dx + dy * dy), min = d;
+static ereal e_min_distance_between_two_lines(const e_line *ls1, const e_line *ls2, int *pwhich) {
+  ereal dx = (ereal)ls1->sx - ls2->sx, dy = (ereal)ls1->sy - ls2->sy, d = E_SQRT(dx * dx + dy * dy), min = d;
   int which = 0;                                      /* SS */
-  dx = ls1->sx - ls2->ex; dy = ls1->sy - ls2->ey; d = sqrt(dx * dx + dy * dy);
+  dx = (ereal)ls1->sx - ls2->ex; dy = (ereal)ls1->sy - ls2->ey; d = E_SQRT(dx * dx + dy * dy);
   if (d < min) { min = d; which = 1; }                /* SE */
-  dx = ls1->ex - ls2->sx; dy = ls1->ey - ls2->sy; d = sqrt(dx * dx + dy * dy);
+  dx = (ereal)ls1->ex - ls2->sx; dy = (ereal)ls1->ey - ls2->sy; d = E_SQRT(dx * dx + dy * dy);
   if (d < min) { min = d; which = 2; }                /* ES */
-  dx = ls1->ex - ls2->ex; dy = ls1->ey - ls2->ey; d = sqrt(dx * dx + dy * dy);
+  dx = (ereal)ls1->ex - ls2->ex; dy = (ereal)ls1->ey - ls2->ey; d = E_SQRT(dx * dx + dy * dy);
   if (d < min) { min = d; which = 3; }                /* EE */
   if (pwhich) *pwhich = which;
   return min;
 }
 static int e_try_to_join(e_line *ls1, e_line *ls2, double max_dist, double max_err) {
   int which;
-  double dist = e_min_distance_between_two_lines(ls1, ls2, &which), dx, dy, prevLen, nextLen, d, mx;
+  ereal dist = e_min_distance_between_two_lines(ls1, ls2, &which), dx, dy, prevLen, nextLen, d, mx;
   const e_line *shorter = ls1, *longer = ls2;
   if (dist > max_dist) return 0;
-  dx = ls1->sx - ls1->ex; dy = ls1->sy - ls1->ey; prevLen = sqrt(dx * dx + dy * dy);
-  dx = ls2->sx - ls2->ex; dy = ls2->sy - ls2->ey; nextLen = sqrt(dx * dx + dy * dy);
+  dx = (ereal)ls1->sx - ls1->ex; dy = (ereal)ls1->sy - ls1->ey; prevLen = E_SQRT(dx * dx + dy * dy);
+  dx = (ereal)ls2->sx - ls2->ex; dy = (ereal)ls2->sy - ls2->ey; nextLen = E_SQRT(dx * dx + dy * dy);
   if (prevLen > nextLen) { shorter = ls2; longer = ls1; }
   dist = e_min_distance(shorter->sx, shorter->sy, longer->a, longer->b, longer->invert);
-  dist += e_min_distance((shorter->sx + shorter->ex) / 2.0, (shorter->sy + shorter->ey) / 2.0, longer->a, longer->b, longer->invert);
+  dist += e_min_distance((double)(((ereal)shorter->sx + shorter->ex) / 2.0), (double)(((ereal)shorter->sy + shorter->ey) / 2.0), longer->a, longer->b, longer->invert);
   dist += e_min_distance(shorter->ex, shorter->ey, longer->a, longer->b, longer->invert);
   dist /= 3.0;
   if (dist > max_err) return 0;
   /* the two end points that are farthest apart (city-block) become the joined line's end points */
-  dx = fabs(ls1->sx - ls2->sx); dy = fabs(ls1->sy - ls2->sy); d = dx + dy; mx = d; which = 1;
-  dx = fabs(ls1->sx - ls2->ex); dy = fabs(ls1->sy - ls2->ey); d = dx + dy; if (d > mx) { mx = d; which = 2; }
-  dx = fabs(ls1->ex - ls2->sx); dy = fabs(ls1->ey - ls2->sy); d = dx + dy; if (d > mx) { mx = d; which = 3; }
-  dx = fabs(ls1->ex - ls2->ex); dy = fabs(ls1->ey - ls2->ey); d = dx + dy; if (d > mx) { mx = d; which = 4; }
+  dx = E_FABS((ereal)ls1->sx - ls2->sx); dy = E_FABS((ereal)ls1->sy - ls2->sy); d = dx + dy; mx = d; which = 1;
+  dx = E_FABS((ereal)ls1->sx - ls2->ex); dy = E_FABS((ereal)ls1->sy - ls2->ey); d = dx + dy; if (d > mx) { mx = d; which = 2; }
+  dx = E_FABS((ereal)ls1->ex - ls2->sx); dy = E_FABS((ereal)ls1->ey - ls2->sy); d = dx + dy; if (d > mx) { mx = d; which = 3; }
+  dx = E_FABS((ereal)ls1->ex - ls2->ex); dy = E_FABS((ereal)ls1->ey - ls2->ey); d = dx + dy; if (d > mx) { mx = d; which = 4; }
   if (which == 1) { ls1->ex = ls2->sx; ls1->ey = ls2->sy; }
   else if (which == 2) { ls1->ex = ls2->ex; ls1->ey = ls2->ey; }
   else if (which == 3) { ls1->sx = ls2->sx; ls1->sy = ls2->sy; }
@@ -459,7 +479,7 @@ static void e_split_segment(const double *x, const double *y, int noPixels, int 
     while (index < noPixels) {
       int startIndex = index, lastGoodIndex = index - 1, goodPixelCount = 0, badPixelCount = 0;
       while (index < noPixels) {
-        double d = e_min_distance(x[index], y[index], lastA, lastB, lastInvert);
+        const ereal d = e_min_distance(x[index], y[index], lastA, lastB, lastInvert);
         if (d <= ED_LINE_ERROR) { lastGoodIndex = index; goodPixelCount++; badPixelCount = 0; }
         else { badPixelCount++; if (badPixelCount >= 5) break; }
         index++;

@@ -27,6 +27,9 @@ def oracle_lib(flavour="ref"):
         if not os.path.exists(path):
             build_oracle()
         lib = C.CDLL(path)
+        if flavour == "edx87":          # edlines_oracle.c alone (x87 intermediates)
+            _libs[flavour] = lib
+            return lib
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
         lib.oracle_lsd.restype = C.c_int
         lib.oracle_lsd.argtypes = [dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
@@ -323,7 +326,8 @@ def orb_oracle(gray_u8, depth_f32=None, fast_threshold=20, nfeatures=10000, max_
 
 
 def edlines_oracle(gray_u8, flavour="ref", cap=4096, debug=False):
-    """oracle_edlines: the restatement of libEDLines.a's object code.  Returns segments [n,4] (sx, sy, ex, ey)[, smooth, G, D, E]."""
+    """oracle_edlines: the restatement of libEDLines.a's object code.  Returns segments [n,4] (sx, sy, ex, ey)[, smooth, G, D, E].
+    flavour "edx87": the same with x87 extended-precision intermediates (the reference's 32-bit archive)."""
     lib = oracle_lib(flavour)
     g = np.ascontiguousarray(gray_u8, np.uint8)
     h, w = g.shape
