@@ -484,6 +484,11 @@ static double o_l2nrmxmy(double *e, const double *y, int n) {
   }
   return sum0 + sum1 + sum2 + sum3;
 }
+/* tests only: replace AX_EQ_B_LU by a caller-supplied solver (tests/test_oracle_front.py plugs in the LAPACK that the
+ * compiled levmar was linked with, to separate "the restatement of dlevmar_dif" from "the rounding of one LAPACK build") */
+typedef int (*o_lu_fn)(const double *A, const double *B, double *x, int m);
+static o_lu_fn o_lu_hook = 0;
+void oracle_set_lu_hook(o_lu_fn fn) { o_lu_hook = fn; }
 int oracle_levmar_dif(o_lm_func func, double *p, int m, int n, int itmax, const double opts[5],
                       double info[10], void *adata) {
   double *e = (double *)malloc(sizeof(double) * (size_t)n * (4 + m));
@@ -540,7 +545,7 @@ int oracle_levmar_dif(o_lm_func func, double *p, int m, int n, int itmax, const 
       mu = tau * tmp;
     }
     for (i = 0; i < m; ++i) jacTjac[i * m + i] += mu;
-    issolved = (m <= 8) ? o_ax_eq_b_lu(jacTjac, jacTe, Dp, m) : 0; ++nlss;   /* lm_core.c:706 */
+    issolved = (m <= 8) ? (o_lu_hook ? o_lu_hook(jacTjac, jacTe, Dp, m) : o_ax_eq_b_lu(jacTjac, jacTe, Dp, m)) : 0; ++nlss;   /* lm_core.c:706 */
     if (issolved) {
       for (i = 0, Dp_L2 = 0.0; i < m; ++i) { pDp[i] = p[i] + (tmp = Dp[i]); Dp_L2 += tmp * tmp; }
       if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
@@ -847,4 +852,36 @@ int oracle_lu_product(const double *A, const double *b, double *x, int m) {
   r = (m == 6) ? lf_lu6(T, B) : lf_lu7(T, B);
   for (i = 0; i < m; i++) x[i] = B[i];
   return r;
+}
+
+/* MLEstimateLine3d's levmar problem (costFun_MLEstimateLine3d on the support points, utils.cpp:980-1012) run twice from
+ * the same start with the SAME cost function o_mle_cost: by the restatement oracle_levmar_dif, and by a compiled
+ * dlevmar_dif handed in as a function pointer (the reference's levmar-2.6 from oracle/_ref, loaded by the test -- nothing of
+ * it is linked here).  out_*: parameters [6] and levmar's info [10] of the two runs; returns the two iteration counts. */
+typedef int (*o_dlevmar_dif_fn)(void (*)(double *, double *, int, int, void *), double *, double *, int, int, int, double *,
+                                double *, double *, double *, void *);
+static void o_mle_cost_nc(double *p, double *hx, int m, int n, void *adata) { o_mle_cost(p, hx, m, n, adata); }
+void oracle_mle_levmar_pair(const double *pts, int n, double focal, const lf_params *P, const double AB[6],
+                            o_dlevmar_dif_fn compiled, double own_p[6], double own_info[10], double ref_p[6],
+                            double ref_info[10], int nit[2]) {
+  orpt *rp = (orpt *)malloc(sizeof(orpt) * (size_t)(n > 0 ? n : 1));
+  double minv = 100, maxv = -100, opts[5], *x0 = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+  const double *A = AB, *B = AB + 3;
+  int e1 = 0, e2 = 0, i, k;
+  o_mle_data data;
+  for (i = 0; i < n; i++) o_comp_pt3d_cov(pts + 3 * i, focal, P, &rp[i]);
+  for (i = 0; i < n; ++i) {
+    double dp = (rp[i].pos[0] - A[0]) * (A[0] - B[0]) + (rp[i].pos[1] - A[1]) * (A[1] - B[1]) + (rp[i].pos[2] - A[2]) * (A[2] - B[2]);
+    if (dp < minv) { minv = dp; e1 = i; }
+    if (dp > maxv) { maxv = dp; e2 = i; }
+  }
+  if (e1 > e2) { int t = e1; e1 = e2; e2 = t; }
+  opts[0] = 1E-03; opts[1] = 1E-10; opts[2] = 1E-20; opts[3] = 1E-20; opts[4] = 1E-06;
+  data.pts = rp; data.n = n; data.idx1 = e1; data.idx2 = e2;
+  lf_inv3(rp[e1].cov, data.ci1);
+  lf_inv3(rp[e2].cov, data.ci2);
+  for (k = 0; k < 3; k++) { own_p[k] = ref_p[k] = rp[e1].pos[k]; own_p[3 + k] = ref_p[3 + k] = rp[e2].pos[k]; }
+  nit[0] = oracle_levmar_dif(o_mle_cost, own_p, 6, n, P->line3d_mle_iter_num, opts, own_info, &data);
+  nit[1] = compiled ? compiled(o_mle_cost_nc, ref_p, x0, 6, n, P->line3d_mle_iter_num, opts, ref_info, 0, 0, &data) : -2;
+  free(rp); free(x0);
 }

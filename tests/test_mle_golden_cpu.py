@@ -65,4 +65,67 @@ def test_mle_line_vs_independent_vectors():
             n_same += (nit == c["levmar_meta"][0] and int(info[6]) == c["levmar_meta"][1])
             assert np.abs(cA - c["levmar_covA"]).max() < 5e-3 * np.abs(cA).max(), k
             assert np.abs(cB - c["levmar_covB"]).max() < 5e-3 * np.abs(cB).max(), k
-    assert n_lev == 0 or n_same >= (7 * n_lev) // 10   # measured: 30 of 40
+    # measured: 28 of 40 with AX_EQ_B_LU in netlib dgetf2 / dgetrs order (30 with OpenCV-order elimination).  The fixture's
+    # levmar was linked against OpenBLAS and driven with the numpy cost function: the path through the quartic valley is
+    # sensitive to the last bit of BOTH (the compiled levmar agrees with ITSELF on 31 of 40 when its cost function is
+    # swapped for the C one) -- test_dlevmar_dif_restatement_is_bit_exact_given_the_same_lapack below separates the two.
+    assert n_lev == 0 or n_same >= (6 * n_lev) // 10
+
+
+def test_dlevmar_dif_restatement_is_bit_exact_given_the_same_lapack():
+    """The 40 MLE problems of the fixtures, solved twice from the same start with the SAME C cost function
+    (costFun_MLEstimateLine3d as restated in the oracle): by the restatement oracle_levmar_dif and by the reference's own
+    compiled dlevmar_dif (oracle/_ref/liblevmar_ref.so, loaded here and handed over as a function pointer).
+      * with the restatement's AX_EQ_B_LU replaced (oracle_set_lu_hook) by dgetrf / dgetrs of the very LAPACK that library
+        is linked with (scipy's OpenBLAS): 40 of 40 identical iteration count, stop reason, number of evaluations AND
+        bit-identical parameters -- everything of dlevmar_dif except the linear solver is pinned bit for bit;
+      * with the netlib-order LU (the published reference LAPACK, what the product runs): the same problems, parameters
+        within 2e-5 m, the path (count / stop reason) identical on at least half -- the difference is the rounding of one
+        LAPACK build against another, which no restatement of the reference's tree can pin."""
+    import pytest
+    from scipy.linalg import lapack
+    path = os.path.join(O.ODIR, "_ref", "liblevmar_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/liblevmar_ref.so not built (needs /root/reference)")
+    ref = C.CDLL(path)
+    fn = C.cast(ref.dlevmar_dif, C.c_void_p)
+    lib = O.oracle_lib("lf")
+    P = capi.default_params(launch=True)
+    LUFN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)
+
+    def lu(A, B, x, m):
+        a = np.array([A[i] for i in range(m * m)]).reshape(m, m)     # symmetric: levmar's column-major copy == a
+        lu_, piv, info = lapack.dgetrf(np.asfortranarray(a))
+        if info != 0:
+            return 0
+        xx, info = lapack.dgetrs(lu_, piv, np.array([B[i] for i in range(m)]))
+        for i in range(m):
+            x[i] = xx[i]
+        return 1
+    hook = LUFN(lu)
+
+    def run(c):
+        p = np.ascontiguousarray(c["pts"], np.float64).reshape(-1, 3)
+        AB = np.ascontiguousarray(c["init"], np.float64)
+        op, oi, rp, ri = np.zeros(6), np.zeros(10), np.zeros(6), np.zeros(10)
+        nit = (C.c_int * 2)()
+        lib.oracle_mle_levmar_pair(C.c_void_p(p.ctypes.data), len(p), C.c_double(525.0), C.byref(P), C.c_void_p(AB.ctypes.data), fn,
+                                   C.c_void_p(op.ctypes.data), C.c_void_p(oi.ctypes.data), C.c_void_p(rp.ctypes.data),
+                                   C.c_void_p(ri.ctypes.data), nit)
+        return op, oi, rp, ri, nit[0], nit[1]
+    cases = G.mle_cases()
+    try:
+        lib.oracle_set_lu_hook(hook)
+        for k, c in enumerate(cases):
+            op, oi, rp, ri, n0, n1 = run(c)
+            assert n0 == n1 and oi[6] == ri[6] and oi[7] == ri[7] and oi[8] == ri[8] and oi[9] == ri[9], k
+            assert op.tobytes() == rp.tobytes() and oi[1] == ri[1], k
+    finally:
+        lib.oracle_set_lu_hook(None)
+    same = 0
+    for k, c in enumerate(cases):
+        op, oi, rp, ri, n0, n1 = run(c)
+        same += (n0 == n1 and oi[6] == ri[6])
+        assert np.abs(op - rp).max() < 2e-5, (k, np.abs(op - rp).max())
+    assert same >= len(cases) // 2, same          # measured: 29 of 40
+

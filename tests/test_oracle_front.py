@@ -63,8 +63,9 @@ def test_levmar_restatement_matches_reference_levmar():
         same_path += (ra == rb and int(ia[6]) == int(ib[6]) and int(ia[7]) == int(ib[7]))
         assert np.allclose(pa, pb, rtol=0, atol=5e-7), (trial, np.abs(pa - pb).max())   # measured: <= 3.5e-8
         assert abs(ia[1] - ib[1]) <= 1e-9 * max(1.0, ia[1])
-    # identical iteration count / stop reason / #function evaluations (8 of 8 since the error norm follows levmar's
-    # LEVMAR_L2NRMXMY summation order; the linear solver stays a restatement: LAPACK's LU differs in rounding)
+    # identical iteration count / stop reason / #function evaluations (the error norm follows levmar's LEVMAR_L2NRMXMY
+    # summation order; the linear solver is netlib's dgetf2 / dgetrs order, the compiled library runs OpenBLAS's:
+    # tests/test_mle_golden_cpu.py shows bit-identity once the same LAPACK is plugged in)
     assert same_path >= 7, same_path
 
 
@@ -86,6 +87,29 @@ def test_jacobi_and_solve_vs_numpy():
         lib.oracle_solve6.restype = C.c_int
         assert lib.oracle_solve6(C.c_void_p(A.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(x.ctypes.data)) == 1
         assert np.allclose(x, np.linalg.solve(A, b), rtol=1e-9, atol=1e-11)
+
+
+def test_lapack_order_lu_two_statements_agree_bit_for_bit():
+    """levmar's AX_EQ_B_LU: the oracle's own routine-by-routine transcription of netlib dgetf2 + dgetrs (column-major,
+    idamax / dswap / dscal / dger / dlaswp / dtrsm) and the product's scalar form (lf_linalg.h lf_lu6 / lf_lu7, row-major,
+    what k_relmotion runs and k_mle's one-column-per-lane form must equal) give identical bits; both solve the system."""
+    lib = O.oracle_lib("lf")
+    rng = np.random.default_rng(0)
+    for t in range(600):
+        m = 6 if t % 2 else 7
+        J = rng.normal(size=(30, m)) * rng.uniform(1e-3, 1e3, size=m)
+        A = J.T @ J + np.eye(m) * rng.uniform(0, 1e-3)
+        A = (A + A.T) / 2
+        if t % 5 == 0:
+            A = rng.normal(size=(m, m))          # general matrices: row interchanges happen
+        b, x1, x2 = rng.normal(size=m), np.zeros(m), np.zeros(m)
+        r1 = lib.oracle_lu_netlib(C.c_void_p(A.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(x1.ctypes.data), m)
+        r2 = lib.oracle_lu_product(C.c_void_p(A.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(x2.ctypes.data), m)
+        assert r1 == r2 == 1 and x1.tobytes() == x2.tobytes()
+        assert np.allclose(x1, np.linalg.solve(A, b), rtol=1e-6, atol=1e-9 * np.abs(x1).max())
+    Z = np.zeros((6, 6)); b = np.ones(6); x = np.zeros(6)
+    assert lib.oracle_lu_netlib(C.c_void_p(Z.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(x.ctypes.data), 6) == 0
+    assert lib.oracle_lu_product(C.c_void_p(Z.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(x.ctypes.data), 6) == 0
 
 
 def test_rand31_is_a_31_bit_counter_generator():
