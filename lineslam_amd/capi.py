@@ -566,6 +566,9 @@ class Context:
     def comm_attach(self, owner):
         self._chk(lib().lf_comm_attach(self._h, owner._h), "lf_comm_attach")
 
+    def comm_destroy(self):
+        self._chk(lib().lf_comm_destroy(self._h), "lf_comm_destroy")
+
     def allgather_keyframes(self, kf_slots, id_offset=0):
         """lf_allgather_keyframes: pack + ONE ncclAllGather + header unpack on the context stream (async).
         Returns (recs_ptr, nlines_ptr, ids_ptr, n_slots, ext_line_cap) for match_external_device / line_matching_device."""

@@ -71,6 +71,7 @@ struct lf_ctx {
   ncclComm_t comm = nullptr;
   bool comm_owner = false;
   int comm_world = 0, comm_rank = 0, comm_max_kf = 0;
+  int xbuf_world = 0, xbuf_max_kf = 0;      // geometry the exchange buffers were allocated for
   lf_line_record *d_xsend = nullptr, *d_xrecv = nullptr;   // [max_kf][line_cap + 1], [world * max_kf][line_cap + 1]
   int *d_xnlines = nullptr, *d_xslots = nullptr;
   uint64_t *d_xids = nullptr;
@@ -1372,8 +1373,23 @@ int lf_comm_unique_id(uint8_t id[LF_COMM_ID_BYTES]) {
   memcpy(id, &u, sizeof u);
   return LF_OK;
 }
+static void free_tracked(lf_ctx *c, void *p) {
+  if (!p) return;
+  for (size_t i = 0; i < c->allocs.size(); i++)
+    if (c->allocs[i] == p) { c->allocs.erase(c->allocs.begin() + (long)i); break; }
+  (void)hipFree(p);
+}
 static int comm_buffers(lf_ctx *c, int world, int max_kf) {
   const size_t rows = (size_t)c->fc.line_cap + 1;
+  // the slot list cached on the host describes the PREVIOUS d_xslots: a communicator that is set up again starts without it
+  c->h_xslots.clear();
+  if (c->d_xsend && c->xbuf_world == world && c->xbuf_max_kf == max_kf) { c->comm_max_kf = max_kf; return LF_OK; }   // same geometry: keep the buffers
+  if (c->d_xsend) {
+    (void)hipStreamSynchronize(c->stream);
+    free_tracked(c, c->d_xsend); free_tracked(c, c->d_xrecv); free_tracked(c, c->d_xnlines); free_tracked(c, c->d_xids); free_tracked(c, c->d_xslots);
+    c->d_xsend = nullptr; c->d_xrecv = nullptr; c->d_xnlines = nullptr; c->d_xids = nullptr; c->d_xslots = nullptr;
+  }
+  c->xbuf_world = world; c->xbuf_max_kf = max_kf;
   ALLOC(c, c->d_xsend, (size_t)max_kf * rows);
   ALLOC(c, c->d_xrecv, (size_t)world * max_kf * rows);
   ALLOC(c, c->d_xnlines, (size_t)world * max_kf);
@@ -1408,6 +1424,7 @@ int lf_comm_destroy(lf_ctx *c) {
     (void)rccl().CommDestroy(c->comm);
   }
   c->comm = nullptr; c->comm_owner = false;
+  c->h_xslots.clear();
   return LF_OK;
 }
 int lf_allgather_keyframes(lf_ctx *c, const int32_t *kf_slots, int n_kf, uint64_t id_offset, const lf_line_record **d_recs,

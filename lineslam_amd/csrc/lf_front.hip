@@ -1091,9 +1091,10 @@ __device__ bool f_clipline(int w, int h, long long *px1, long long *py1, long lo
   return (c1 | c2) == 0;
 }
 
-#define MSLD_TILE 64
+#define MSLD_SPP 7   // samples per pass: 7 x 9 sub-regions on 63 lanes
+__device__ const double k_msld_gauss[9] = {0.24142, 0.30046, 0.35127, 0.38579, 0.39804, 0.38579, 0.35127, 0.30046, 0.24142};   // utils.cpp:1560
 __global__ void __launch_bounds__(64) k_describe(FrontConsts c, FrontBuffers b) {
-  __shared__ double G[(MSLD_TILE / 2) * 36];   // half a tile of sample columns at a time: 9 KB per wavefront keeps 4 waves per SIMD resident
+  __shared__ double G[MSLD_SPP * 36];
   const int li = blockIdx.x, f = blockIdx.y, lane = f_lane();
   int nl = b.nlines[f];
   if (nl > c.line_cap) nl = c.line_cap;
@@ -1138,7 +1139,6 @@ __global__ void __launch_bounds__(64) k_describe(FrontConsts c, FrontBuffers b) 
   const int s = (int)(5 * W / 800.0);
   const double sd = (double)s, step = c.P.msld_sample_interval;
   const double len = lf_sqrt((p0 - q0) * (p0 - q0) + (p1 - q1) * (p1 - q1));
-  const double gauss[9] = {0.24142, 0.30046, 0.35127, 0.38579, 0.39804, 0.38579, 0.35127, 0.30046, 0.24142};
   // number of sample indices i with i*step < len
   int ntot = 0;
   if (len > 0 && step > 0) {
@@ -1148,54 +1148,54 @@ __global__ void __launch_bounds__(64) k_describe(FrontConsts c, FrontBuffers b) 
   }
   double sum = 0, sum2 = 0;   // lanes 0..35: running sums of component `lane`
   int nvalid = 0;
-  for (int i0 = 0; i0 < ntot; i0 += MSLD_TILE) {
-    int i = i0 + lane;
-    bool ok = i < ntot;
-    double col[36];
+  // One lane per (sample, sub-region): MSLD_SPP = 7 samples x 9 sub-regions per pass (lane 63 idles).  A lane keeps the four
+  // sums of ITS sub-region only (computeSubPSR, utils.cpp:1510-1542) and writes them straight into the LDS tile of the pass
+  // -- no per-lane 36-entry column, no scratch.  A sample counts only if all nine of its sub-regions lie inside the image
+  // (the reference breaks out of the sample otherwise): nine-bit groups of one ballot.  Accumulator lane c then adds
+  // component c of the valid samples in sample order.
+  const int sidx = lane / 9, jj = lane - 9 * sidx, j = jj - 4;
+  const double gw = (lane < 36) ? k_msld_gauss[lane >> 2] : 0.0;
+  for (int i0 = 0; i0 < ntot; i0 += MSLD_SPP) {
+    const int i = i0 + sidx;
+    bool ok = lane < 9 * MSLD_SPP && i < ntot;
+    double tl_x = 0, tl_y = 0;
     if (ok) {
       double t = (i * step / len);
       double ptx = p0 + (q0 - p0) * t, pty = p1 + (q1 - p1) * t;
-      for (int j = -4; j <= 4 && ok; ++j) {   // computeSubPSR (utils.cpp:1510-1542)
-        double px = ptx + r0 * (j * s), py = pty + r1 * (j * s);
-        double tl_x = __builtin_floor(px - sd / 2), tl_y = __builtin_floor(py - sd / 2);
-        if (tl_x < 0 || tl_y < 0 || tl_x + sd + 1 > W || tl_y + sd + 1 > H || !(tl_x == tl_x) || !(tl_y == tl_y)) { ok = false; break; }
-        double v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-        for (int y = (int)tl_y; y < tl_y + sd; ++y)
-          for (int x = (int)tl_x; x < tl_x + sd; ++x) {
-            const uint32_t gv = gxy[y * W + x];
-            double xg = (double)(int16_t)(gv & 0xffffu), yg = (double)(int16_t)(gv >> 16);
-            double tmp1 = xg * r0 + yg * r1;
-            double tmp2 = xg * (-r1) + yg * r0;
-            if (tmp1 >= 0) v1 = v1 + tmp1; else v2 = v2 - tmp1;
-            if (tmp2 >= 0) v3 = v3 + tmp2; else v4 = v4 - tmp2;
-          }
-        col[(j + 4) * 4 + 0] = v1; col[(j + 4) * 4 + 1] = v2; col[(j + 4) * 4 + 2] = v3; col[(j + 4) * 4 + 3] = v4;
-      }
+      double px = ptx + r0 * (j * s), py = pty + r1 * (j * s);
+      tl_x = __builtin_floor(px - sd / 2); tl_y = __builtin_floor(py - sd / 2);
+      if (tl_x < 0 || tl_y < 0 || tl_x + sd + 1 > W || tl_y + sd + 1 > H || !(tl_x == tl_x) || !(tl_y == tl_y)) ok = false;
     }
-    u64 mv = __ballot(ok);
-    const int slot = __popcll(mv & f_lt()), cnt = __popcll(mv);
-    // the valid samples' columns pass through LDS in two halves (slots 0..31, then 32..63); accumulator lane c adds
-    // component c of the samples in slot order
+    const u64 mv = __ballot(ok);
+    unsigned vs = 0;                                       // valid samples of this pass (uniform)
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-      const int s0 = half * (MSLD_TILE / 2);
-      if (s0 >= cnt) break;
-      if (ok && slot >= s0 && slot < s0 + MSLD_TILE / 2) {
-#pragma unroll
-        for (int k = 0; k < 36; k++) G[(slot - s0) * 36 + k] = col[k];
-      }
-      f_sync();
-      const int m = min(cnt - s0, MSLD_TILE / 2);
-      if (lane < 36) {
-        double gw = gauss[lane / 4];
-        for (int j = 0; j < m; j++) {
-          double v = G[j * 36 + lane] * gw;
-          sum += v;
-          sum2 += v * v;
+    for (int k = 0; k < MSLD_SPP; k++) vs |= (unsigned)(((mv >> (9 * k)) & 0x1ffull) == 0x1ffull) << k;
+    const int cnt = __popc(vs);
+    if (cnt == 0) continue;
+    if (lane < 9 * MSLD_SPP && ((vs >> sidx) & 1u)) {
+      const int slot = __popc(vs & ((1u << sidx) - 1u));
+      double v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+      for (int y = (int)tl_y; y < tl_y + sd; ++y)
+        for (int x = (int)tl_x; x < tl_x + sd; ++x) {
+          const uint32_t gv = gxy[y * W + x];
+          double xg = (double)(int16_t)(gv & 0xffffu), yg = (double)(int16_t)(gv >> 16);
+          double tmp1 = xg * r0 + yg * r1;
+          double tmp2 = xg * (-r1) + yg * r0;
+          if (tmp1 >= 0) v1 = v1 + tmp1; else v2 = v2 - tmp1;
+          if (tmp2 >= 0) v3 = v3 + tmp2; else v4 = v4 - tmp2;
         }
-      }
-      f_sync();
+      double *g = &G[slot * 36 + jj * 4];
+      g[0] = v1; g[1] = v2; g[2] = v3; g[3] = v4;
     }
+    f_sync();
+    if (lane < 36) {
+      for (int q = 0; q < cnt; q++) {
+        double v = G[q * 36 + lane] * gw;
+        sum += v;
+        sum2 += v * v;
+      }
+    }
+    f_sync();
     nvalid += cnt;
   }
   double *des = R->des;

@@ -7,6 +7,8 @@ TUM intrinsics K = (525, 525, 319.5, 239.5) (src/openni_listener.cpp:1256-1259) 
   * a float32 depth map in metres, quantised to 1/5000 m like TUM PNGs (:1236-1244), with
     NaN holes (0 -> NaN, as loadRawData does).
 """
+import os
+
 import numpy as np
 
 K_TUM = np.array([[525.0, 0.0, 319.5], [0.0, 525.0, 239.5], [0.0, 0.0, 1.0]])
@@ -149,32 +151,99 @@ def render(scene, T_wc, K=K_TUM, w=640, h=480, noise_seed=0, noise_sigma=2.0, ho
     return np.clip(np.rint(img), 0, 255).astype(np.uint8), depth
 
 
-def sequence(n_frames, seed=0, fps=30.0, w=640, h=480, n_unique=None):
+_scene_cache = {}
+
+
+def _clean_frame(args):
+    """noise-free render of pose i of sequence `seed` (worker of sequence(); the scene is built once per process)"""
+    seed, i, fps, w, h = args
+    if seed not in _scene_cache:
+        _scene_cache[seed] = make_scene(seed)
+    T = camera_pose(i / fps, seed)
+    g, d = render(_scene_cache[seed], T, w=w, h=h, noise_seed=seed * 100003 + i, noise_sigma=0.0, hole_frac=0.0)
+    return g, d, T
+
+
+def _noisy_frame(g, d, seed, i):
+    rng = np.random.default_rng(seed * 7919 + i)
+    gi = np.clip(np.rint(g.astype(np.float64) + rng.normal(0.0, 2.0, g.shape)), 0, 255).astype(np.uint8)
+    di = d.copy()
+    di[rng.random(d.shape) < 0.05] = np.nan
+    return gi, di
+
+
+def _full_frame(args):
+    g, d, T = _clean_frame(args)
+    gi, di = _noisy_frame(g, d, args[0], args[1])
+    return gi, di, T
+
+
+def _render_range(lo, hi, seed, fps, w, h, full, out):
+    """worker process of _render_parallel: poses lo .. hi-1 into one .npz"""
+    fr = [(_full_frame if full else _clean_frame)((seed, i, fps, w, h)) for i in range(lo, hi)]
+    np.savez(out, g=np.stack([f[0] for f in fr]), d=np.stack([f[1] for f in fr]), T=np.stack([f[2] for f in fr]))
+
+
+def _render_parallel(jobs, full, workers):
+    """The poses split into contiguous ranges, one plain child interpreter per range (no fork of a process that may hold a
+    HIP context, no re-import of the caller's __main__), results through a temporary directory."""
+    import subprocess
+    import sys
+    import tempfile
+    seed, _, fps, w, h = jobs[0]
+    n = len(jobs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory(prefix="lf_synth_") as tmp:
+        procs = []
+        for k in range(workers):
+            lo, hi = n * k // workers, n * (k + 1) // workers
+            if lo == hi:
+                continue
+            out = os.path.join(tmp, "r%03d.npz" % k)
+            code = "import sys; sys.path.insert(0, %r); from lineslam_amd import synth; synth._render_range(%d, %d, %d, %r, %d, %d, %r, %r)" % (
+                root, lo, hi, seed, fps, w, h, bool(full), out)
+            env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+            procs.append((subprocess.Popen([sys.executable, "-c", code], env=env), out))
+        clean = []
+        for p, out in procs:
+            if p.wait() != 0:
+                raise RuntimeError("synthetic frame renderer failed")
+            z = np.load(out)
+            clean += [(z["g"][i], z["d"][i], z["T"][i]) for i in range(len(z["g"]))]
+    return clean
+
+
+def sequence(n_frames, seed=0, fps=30.0, w=640, h=480, n_unique=None, workers=None):
     """Frames of a synthetic sequence: returns (gray [n,h,w] u8, depth [n,h,w] f32, poses [n,4,4]).
     With n_unique < n_frames only n_unique camera poses are ray-cast; the remaining frames reuse the
     geometry of frame (i mod n_unique) with fresh sensor noise and holes (cheap to generate, still
-    distinct inputs).  The pose index ping-pongs (0..nu-1..0..) so frame i and i+1 are always adjacent."""
-    scene = make_scene(seed)
+    distinct inputs).  The pose index ping-pongs (0..nu-1..0..) so frame i and i+1 are always adjacent.
+    workers > 1 (default: the cores this process may run on, capped at 32, once 32 or more poses are ray-cast; LF_SYNTH_WORKERS overrides):
+    the poses are rendered by child interpreters -- same frames, bit for bit, as the serial loop."""
     nu = n_frames if n_unique is None else min(n_unique, n_frames)
     gray = np.zeros((n_frames, h, w), np.uint8)
     depth = np.zeros((n_frames, h, w), np.float32)
     poses = np.zeros((n_frames, 4, 4))
-    clean = []
-    for i in range(nu):
-        T = camera_pose(i / fps, seed)
-        g, d = render(scene, T, w=w, h=h, noise_seed=seed * 100003 + i, noise_sigma=0.0, hole_frac=0.0)
-        clean.append((g, d, T))
+    if workers is None:
+        workers = int(os.environ.get("LF_SYNTH_WORKERS", "0")) or (min(32, len(os.sched_getaffinity(0))) if nu >= 32 else 1)
+    jobs = [(seed, i, fps, w, h) for i in range(nu)]
+    all_unique = nu == n_frames
+    if workers > 1 and nu > 1:
+        clean = _render_parallel(jobs, all_unique, min(workers, nu))
+    else:
+        clean = [(_full_frame if all_unique else _clean_frame)(j) for j in jobs]
+    if all_unique:
+        for i, (g, d, T) in enumerate(clean):
+            gray[i], depth[i], poses[i] = g, d, T
+        return gray, depth, poses
     for i in range(n_frames):
         # ping-pong over the ray-cast poses so that consecutive frames are always neighbours in time
         j = i % (2 * nu - 2) if nu > 1 else 0
         if j >= nu:
             j = 2 * nu - 2 - j
         g, d, T = clean[j]
-        rng = np.random.default_rng(seed * 7919 + i)
-        gi = np.clip(np.rint(g.astype(np.float64) + rng.normal(0.0, 2.0, g.shape)), 0, 255).astype(np.uint8)
-        di = d.copy()
-        di[rng.random(d.shape) < 0.05] = np.nan
-        gray[i], depth[i], poses[i] = gi, di, T
+        gray[i], depth[i] = _noisy_frame(g, d, seed, i)
+        poses[i] = T
     return gray, depth, poses
 
 

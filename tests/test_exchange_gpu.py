@@ -58,6 +58,21 @@ def test_library_exchange_equals_the_torch_carrier(built_lib):
             rr = [ctx.pair_result(i, allow_overflow=True) for i in range(3)]    # (slot 2 is the query frame itself: > match_cap matches)
             res.append([(r.n_matches, r.n_inliers, r.overflow, bytes(r.T)) for r in rr])
         assert res[0] == res[1]
+        # a communicator that is torn down and set up again (other capacity, then the first one) must not reuse the slot
+        # list cached for the buffers of the previous one: the same key frames come back byte for byte
+        want = [torch.as_tensor(capi._DevArray(la[k], (3,), t), device="cuda").cpu().numpy().copy() for k, t in ((1, "<i4"), (2, "<i8"))]
+        for max_kf in (5, 3):
+            ctx.comm_destroy()
+            ctx.comm_init(1, 0, capi.comm_unique_id(), max_keyframes=max_kf)
+            lb = ctx.allgather_keyframes(kf, 100000)
+            ctx.synchronize()
+            got_n = torch.as_tensor(capi._DevArray(lb[1], (3,), "<i4"), device="cuda").cpu().numpy()
+            got_i = torch.as_tensor(capi._DevArray(lb[2], (3,), "<i8"), device="cuda").cpu().numpy()
+            assert np.array_equal(got_n, want[0]) and np.array_equal(got_i, want[1]), max_kf
+            blob = torch.as_tensor(capi._DevArray(lb[0] - parallel.REC_BYTES, (3, rows), "|u1"), device="cuda").cpu().numpy()
+            for s in range(3):
+                nb = (1 + int(nl[s])) * parallel.REC_BYTES
+                assert np.array_equal(blob[s, :nb], tor_blob[s, :nb]), (max_kf, s)
         ctx.close()
     finally:
         dist.destroy_process_group()

@@ -174,3 +174,56 @@ def test_hybrid_over_point_match_counts(built_lib, seq, npm, nlines):
     assert np.array_equal(ctx2.pair_point_inliers(0), pinl) and np.array_equal(ctx2.pair_inliers(0), linl)
     assert np.float32(r.rmse) == np.float32(rmse)
     ctx2.close()
+
+
+def test_solve_pairs_device_at_and_over_the_match_capacities(built_lib, seq):
+    """lf_solve_pairs_device (getTransform_PtsLines_ransac with the CALLER's matches) at the compiled maxima of the default
+    context -- 256 line matches, 512 point matches: accepted and solved -- and one past either: LF_ERR_CAPACITY before
+    anything is enqueued (the reference's vectors are unbounded; a silent cut would change the pose)."""
+    import torch
+    from lineslam_amd import capi
+    ctx, recs, poses, P, ids, pts, dpts = seq
+    caps = capi.default_caps()
+    assert (caps.match_cap, caps.pt_match_cap) == (256, 512)
+    rng = np.random.default_rng(77)
+    NB = 700                                                 # more landmarks than pt_match_cap
+    Pw = np.c_[rng.uniform(-1.2, 1.2, NB), rng.uniform(-0.9, 0.9, NB), rng.uniform(1.0, 3.5, NB), np.ones(NB)]
+    Pw = (poses[0] @ Pw.T).T
+    big = np.zeros((NF, NB, 4), np.float32)
+    for f in range(NF):
+        pc = (np.linalg.inv(poses[f]) @ Pw.T).T
+        big[f] = pc.astype(np.float32)
+        big[f, :, 3] = 1.0
+    dbig = torch.from_numpy(big).cuda()
+    q, t = np.array([1], np.int32), np.array([0], np.int32)
+    n1, n0 = len(recs[1]), len(recs[0])
+
+    def lm(n):                                               # n line "matches" (indices inside both maps; mostly wrong)
+        a = (np.arange(n) % n1).astype(np.int32)[None]
+        b = (np.arange(n) % n0).astype(np.int32)[None]
+        return a, b, np.array([n], np.int32)
+
+    def pm(n):
+        a = np.arange(n, dtype=np.int32)[None]
+        return a, a.copy(), np.array([n], np.int32)
+    # at the capacities: runs, nothing flagged
+    a, b, n = lm(256)
+    pa, pb, pn = pm(512)
+    ctx.solve_pairs_device(q, t, a, b, n, dbig.data_ptr(), NB, pa, pb, pn, synth.K_TUM)
+    r = ctx.pair_result(0)
+    assert r.overflow == 0 and r.n_matches == 256 and r.n_point_matches == 512
+    assert bool(r.valid) and r.n_point_inliers > 400          # the 512 exact point matches carry the pose
+    # one line match too many / one point match too many / both
+    for nl, npm in ((257, 512), (256, 513), (300, 600)):
+        a, b, n = lm(nl)
+        pa, pb, pn = pm(npm)
+        with pytest.raises(capi.LinefrontError) as e:
+            ctx.solve_pairs_device(q, t, a, b, n, dbig.data_ptr(), NB, pa, pb, pn, synth.K_TUM)
+        assert e.value.status == capi.LF_ERR_CAPACITY, (nl, npm)
+    # ... and the lines-only form of the same entry point
+    a, b, n = lm(257)
+    with pytest.raises(capi.LinefrontError) as e:
+        ctx.solve_pairs_device(q, t, a, b, n)
+    assert e.value.status == capi.LF_ERR_CAPACITY
+    # the batch the context held before is untouched by the refused calls: the accepted call still reads back
+    assert ctx.pair_result(0).n_point_matches == 512

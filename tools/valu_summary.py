@@ -18,7 +18,7 @@ for ln in lines[1:]:
               "wave_wait_frac": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"),
               "wave_issue_stall_frac": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
               "wave_valu_frac": g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES"),
-              "valu_insts_per_dispatch": g("SQ_INSTS_VALU") / max(float(r.get("Dispatches") or 1), 1),
+              "valu_insts_per_dispatch": g("SQ_INSTS_VALU"),      # (the table of tools/sq_summary.py is already per dispatch)
               "l2_hit": hit / (hit + miss) if hit + miss > 0 else None}
 json.dump({"source": src + " (rocprofv3 --pmc SQ_* / GRBM_GUI_ACTIVE passes of one serial bench pass) " + note,
            "definition": "valu_busy_chip = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): fraction of the chip's VALU issue "
