@@ -57,7 +57,14 @@ def parse():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1147, help="frames per sequence (TUM fr3/cabinet: 1147)")
-    ap.add_argument("--unique", type=int, default=16, help="ray-cast poses per sequence (rest: fresh noise)")
+    ap.add_argument("--unique", type=int, default=256,
+                    help="ray-cast poses per sequence (the remaining frames revisit them, ping-pong, with fresh sensor noise); "
+                         "--unique 1147 renders every frame of the trajectory")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = one sequence per rank (BASELINE configs[4]); strong = ONE sequence, round-robin blocks of 64 "
+                         "frames per rank, block-boundary line maps carried by the step's one all-gather (SURVEY.md 8e)")
+    ap.add_argument("--h2d-steps", type=int, default=4,
+                    help="steps of the extra leg that starts from raw TUM frames in pinned host memory (value_including_h2d); 0 = skip")
     ap.add_argument("--keyframes", type=int, default=32, help="keyframes per rank exchanged by the all-gather")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -162,6 +169,7 @@ def main():
     # LF_BENCH_FORCE_EXCHANGE=1: run the multi-rank code path (process group, keyframe all-gather, loop-closure
     # matching against the gathered map) even with one rank -- the only way to exercise it on a 1-GPU box
     dist_on = world > 1 or os.environ.get("LF_BENCH_FORCE_EXCHANGE") == "1"
+    strong = a.scaling == "strong"
     import torch
     import torch.distributed as dist
     from lineslam_amd import ate, build, capi, parallel, synth
@@ -178,22 +186,35 @@ def main():
         build.build()
     if dist_on:
         dist.barrier()
+    if strong and a.points:
+        raise SystemExit("bench.py: --scaling strong runs the headline (lines-only) workload")
     P = capi.default_params(launch=not a.default_params)
     if a.detector == "edlines":
         P.line_detector = 1
-    F = a.frames
-    gray, depth, poses = synth.sequence(F, seed=2 + rank, n_unique=a.unique)
+    FT = a.frames                                        # frames of one sequence
+    gray, depth, poses = synth.sequence(FT, seed=2 if strong else 2 + rank, n_unique=a.unique)
+    plan = None
+    if strong:
+        # ONE sequence: this rank's round-robin blocks (node id == global frame index on every rank)
+        plan = parallel.strong_plan(FT, world, rank, block=max(1, min(64, FT // world)))
+        gray_all, depth_all = gray, depth
+        gray, depth = np.ascontiguousarray(gray[plan["frames"]]), np.ascontiguousarray(depth[plan["frames"]])
+    F = len(gray)                                        # frames this rank processes per step
     nfl = max(1, a.inflight)
     streams = [torch.cuda.Stream() for _ in range(nfl)]
     ctxs = [capi.Context(640, 480, max_batch=F, params=P, device=local, stream=st.cuda_stream) for st in streams]
     ctx = ctxs[0]
     dg, dd = torch.from_numpy(gray).cuda(), torch.from_numpy(depth).cuda()
     torch.cuda.synchronize()
-    ids = np.arange(F, dtype=np.uint64)
-    pq, pt = np.arange(1, F, dtype=np.int32), np.arange(0, F - 1, dtype=np.int32)
+    if strong:
+        ids = plan["frames"].astype(np.uint64)
+        pq, pt = plan["pair_q"], plan["pair_t"]
+    else:
+        ids = np.arange(F, dtype=np.uint64)
+        pq, pt = np.arange(1, F, dtype=np.int32), np.arange(0, F - 1, dtype=np.int32)
     K = synth.K_TUM
     # keyframe line maps for the loop-closure exchange (config 5): fixed-stride records, one all-gather per step
-    kf = parallel.pick_keyframes(F, a.keyframes) if dist_on else None
+    kf = (plan["kf_local"] if strong else parallel.pick_keyframes(F, a.keyframes)) if dist_on else None
 
     pts_state = None
     if a.points:
@@ -210,6 +231,9 @@ def main():
 
     n_lc = min(64, F)   # loop-closure queries per step on every rank (config 4 style: local frames vs all keyframes)
     lc_q, lc_t = parallel.loop_closure_pairs(n_lc, F - 1, world, len(kf)) if dist_on else (None, None)
+    if strong and dist_on:
+        lc_q, lc_t = plan["bnd_q"], plan["bnd_t"]         # the block-boundary odometry pairs against the gathered map
+    kf_id_offset = 0 if strong else 100000 * (rank + 1)
     exch, carrier = {}, a.exchange
     if dist_on:
         # node ids of different ranks far apart (loop closures, never "adjacent"); ONE all-gather per step and context
@@ -231,7 +255,7 @@ def main():
                 uid = [capi.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
                 for c in ctxs:
-                    exch[id(c)] = parallel.KeyframeExchange(c, torch, dist, world, rank, kf, 100000 * (rank + 1), "lib",
+                    exch[id(c)] = parallel.KeyframeExchange(c, torch, dist, world, rank, kf, kf_id_offset, "lib",
                                                             comm_owner=ctxs[0] if c is not ctxs[0] else None, unique_id=uid[0])
             except capi.LinefrontError as e:
                 if world > 1:
@@ -240,7 +264,7 @@ def main():
                 carrier, exch = "torch", {}
         if carrier == "torch":
             for c in ctxs:
-                exch[id(c)] = parallel.KeyframeExchange(c, torch, dist, world, rank, kf, 100000 * (rank + 1), "torch")
+                exch[id(c)] = parallel.KeyframeExchange(c, torch, dist, world, rank, kf, kf_id_offset, "torch")
 
     def step(i):
         ctx = ctxs[i % nfl]
@@ -268,7 +292,8 @@ def main():
         if dist_on:
             # RCCL over xGMI: the key-frame line maps of all ranks, then loop-closure candidates against the gathered map
             r_ptr, n_ptr, i_ptr, n_slots, ext_cap = exch[id(ctx)].exchange()
-            ctx.match_external_device(lc_q, lc_t, r_ptr, n_ptr, i_ptr, n_slots, ext_cap)
+            if len(lc_q):
+                ctx.match_external_device(lc_q, lc_t, r_ptr, n_ptr, i_ptr, n_slots, ext_cap)
             return n_slots
         return None
 
@@ -309,20 +334,95 @@ def main():
         dts = time.perf_counter() - ts
         serial = {"value": F * ks / dts, "ms_per_step": dts / ks * 1e3, "steps": ks,
                   "stage_ms": {k: float(np.mean(v)) for k, v in sst.items()}}
+    # the same workload starting from RAW TUM frames in pinned host memory (8-bit RGB + 16-bit depth, 1.54 MB per frame):
+    # host -> device copy, the pixel conversions of loadRawData (k_ingest_tum), then the step as above, every step, inside the
+    # timed region, on the same streams (not `value`: BASELINE's metric is quoted with the inputs resident in HBM)
+    h2d = None
+    if a.h2d_steps > 0 and world == 1 and not dist_on and not a.points and rank == 0:
+        rgb_h = torch.from_numpy(np.repeat(gray[..., None], 3, axis=-1)).pin_memory()
+        d16_h = torch.from_numpy(np.rint(np.nan_to_num(depth, nan=0.0).astype(np.float64) * 5000.0).astype(np.uint16).view(np.int16)).pin_memory()
+        raw = [(torch.empty(rgb_h.shape, dtype=torch.uint8, device="cuda"), torch.empty(d16_h.shape, dtype=torch.int16, device="cuda"),
+                torch.empty((F, 480, 640), dtype=torch.uint8, device="cuda"), torch.empty((F, 480, 640), dtype=torch.float32, device="cuda"))
+               for _ in range(nfl)]
+
+        def step_h2d(i):
+            c = ctxs[i % nfl]
+            r_d, z16_d, g_d, z_d = raw[i % nfl]
+            with torch.cuda.stream(streams[i % nfl]):
+                r_d.copy_(rgb_h, non_blocking=True)
+                z16_d.copy_(d16_h, non_blocking=True)
+                c.ingest_tum_device(r_d.data_ptr(), z16_d.data_ptr(), F, g_d.data_ptr(), z_d.data_ptr())
+                c.detect3d_batch_device(g_d.data_ptr(), z_d.data_ptr(), F, K, ids)
+                c.match_pairs_device(pq, pt)
+        for i in range(nfl):
+            step_h2d(i)
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for i in range(a.h2d_steps):
+            step_h2d(i)
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - th
+        same_gray = bool(torch.equal(raw[0][2], dg))      # grey of a grey RGB triple == the grey image (CV_RGB2GRAY weights sum to 1)
+        h2d = {"value": F * a.h2d_steps / dth, "ms_per_step": dth / a.h2d_steps * 1e3, "steps": a.h2d_steps,
+               "host_bytes_per_frame": int(rgb_h[0].numel() + 2 * d16_h[0].numel()), "ingested_grey_equals_input": same_gray,
+               "note": "pinned host RGB + 16-bit depth -> hipMemcpyAsync -> k_ingest_tum -> the step; copies of one pass overlap the kernels of the others"}
+        del raw, rgb_h, d16_h
     if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / a.steps * 1e3
-    value = world * F * a.steps / dt
+    value = (FT if strong else world * F) * a.steps / dt
 
     out = None
+    strong_info = None
+    if strong:
+        # the ONE sequence's trajectory from all ranks (untimed): every rank reads back its internal pairs, then the block-
+        # boundary pairs solved against the gathered map; rank 0 assembles them in frame order and holds them against the
+        # same sequence run on one context alone (pairs 1..F-1 vs 0..F-2): the bytes must be identical.
+        import types
+
+        def grab(n):
+            rr = [ctx.pair_result(i, allow_overflow=True) for i in range(n)]
+            return [(bytes(bytearray(np.array(list(r.T), np.float32).tobytes())), int(r.valid), int(r.overflow), int(r.n_matches), int(r.n_inliers)) for r in rr]
+        if len(pq):
+            ctx.match_pairs_device(pq, pt)
+        mine_i = grab(len(pq))
+        mine_b = []
+        if dist_on and len(lc_q):
+            r_ptr, n_ptr, i_ptr, n_slots, ext_cap = exch[id(ctx)].exchange()
+            ctx.match_external_device(lc_q, lc_t, r_ptr, n_ptr, i_ptr, n_slots, ext_cap)
+            mine_b = grab(len(lc_q))
+        elif dist_on:
+            exch[id(ctx)].exchange()                      # (collective: every rank takes part)
+        if dist_on and world > 1:
+            gi, gb = [None] * world, [None] * world
+            dist.all_gather_object(gi, mine_i)
+            dist.all_gather_object(gb, mine_b)
+        else:
+            gi, gb = [mine_i], [mine_b]
+        if rank == 0:
+            blk = max(1, min(64, FT // world))
+            traj = parallel.strong_assemble(FT, [parallel.strong_plan(FT, world, r, blk) for r in range(world)], gi, gb)
+            full = capi.Context(640, 480, max_batch=FT, params=P, device=local)
+            fg, fd = torch.from_numpy(gray_all).cuda(), torch.from_numpy(depth_all).cuda()
+            full.detect3d_batch_device(fg.data_ptr(), fd.data_ptr(), FT, K, np.arange(FT, dtype=np.uint64))
+            full.match_pairs_device(np.arange(1, FT, dtype=np.int32), np.arange(0, FT - 1, dtype=np.int32))
+            one = [full.pair_result(i, allow_overflow=True) for i in range(FT - 1)]
+            same = sum(t[0] == np.array(list(r.T), np.float32).tobytes() and t[1] == int(r.valid) and t[3] == r.n_matches and t[4] == r.n_inliers
+                       for t, r in zip(traj, one))
+            full.close()
+            del fg, fd
+            strong_info = {"pairs_identical_to_one_rank_run": int(same), "pairs": FT - 1, "blocks_of": blk,
+                           "boundary_pairs_through_the_all_gather": int(sum(len(b) for b in gb))}
+            res_strong = [types.SimpleNamespace(T=np.frombuffer(t[0], np.float32).tolist(), valid=t[1], overflow=t[2], n_matches=t[3], n_inliers=t[4],
+                                                n_point_matches=0, n_point_inliers=0) for t in traj]
     if rank == 0:
         # result quality on this rank's sequence: odometry chain vs ground truth.  With the exchange enabled the
         # pair slots hold the loop-closure results of the last step: run the odometry pairs once more (untimed).
-        if dist_on and not a.points:
+        if dist_on and not a.points and not strong:
             ctx.match_pairs_device(pq, pt)
-        res = [ctx.pair_result(i, allow_overflow=True) for i in range(F - 1)]
+        res = res_strong if strong else [ctx.pair_result(i, allow_overflow=True) for i in range(F - 1)]
         valid = np.array([r.valid for r in res], bool)
         Ts = [np.array(list(r.T), np.float64).reshape(4, 4) for r in res]
         est = ate.chain_odometry(Ts, valid)
@@ -358,19 +458,22 @@ def main():
         out = {
             "metric": "RGB-D frames/sec (detect+match+pose) at 640\u00d7480; ATE vs reference", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("fused point + line odometry (BASELINE configs[2]) on a %d-frame 640x480 sequence: front end as "
                                     "below + ORB extraction (600 key points), projectTo3D, Hamming feature matching, hybrid RANSAC / LM" % F)
                        if a.points else
                                    "TUM fr3/cabinet-length sequence (%d frames, 640x480), lines-only odometry: "
                                    "%s + 3D line fit + MSLD + MLE per frame, line matching + 3-line RANSAC + LM "
                                    "pose vs predecessor; synthetic seeded RGB-D (lineslam_amd/synth.py)" %
-                                   (F, "EDLines (line_detect_algorithm = EDLINES, not the headline configuration)" if a.detector == "edlines" else "LSD"),
-                       "frames_per_gpu": F, "params": "ParameterServer defaults" if a.default_params else "launch/lineslam.launch (lsd_angle_thres 40, min_matches 10)",
+                                   (FT, "EDLines (line_detect_algorithm = EDLINES, not the headline configuration)" if a.detector == "edlines" else "LSD"),
+                       "frames_per_gpu": F, "ray_cast_poses": min(a.unique, FT),
+                       "sequence": "%d frames at 30 Hz along one smooth hand-held trajectory; %d ray-cast poses%s" % (
+                           FT, min(a.unique, FT), "" if a.unique >= FT else " revisited ping-pong (consecutive frames are always neighbours in time) with fresh sensor noise and depth holes per frame"), "params": "ParameterServer defaults" if a.default_params else "launch/lineslam.launch (lsd_angle_thres 40, min_matches 10)",
                        "lines_per_frame": nlines, "passes_in_flight": nfl,
                        "parallelism": "frames in flight: one wavefront per frame (LSD sweep), "
                        "per segment (3D fit), per pair (pose); %d passes in flight on separate HIP streams" % nfl +
-                       ("; %d ranks, 1 sequence each, 1 all-gather of %d key-frame maps per step (%s carrier)" % (world, len(kf), carrier) if dist_on else "")},
+                       (("; %d ranks share ONE sequence in round-robin blocks, 1 all-gather of %d block-boundary line maps per rank and step (%s carrier)" if strong else
+                         "; %d ranks, 1 sequence each, 1 all-gather of %d key-frame maps per step (%s carrier)") % (world, len(kf), carrier) if dist_on else "")},
             "roofline": {"bound": "hbm", "kernel": "k_lsd_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": sw, "algorithmic_bytes_per_launch": algo,
@@ -387,15 +490,16 @@ def main():
                                  "duration in the timed region, where it shares the chip with the other passes in flight"},
             "stage_ms": {"lsd_data_parallel": float(np.mean(pre_ms)), "lsd_sweep": sw,
                          "lines3d_msld_mle": float(np.mean(front_ms)), "match_pose": float(np.mean(pair_ms))},
-            "serial": serial, "points": point_stats,
+            "serial": serial, "value_including_h2d": (h2d or {}).get("value"), "including_h2d": h2d,
+            "points": point_stats, "strong_scaling": strong_info,
             "quality": {"valid_pairs": int(valid.sum()), "pairs": int(len(valid)), "pairs_over_a_capacity": n_over,
                         "ate_rmse_m_vs_ground_truth": ate.ate_rmse(est[:, :3, 3], gt[:, :3, 3])},
         }
         if a.detector == "edlines" and not a.no_cpu:
             print("bench: --detector edlines: the cpu_baseline leg times the LSD configuration only; skipped", file=sys.stderr)
         if not a.no_cpu and a.detector != "edlines":
-            ncpu = a.cpu_frames or max(16, min(F, 6 * (os.cpu_count() or 1)))
-            out["cpu_baseline"] = cpu_baseline(gray, depth, P, ncpu)   # (lines-only CPU path, also next to --points)
+            ncpu = a.cpu_frames or max(16, min(FT, 6 * (os.cpu_count() or 1)))
+            out["cpu_baseline"] = cpu_baseline(gray_all if strong else gray, depth_all if strong else depth, P, ncpu)   # (lines-only CPU path, also next to --points)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
             # ATE of the GPU odometry chain against the CPU path's chain over the sampled frames (the CPU side uses
             # libm, the GPU lf_math.h: the poses agree to float rounding, not bit for bit)

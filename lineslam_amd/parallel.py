@@ -29,6 +29,53 @@ def shard_frames(n_frames, world, rank, block=64):
     return np.asarray(out, np.int64)
 
 
+def strong_plan(n_frames, world, rank, block=64):
+    """ONE sequence on `world` ranks (strong scaling): round-robin blocks of `block` consecutive frames
+    (shard_frames); node id == global frame index on every rank.  The odometry pair (i, i-1) is solved by the owner of the
+    NEWER frame i: inside a block both line maps are local; for the first frame of a block the predecessor is the last frame of
+    the previous block, which its owner (another rank when world > 1) contributes as a key frame to the step's ONE all-gather.  Every rank contributes the
+    same number K of key frames (the last frame of each of its blocks; ranks with fewer blocks repeat their last one).
+    Returns a dict:
+      frames      [n]   global indices of the rank's frames, ascending (local slot j holds frame frames[j])
+      pair_q/t    [m]   local slots of the pairs whose two frames are both local (query = newer)
+      kf_local    [K]   local slots of the key frames this rank sends
+      bnd_q       [b]   local slots of the block-first frames (global index > 0)
+      bnd_t       [b]   slot of their predecessor in the gathered map (owner * K + index)
+      K                 key frames per rank"""
+    nblk = (n_frames + block - 1) // block
+    K = max(1, (nblk + world - 1) // world)
+    frames = shard_frames(n_frames, world, rank, block)
+    local = {int(g): j for j, g in enumerate(frames)}
+    pq = [local[int(g)] for g in frames if int(g) - 1 in local]
+    pair_q = np.asarray(pq, np.int32)
+    pair_t = pair_q - 1
+    mine = [b for b in range(nblk) if b % world == rank]
+    last = [local[min(n_frames, (b + 1) * block) - 1] for b in mine]
+    kf_local = np.asarray((last + [last[-1]] * K)[:K] if last else [0] * K, np.int32)
+    bq, bt = [], []
+    for b in mine:
+        if b == 0 or b * block - 1 in local:           # (one rank: every predecessor is local)
+            continue
+        owner, idx = (b - 1) % world, (b - 1) // world
+        bq.append(local[b * block]); bt.append(owner * K + idx)
+    return dict(frames=frames, pair_q=pair_q, pair_t=pair_t, kf_local=kf_local, bnd_q=np.asarray(bq, np.int32),
+                bnd_t=np.asarray(bt, np.int32), K=K)
+
+
+def strong_assemble(n_frames, plans, internal, boundary):
+    """The trajectory of the whole sequence from the ranks' results: plans[r] = strong_plan(...), internal[r][k] / boundary[r][k]
+    = whatever the solver returned for pair k of pair_q / bnd_q (any object).  Returns the list of n_frames - 1 results in
+    frame order (entry i-1 = pair (i, i-1)) -- what one rank alone produces with pairs (1..n-1, 0..n-2)."""
+    out = [None] * (n_frames - 1)
+    for pl, ri, rb in zip(plans, internal, boundary):
+        for k, q in enumerate(pl["pair_q"]):
+            out[int(pl["frames"][q]) - 1] = ri[k]
+        for k, q in enumerate(pl["bnd_q"]):
+            out[int(pl["frames"][q]) - 1] = rb[k]
+    assert all(o is not None for o in out)
+    return out
+
+
 def pick_keyframes(n_frames, n_key):
     return np.linspace(0, n_frames - 1, n_key).astype(np.int64)
 

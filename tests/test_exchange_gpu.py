@@ -88,3 +88,69 @@ def test_bench_multi_rank_path_with_one_rank(built_lib, carrier):
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["quality"]["valid_pairs"] >= 35
     assert ("%s carrier" % carrier) in j["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("world,block", [(2, 8), (3, 5)])
+def test_strong_scaling_plan_emulated_ranks_reproduce_the_one_rank_trajectory(built_lib, world, block):
+    """--scaling strong on one GPU: `world` emulated ranks (one context each) share ONE sequence in round-robin blocks
+    (parallel.strong_plan); the line maps of the block-boundary frames travel in the key-frame blob (packed per rank, laid
+    rank-major as the all-gather delivers them) and the boundary pairs are solved against that external map.  Assembled in
+    frame order, the trajectory is byte-identical to the same sequence run on one context alone."""
+    import torch
+    from lineslam_amd import capi
+    F = 40
+    g, d, _ = synth.sequence(F, seed=9, n_unique=10)
+    P = capi.default_params(launch=True)
+    full = capi.Context(640, 480, max_batch=F, params=P)
+    dg, dd = torch.from_numpy(g).cuda(), torch.from_numpy(d).cuda()
+    full.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), F, synth.K_TUM, np.arange(F, dtype=np.uint64))
+    full.match_pairs_device(np.arange(1, F, dtype=np.int32), np.arange(0, F - 1, dtype=np.int32))
+    one = [full.pair_result(i) for i in range(F - 1)]
+    want = [(bytes(bytearray(r.T)), r.valid, r.n_matches, r.n_inliers, r.ransac_best_iter) for r in one]
+    assert sum(r.valid for r in one) > F // 2
+    plans = [parallel.strong_plan(F, world, r, block) for r in range(world)]
+    K = plans[0]["K"]
+    ctxs, blobs = [], []
+    for r, pl in enumerate(plans):
+        fr = pl["frames"]
+        c = capi.Context(640, 480, max_batch=len(fr), params=P)
+        gg, zz = torch.from_numpy(np.ascontiguousarray(g[fr])).cuda(), torch.from_numpy(np.ascontiguousarray(d[fr])).cuda()
+        c.detect3d_batch_device(gg.data_ptr(), zz.data_ptr(), len(fr), synth.K_TUM, fr.astype(np.uint64))    # node id = global frame index
+        c.synchronize()
+        recs_t, nl_t, ids_t = c.device_records(torch)
+        sel = torch.from_numpy(pl["kf_local"].astype(np.int64)).cuda()
+        blobs.append(parallel.pack_keyframes(torch, recs_t, nl_t, ids_t, sel, 0, c.line_cap))
+        ctxs.append(c)
+    gathered = torch.cat(blobs).contiguous()                 # rank-major: what ONE all-gather leaves on every rank
+    n_t, i_t = parallel.unpack_headers(torch, gathered)
+    n_t, i_t = n_t.contiguous(), i_t.contiguous()
+    internal, boundary = [], []
+    for c, pl in zip(ctxs, plans):
+        get = lambda n: [(bytes(bytearray(r.T)), r.valid, r.n_matches, r.n_inliers, r.ransac_best_iter) for r in (c.pair_result(i) for i in range(n))]
+        c.match_pairs_device(pl["pair_q"], pl["pair_t"])
+        internal.append(get(len(pl["pair_q"])))
+        if len(pl["bnd_q"]):
+            c.match_external_device(pl["bnd_q"], pl["bnd_t"], gathered.data_ptr() + parallel.REC_BYTES, n_t.data_ptr(), i_t.data_ptr(),
+                                    world * K, c.line_cap + 1)
+            boundary.append(get(len(pl["bnd_q"])))
+        else:
+            boundary.append([])
+    assert sum(len(b) for b in boundary) == (F + block - 1) // block - 1          # every block boundary went through the map
+    traj = parallel.strong_assemble(F, plans, internal, boundary)
+    assert traj == want
+    for c in ctxs + [full]:
+        c.close()
+
+
+def test_bench_strong_scaling_mode_one_rank(built_lib):
+    """bench.py --scaling strong (one rank: every block is local, the exchange still runs) reports the trajectory identical to
+    the plain one-context run, and the extra leg that starts from raw frames in pinned host memory."""
+    env = dict(os.environ, LF_BENCH_FORCE_EXCHANGE="1", MASTER_PORT="29549")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "72", "--unique", "8", "--steps", "3", "--warmup", "1",
+                          "--no-cpu", "--scaling", "strong"], check=True, capture_output=True, text=True, env=env, timeout=900)
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["scaling"] == "strong" and j["strong_scaling"]["pairs_identical_to_one_rank_run"] == j["strong_scaling"]["pairs"] == 71
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "48", "--unique", "8", "--steps", "3", "--warmup", "1",
+                          "--no-cpu", "--h2d-steps", "2"], check=True, capture_output=True, text=True, timeout=900)
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["value_including_h2d"] > 0 and j["including_h2d"]["ingested_grey_equals_input"] and j["config"]["ray_cast_poses"] == 8

@@ -86,3 +86,90 @@ def test_sharding_covers_everything_once():
         assert sorted(seqs) == list(range(8))
     k = parallel.pick_keyframes(1147, 32)
     assert k[0] == 0 and k[-1] == 1146 and len(np.unique(k)) == 32
+
+
+# ---------------------------------------------------------------- strong scaling (ONE sequence, round-robin blocks)
+SF, SBLK = 40, 8
+
+
+class _SeqCtx:
+    """line maps of this rank's frames of ONE shared sequence: frame f's records are a function of f alone"""
+
+    def __init__(self, frames):
+        self.line_cap = LINE_CAP
+        self.frames = frames
+        rec = [np.random.default_rng(1000 + int(f)).integers(0, 256, LINE_CAP * parallel.REC_BYTES, dtype=np.uint8) for f in frames]
+        self.recs = torch.from_numpy(np.stack(rec))
+        self.nl = torch.from_numpy(np.array([1 + int(f) % LINE_CAP for f in frames], np.int32))
+        self.ids = torch.from_numpy(np.asarray(frames, np.int64))            # node id == global frame index
+
+    def device_records(self, _torch):
+        return self.recs, self.nl, self.ids
+
+
+def _pair_digest(q_recs, q_n, q_id, t_recs, t_n, t_id):
+    """stand-in for the pair solver on the CPU: any deterministic function of the two line maps and node ids"""
+    import hashlib
+    h = hashlib.sha1()
+    h.update(q_recs[:q_n * parallel.REC_BYTES].tobytes()); h.update(t_recs[:t_n * parallel.REC_BYTES].tobytes())
+    h.update(np.array([q_id, t_id], np.int64).tobytes())
+    return h.hexdigest()
+
+
+def _strong_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pl = parallel.strong_plan(SF, world, rank, SBLK)
+    # two passes in flight, as bench.py keeps them: two contexts of the same frames, each with its own exchange object on the
+    # one process group; the host loop issues their collectives in the same order on every rank
+    ctxs = [_SeqCtx(pl["frames"]), _SeqCtx(pl["frames"])]
+    exs = [parallel.KeyframeExchange(c, torch, dist, world, rank, pl["kf_local"], 0, carrier="torch") for c in ctxs]
+    res = []
+    for rep in range(3):
+        for c, ex in zip(ctxs, exs):
+            ex.exchange()
+            allb, n, i = ex._keep
+            rows = allb.numpy().reshape(world * pl["K"], LINE_CAP + 1, parallel.REC_BYTES)
+            internal = [_pair_digest(c.recs[q].numpy(), int(c.nl[q]), int(c.ids[q]), c.recs[t].numpy(), int(c.nl[t]), int(c.ids[t]))
+                        for q, t in zip(pl["pair_q"], pl["pair_t"])]
+            boundary = [_pair_digest(c.recs[q].numpy(), int(c.nl[q]), int(c.ids[q]), rows[s, 1:].reshape(-1), int(n[s]), int(i[s]))
+                        for q, s in zip(pl["bnd_q"], pl["bnd_t"])]
+            res.append((internal, boundary))
+    assert all(r == res[0] for r in res)                          # every pass, either context: the same results
+    import pickle
+    pickle.dump(res[0], open(os.path.join(tmp, "s%d.pkl" % rank), "wb"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_one_sequence_gloo_world2(tmp_path):
+    import pickle
+    world, port = 2, _free_port()
+    mp.spawn(_strong_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [pickle.load(open(tmp_path / ("s%d.pkl" % r), "rb")) for r in range(world)]
+    plans = [parallel.strong_plan(SF, world, r, SBLK) for r in range(world)]
+    traj = parallel.strong_assemble(SF, plans, [g[0] for g in got], [g[1] for g in got])
+    # the one-rank run of the same sequence: pairs (i, i-1) for i = 1 .. SF-1 on one context
+    one = _SeqCtx(np.arange(SF))
+    want = [_pair_digest(one.recs[i].numpy(), int(one.nl[i]), i, one.recs[i - 1].numpy(), int(one.nl[i - 1]), i - 1) for i in range(1, SF)]
+    assert traj == want
+    assert sum(len(g[1]) for g in got) == SF // SBLK - 1          # the block boundaries, and only they, used the gathered map
+
+
+def test_strong_plan_covers_every_pair_once():
+    for F, W, B in ((1147, 8, 64), (1147, 4, 64), (1147, 2, 64), (1147, 1, 64), (40, 3, 8), (65, 2, 64), (64, 2, 32)):
+        plans = [parallel.strong_plan(F, W, r, B) for r in range(W)]
+        K = plans[0]["K"]
+        assert np.array_equal(np.sort(np.concatenate([p["frames"] for p in plans])), np.arange(F))
+        slot = {r * K + k: int(p["frames"][l]) for r, p in enumerate(plans) for k, l in enumerate(p["kf_local"])}
+        newer = []
+        for p in plans:
+            assert len(p["kf_local"]) == K
+            for q, t in zip(p["pair_q"], p["pair_t"]):
+                assert p["frames"][q] - 1 == p["frames"][t]
+                newer.append(int(p["frames"][q]))
+            for q, t in zip(p["bnd_q"], p["bnd_t"]):
+                assert slot[int(t)] == p["frames"][q] - 1
+                newer.append(int(p["frames"][q]))
+        assert sorted(newer) == list(range(1, F))
