@@ -506,7 +506,11 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
 // lane-parallel; J^T J / J^T e use one accumulator per lane walking the rows in levmar's order.
 #define MLE_N 104
 #define MLE_ROW_DOUBLES 20   // LDS doubles per support point: pos 3, DU 9, Jacobian row 6, e 1, scratch 1
-#define MLE_ACC_DOUBLES 28   // + per group: the 27 accumulators of J^T J / J^T e, published for the whole group
+#define MLE_ACC_DOUBLES 88   // + per group: 8 remainder squares of the ordered sums, then the published normal equations: M [6][8]
+                             //   (J^T J symmetric in columns 0..5, J^T e in column 6, zeros in column 7) and D [6], the plain diagonal
+#define MLE_M(S) ((S).accs)
+#define MLE_D(S) ((S).accs + 48)
+#define MLE_CI(S) ((S).accs + 56)   // [2][9]: inverse covariances of the two end points (read by the two lanes that own those rows)
 struct MState {   // views into the group's LDS block, sized for the kernel variant's row capacity
   double *pos;    // [rows][3]
   double *DU;     // [rows][9]
@@ -517,7 +521,7 @@ struct MState {   // views into the group's LDS block, sized for the kernel vari
 };
 __device__ __forceinline__ void f_mstate_bind(MState &S, double *lds, int rows) {
   S.pos = lds; S.DU = S.pos + rows * 3; S.jac = S.DU + rows * 9; S.e = S.jac + rows * 6;
-  S.scr = S.e + rows; S.accs = S.scr + rows;
+  S.scr = S.e + rows; S.accs = S.scr + rows + 8;    // scr: [rows] block rows, [8] remainder rows
 }
 
 // ---- lane groups.  A 3D line with n support points is handled by a GROUP of G lanes: G = 64 (one line per
@@ -662,19 +666,37 @@ __device__ __forceinline__ void f_mle_cost(const MState &S, const MleGroup &g, i
 // sum0+sum1+sum2+sum3.  Group lane l runs chain l mod 4 from the squares published in LDS; every lane then adds the four.
 template <int G, int RW>
 __device__ __forceinline__ double f_ordered_sumsq(const MState &S, const double *v, const MleGroup &g, int n) {
-#pragma unroll
-  for (int h = 0; h < MleCfgT<G, RW>::SLOTS; h++) { int i = g.glane + G * h; if (i < n) S.scr[i] = v[h] * v[h]; }
-  g_order<G>();
+  // scr: squares of the rows of the complete blocks of eight at their row index (the rows from blockn on stay zero: set once
+  // in f_levmar6, never written), the squares of the remainder rows n - r .. n - 1 in the eight slots behind the row area
+  // (slots >= r stay zero).  All operands of a chain are loaded before its additions start; blocks of zeros in front of the
+  // first real block add +0.0 to a sum that is still +0.0.
+  constexpr int ROWS = MleCfgT<G, RW>::ROWS, NB = ROWS / 8, NCH = (NB + 3) / 4;
   const int c = g.glane & 3, nb = n >> 3, r = n & 7, blockn = nb << 3;
-  double s = 0.0;
-  for (int b = nb - 1; b >= 0; --b) {
-    const double q0 = S.scr[8 * b + 7 - c], q1 = S.scr[8 * b + 3 - c];
-    s += q0;
-    s += q1;
+#pragma unroll
+  for (int h = 0; h < MleCfgT<G, RW>::SLOTS; h++) {
+    const int i = g.glane + G * h;
+    if (i < n) S.scr[(i < blockn) ? i : ROWS + (i - blockn)] = v[h] * v[h];
   }
+  g_order<G>();
   const int t0 = (c - (7 - r)) & 3;
-  if (t0 < r) s += S.scr[blockn + t0];
-  if (t0 + 4 < r) s += S.scr[blockn + t0 + 4];
+  const double r0 = S.scr[ROWS + t0], r1 = S.scr[ROWS + t0 + 4];
+  double s = 0.0;
+#pragma unroll
+  for (int cb = NCH - 1; cb >= 0; --cb) {          // four blocks of eight per trip, from the top of the vector downwards
+    if (cb * 4 < nb) {
+      double q[8];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int b = cb * 4 + 3 - k;
+        if (b < NB) { q[2 * k] = S.scr[8 * b + 7 - c]; q[2 * k + 1] = S.scr[8 * b + 3 - c]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (cb * 4 + 3 - k < NB) { s += q[2 * k]; s += q[2 * k + 1]; }
+    }
+  }
+  s += r0;
+  s += r1;
   g_order<G>();
   const double s0 = g_get<G>(s, g, 0), s1 = g_get<G>(s, g, 1), s2 = g_get<G>(s, g, 2), s3 = g_get<G>(s, g, 3);
   return s0 + s1 + s2 + s3;
@@ -697,7 +719,7 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
   constexpr int SL = MleCfgT<G, RW>::SLOTS;
   const int m = 6, lane = g.glane;
   const double tau = 1E-03, eps1 = 1E-10, eps2 = 1E-20, eps2_sq = 1E-20 * 1E-20, eps3 = 1E-20, delta = 1E-06;
-  double jacTe[6], Dp[6], diag[6], pDp[6];
+  double Dp[6];
   double hx[SL], ev[SL], wrk[SL], wrk2[SL];
   double mu = 0, tmp, p_eL2, jacTe_inf = 0, pDp_eL2, p_L2 = 0, Dp_L2 = DBL_MAX, dF, dL;
   int nu, nu2, stop = 0, K = 10, updjac = 0, updp = 1, newjac = 0, k;
@@ -724,8 +746,13 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
     if (i >= n && i < n8) {
 #pragma unroll
       for (int j = 0; j < 6; j++) S.jac[i * m + j] = 0.0;
-      S.e[i] = 0.0; S.scr[i] = 0.0;
+      S.e[i] = 0.0;
     }
+  }
+  {   // the operand area of the ordered sums starts as zeros (f_ordered_sumsq), column 7 of M stays zero
+    constexpr int ROWS = MleCfgT<G, RW>::ROWS;
+    for (int i = lane; i < ROWS + 8; i += G) S.scr[i] = 0.0;
+    if (lane < 6) MLE_M(S)[lane * 8 + 7] = 0.0;
   }
   f_mle_cost<G, RW>(S, g, n, e1, e2, ci1, ci2, p, hx);
 #pragma unroll
@@ -778,15 +805,20 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
       {   // the accumulator lanes publish their entries; J^T J stays in LDS (read where the system is set up), the
           // group keeps J^T e and the diagonal in registers
 #pragma unroll
-        for (int q = 0; q < NACC; q++) { int a = lane + G * q; if (a < 27) S.accs[a] = acc[q]; }
+        for (int q = 0; q < NACC; q++) {
+          const int a = lane + G * q;
+          if (a < 21) {                            // J^T J: both halves of the square, the diagonal also into D
+            MLE_M(S)[ai[q] * 8 + aj[q]] = acc[q];
+            MLE_M(S)[aj[q] * 8 + ai[q]] = acc[q];
+            if (ai[q] == aj[q]) MLE_D(S)[ai[q]] = acc[q];
+          } else if (a < 27) MLE_M(S)[ai[q] * 8 + 6] = acc[q];      // J^T e: column 6
+        }
         g_order<G>();
-#pragma unroll
-        for (int i = 0; i < 6; i++) { diag[i] = S.accs[i * (i + 1) / 2 + i]; jacTe[i] = S.accs[21 + i]; }
       }
       p_L2 = jacTe_inf = 0.0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        if (jacTe_inf < (tmp = lf_fabs(jacTe[i]))) jacTe_inf = tmp;
+        if (jacTe_inf < (tmp = lf_fabs(MLE_M(S)[i * 8 + 6]))) jacTe_inf = tmp;
         p_L2 += p[i] * p[i];
       }
     }
@@ -795,22 +827,18 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
     if (k == 0) {
       tmp = DBL_MIN;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) if (diag[i] > tmp) tmp = diag[i];
+      for (int i = 0; i < 6; ++i) { const double dgi = MLE_D(S)[i]; if (dgi > tmp) tmp = dgi; }
       mu = tau * tmp;
     }
     int issolved;
-    {   // the augmented normal equations (J^T J + mu I) Dp = J^T e (AX_EQ_B_LU, lm_core.c:706): group lane j < 6 takes
-        // column j from the 21 published sums (symmetric fill), group lane 6 takes J^T e
+    {   // the augmented normal equations (J^T J + mu I) Dp = J^T e (AX_EQ_B_LU, lm_core.c:706): the diagonal lanes put
+        // D + mu I into the published square, then group lane j takes column j of it (j = 6: J^T e, j >= 7: zeros)
       double cl[6];
-      const int jc = (lane < 6) ? lane : 5;
+      if (lane < 6) MLE_M(S)[lane * 9] = MLE_D(S)[lane] + mu;
+      g_order<G>();
+      const double *colp = MLE_M(S) + ((lane < 7) ? lane : 7);
 #pragma unroll
-      for (int i = 0; i < 6; i++) {
-        const int hi = (i > jc) ? i : jc, lo = (i > jc) ? jc : i;
-        double v = S.accs[hi * (hi + 1) / 2 + lo];
-        if (i == lane) v += mu;
-        if (lane >= 6) v = (lane == 6) ? jacTe[i] : 0.0;
-        cl[i] = v;
-      }
+      for (int i = 0; i < 6; i++) cl[i] = colp[i * 8];
       issolved = f_lu6_cols<G, 1, true>(cl, g);
 #pragma unroll
       for (int i = 0; i < 6; i++) Dp[i] = g_get<G>(cl[i], g, 6);
@@ -819,10 +847,15 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
     if (issolved) {
       Dp_L2 = 0.0;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { pDp[i] = p[i] + (tmp = Dp[i]); Dp_L2 += tmp * tmp; }
+      for (int i = 0; i < 6; ++i) { tmp = Dp[i]; Dp_L2 += tmp * tmp; }
       if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
       if (Dp_L2 >= (p_L2 + eps2) / (1E-12 * 1E-12)) { stop = 4; break; }
-      f_mle_cost<G, RW>(S, g, n, e1, e2, ci1, ci2, pDp, wrk);
+      {
+        double pDp[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pDp[i] = p[i] + Dp[i];
+        f_mle_cost<G, RW>(S, g, n, e1, e2, ci1, ci2, pDp, wrk);
+      }
       MT(5);
 #pragma unroll
       for (int h = 0; h < SL; h++) wrk2[h] = 0.0 - wrk[h];
@@ -849,14 +882,14 @@ __device__ int f_levmar6(MState &S, const MleGroup &g, int n, int e1, int e2, co
       MT(7);
       dL = 0.0;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dL += Dp[i] * (mu * Dp[i] + jacTe[i]);
+      for (int i = 0; i < 6; ++i) dL += Dp[i] * (mu * Dp[i] + MLE_M(S)[i * 8 + 6]);
       if (dL > 0.0 && dF > 0.0) {
         tmp = (2.0 * dF / dL - 1.0);
         tmp = 1.0 - tmp * tmp * tmp;
         mu = mu * ((tmp >= 0.3333333334) ? tmp : 0.3333333334);
         nu = 2;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) p[i] = pDp[i];
+        for (int i = 0; i < 6; ++i) p[i] = p[i] + Dp[i];          // (== pDp: the same addition)
 #pragma unroll
         for (int h = 0; h < SL; h++) { int i = lane + G * h; hx[h] = wrk[h]; if (i < n) S.e[i] = wrk2[h]; }
         p_eL2 = pDp_eL2;
@@ -932,18 +965,25 @@ __device__ __forceinline__ void f_mle_line(const FrontConsts &c, const FrontBuff
     e2 = (imax == (1 << 30)) ? 0 : imax;
     if (e1 > e2) { int t = e1; e1 = e2; e2 = t; }
   }
-  double ci1[9], ci2[9], para[6];
-  {
-    double cov[9];
+  double para[6];
+  {   // the inverse covariances of the two end points live in LDS: only the two lanes that own those rows read them
+    double cov[9], ci[9];
     f_pt_cov(&S.pos[3 * e1], c.K[0], P, cov);
-    lf_inv3(cov, ci1);
+    lf_inv3(cov, ci);
+    if (lane == 0)
+#pragma unroll
+      for (int k = 0; k < 9; k++) MLE_CI(S)[k] = ci[k];
     f_pt_cov(&S.pos[3 * e2], c.K[0], P, cov);
-    lf_inv3(cov, ci2);
+    lf_inv3(cov, ci);
+    if (lane == 0)
+#pragma unroll
+      for (int k = 0; k < 9; k++) MLE_CI(S)[9 + k] = ci[k];
 #pragma unroll
     for (int k = 0; k < 3; k++) { para[k] = S.pos[3 * e1 + k]; para[3 + k] = S.pos[3 * e2 + k]; }
   }
+  g_order<G>();
   int stop = 0;
-  int nit = f_levmar6<G, RW>(S, g, ns, e1, e2, ci1, ci2, para, P.line3d_mle_iter_num, &stop);
+  int nit = f_levmar6<G, RW>(S, g, ns, e1, e2, MLE_CI(S), MLE_CI(S) + 9, para, P.line3d_mle_iter_num, &stop);
   // ---- MleLine3dCov (utils.cpp:1138-1159): H = J^T J in point order, cov = H^-1.  Every lane forms the 3x6 Jacobian
   // of its own rows, the rows are published in LDS (over pos / DU, which are dead by then), and 21 accumulator lanes
   // walk them in the reference's order (point by point, residual row by row); H is symmetric term by term.
@@ -997,7 +1037,8 @@ __device__ __forceinline__ void f_mle_line(const FrontConsts &c, const FrontBuff
           acc += a1 * b1;
           acc += a2 * b2;
         }
-        S.accs[a] = acc;
+        MLE_M(S)[hk * 8 + hl] = acc;
+        MLE_M(S)[hl * 8 + hk] = acc;
       }
     }
     g_order<G>();
@@ -1011,8 +1052,7 @@ __device__ __forceinline__ void f_mle_line(const FrontConsts &c, const FrontBuff
     const int jc = (lane < 6) ? lane : 5;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      const int hi = (i > jc) ? i : jc, lo = (i > jc) ? jc : i;
-      double v = S.accs[hi * (hi + 1) / 2 + lo];
+      double v = MLE_M(S)[i * 8 + jc];
       if (lane >= 6) v = (lane - 6 == i) ? 1.0 : 0.0;
       cl[i] = v;
     }

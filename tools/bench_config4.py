@@ -53,7 +53,7 @@ dt = time.perf_counter() - t0
 kernel_ms = ctx.stage_ms(3) if a.pose else ev[0].elapsed_time(ev[1]) / a.steps
 L_kf, L_q = float(nl[:NK].mean()), int(nl[NK])
 algo = int(sum(int(n) * (72 + 11) * 8 + int(n) * 12 for n in nl[:NK]) + L_q * (72 + 11) * 8)
-nmatch = int(sum(ctx.pair_result(i, allow_overflow=True).n_matches for i in range(NK)))
+nmatch = int(sum(len(ctx.pair_matches(i)[0]) for i in range(NK)))
 print(json.dumps({
     "metric": "loop-closure pairs/sec: 1 query frame vs %d key-frame line maps, %s" % (NK, "line matching + pose" if a.pose else "all-pairs line matching only"),
     "value": NK * a.steps / dt, "unit": "pairs/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
