@@ -78,6 +78,8 @@ def parse():
                     help="BASELINE configs[2] instead of configs[1]: fused point + line odometry -- projectTo3D, Hamming "
                          "feature matching and the hybrid RANSAC / LM solver on the key points of the HIP ORB extractor; "
                          "not the headline workload")
+    ap.add_argument("--serial-points", action="store_true",
+                    help="with --points: the point front end on the context's own stream instead of beside the line front end")
     ap.add_argument("--default-params", action="store_true",
                     help="ParameterServer defaults (lsd_angle_thres 22.5, min_matches 20) instead of the shipped "
                          "launch/lineslam.launch values (40, 10), which are what the reference actually runs with")
@@ -204,6 +206,9 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(nfl)]
     ctxs = [capi.Context(640, 480, max_batch=F, params=P, device=local, stream=st.cuda_stream) for st in streams]
     ctx = ctxs[0]
+    if a.points and not a.serial_points:
+        for c in ctxs:
+            c.point_stream(True)
     dg, dd = torch.from_numpy(gray).cuda(), torch.from_numpy(depth).cuda()
     torch.cuda.synchronize()
     if strong:
@@ -272,14 +277,17 @@ def main():
             return step_on(ctx)
 
     def step_on(ctx):
-        ctx.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), F, K, ids)
         if a.points:
             st = pts_state[ctxs.index(ctx)]
-            # Node::Node, ORB branch: AORB detection + removeDepthless + retainBest(600) + ORB descriptors, on the device
+            # Node::Node, ORB branch: AORB detection + removeDepthless + retainBest(600) + ORB descriptors, on the device -- on the
+            # context's point stream, beside the line front end issued right after it (node.cpp:208-217: two threads)
             ctx.orb_extract_device(dg.data_ptr(), dd.data_ptr(), F, st["kp"].data_ptr(), st["desc"].data_ptr(), st["nkp"].data_ptr(), NK,
                                    fast_threshold=20, max_keypoints=NK)
             ctx.project_keypoints_device(dd.data_ptr(), F, st["kp"].data_ptr(), st["nkp"].data_ptr(), NK, K, st["pts"].data_ptr(),
                                          st["npts"].data_ptr(), st["kept"].data_ptr(), max_keypoints=NK)
+        ctx.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), F, K, ids)
+        if a.points:
+            ctx.point_join()               # (stream-side join, node.cpp:313-316) before this stream reads the key points
             # descriptors follow the surviving key points (device gather, stream-ordered)
             dsel = torch.gather(st["desc"], 1, st["kept"].long().clamp_(0, NK - 1).unsqueeze(-1).expand(-1, -1, 32)).contiguous()
             st["dsel"] = dsel

@@ -379,6 +379,16 @@ LF_API int lf_project_keypoints_device(lf_ctx *ctx, const float *d_depth, size_t
                                        const int32_t *d_nkp, int kp_cap, const double K[9], double depth_scaling,
                                        int max_keypoints, float *d_points_out, int32_t *d_npts_out,
                                        int32_t *d_kept_out);
+/* The point front end beside the line front end: Node::Node runs detect3DLines in a second thread while the key points are
+ * detected and described (src/node.cpp:208-217, joined at :313-316).  enable != 0: lf_orb_extract_device and
+ * lf_project_keypoints_device are enqueued on a second HIP stream owned by the context.  They start after everything that was
+ * enqueued on the context's stream BEFORE the call (their inputs) and overlap what is enqueued after it -- so issue them
+ * first, then lf_detect3d_batch_device.  They are joined stream-side (no host wait) in front of their first consumer on the
+ * context's stream: lf_feature_match_pairs_device, the hybrid solvers, lf_orb_check / lf_orb_get_level, lf_ctx_synchronize --
+ * or explicitly by lf_ctx_point_join before the caller enqueues work of its own that reads their outputs. */
+LF_API int lf_ctx_point_stream(lf_ctx *ctx, int enable);
+LF_API int lf_ctx_point_join(lf_ctx *ctx);
+
 /* The ORB extractor: the ORB branch of Node::Node (src/node.cpp:222-290) for a batch of frames --
  *   detector->detect      = AorbFeatureDetector(10000, 1.2, 8, 31, 0, 2, HARRIS_SCORE, 31, fast_threshold)
  *                           (src/feature_adjuster.cpp:86-89 with the DetectorAdjuster's start threshold 20, src/features.cpp:75-76;
@@ -411,6 +421,13 @@ LF_API int lf_feature_match_pairs_device(lf_ctx *ctx, const uint8_t *d_desc, con
                                          const int32_t *query_frames, const int32_t *train_frames, int n_pairs,
                                          double nn_distance_ratio, int32_t *d_match_q, int32_t *d_match_t,
                                          float *d_match_dist, int32_t *d_nmatch);
+/* unsigned int Node::featureMatching(const Node* other, std::vector<cv::DMatch>* matches) (src/node.cpp:568-641, the
+ * BRUTEFORCE / ORB branch) for two HOST-resident nodes: desc_* = feature_descriptors_ rows (32 bytes each, at most 1024 per
+ * node), newer = this (query), older = other (train).  Outputs cv::DMatch members; *n_out = matches->size();
+ * LF_ERR_CAPACITY if cap is too small.  Overwrites the node ids of frame slots 0 and 1.  Synchronises. */
+LF_API int lf_feature_match_node_pair(lf_ctx *ctx, const uint8_t *desc_newer, int n_newer, uint64_t id_newer,
+                                      const uint8_t *desc_older, int n_older, uint64_t id_older, double nn_distance_ratio,
+                                      int32_t *query_idx, int32_t *train_idx, float *dist, int cap, int *n_out);
 /* lf_match_pairs_hybrid_device with the point matches already on the DEVICE (e.g. straight from
  * lf_feature_match_pairs_device): rows of pm_stride entries.  A count above pt_match_cap cannot be refused on the host
  * here: the solver then uses the first pt_match_cap matches, sets LF_OVF_PT_MATCHES in lf_pair_result::overflow, and the

@@ -54,6 +54,8 @@ class Node {
   int id_ = 0;
   std::vector<FrameLine> lines;     // src/node.h:280
   std::vector<std::array<float, 4>> feature_locations_3d_;   // src/node.h:  x,y,z,1 per keypoint, z = NaN without depth
+  std::vector<std::array<uint8_t, 32>> feature_descriptors_; // src/node.h: cv::Mat feature_descriptors_, one ORB row per key point
+  double nn_distance_ratio = 0.75;                           // ParameterServer "nn_distance_ratio" (launch/lineslam.launch)
   Context* ctx = nullptr;
   double K[9] = {525.0, 0, 319.5, 0, 525.0, 239.5, 0, 0, 1};   // the reference's global K (set by detect3DLines)
 
@@ -84,9 +86,18 @@ class Node {
   // Node::matchNodePair (src/node.cpp:1494-1615): valid edge <=> mr.edge.id1 >= 0.
   // point_matches = MatchingResult::all_matches, i.e. what Node::featureMatching produced for the two nodes'
   // feature_locations_3d_ (node.cpp:1519); nullptr / empty = lines only.
+  // With point_matches == nullptr and descriptors on both nodes the matches come from featureMatching, as the reference
+  // does itself at node.cpp:1504.
   MatchingResult matchNodePair(const Node* older_node, const std::vector<DMatch>* point_matches = nullptr) const {
     MatchingResult mr;
     lf_pair_result r;
+    std::vector<DMatch> own;
+    if (!point_matches && !feature_descriptors_.empty() && !older_node->feature_descriptors_.empty() &&
+        feature_descriptors_.size() == feature_locations_3d_.size() &&
+        older_node->feature_descriptors_.size() == older_node->feature_locations_3d_.size()) {
+      featureMatching(older_node, &own);
+      point_matches = &own;
+    }
     const bool hybrid = point_matches && !point_matches->empty();
     if (hybrid) {
       std::vector<int32_t> pq, pt;
@@ -121,6 +132,22 @@ class Node {
     mr.edge.id1 = r.valid ? r.id_older : -1;
     mr.edge.id2 = r.valid ? r.id_newer : -1;
     return mr;
+  }
+
+  // unsigned int Node::featureMatching(const Node* other, std::vector<cv::DMatch>* matches) (src/node.cpp:568-641, ORB /
+  // BRUTEFORCE branch): 2-nearest-neighbour Hamming search, ratio test, unique train indices; appends, returns matches->size()
+  unsigned featureMatching(const Node* other, std::vector<DMatch>* matches) const {
+    const int cap = (int)feature_descriptors_.size() + 1;
+    std::vector<int32_t> q((size_t)cap), t((size_t)cap);
+    std::vector<float> d((size_t)cap);
+    int n = 0;
+    check(lf_feature_match_node_pair(ctx->h, feature_descriptors_.empty() ? nullptr : feature_descriptors_[0].data(),
+                                     (int)feature_descriptors_.size(), (uint64_t)id_,
+                                     other->feature_descriptors_.empty() ? nullptr : other->feature_descriptors_[0].data(),
+                                     (int)other->feature_descriptors_.size(), (uint64_t)other->id_, nn_distance_ratio, q.data(), t.data(),
+                                     d.data(), cap, &n), "lf_feature_match_node_pair");
+    for (int i = 0; i < n; i++) matches->push_back({q[i], t[i], d[i]});
+    return (unsigned)matches->size();
   }
 
   // Node::lineMatching (src/node.cpp:1619-1694): the matcher alone (no pose solve), with the reference's adjacentFrame

@@ -85,6 +85,9 @@ SYMBOLS = {
     "lf_ingest_tum_device": (_i, [_vp, _vp, _vp, _i, C.c_double, _vp, _vp]),
     "lf_project_keypoints_device": (_i, [_vp, _vp, C.c_size_t, _i, _i, _vp, _vp, _i, _vp, C.c_double, _i, _vp, _vp, _vp]),
     "lf_feature_match_pairs_device": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, C.c_double, _vp, _vp, _vp, _vp]),
+    "lf_ctx_point_stream": (_i, [_vp, _i]),
+    "lf_ctx_point_join": (_i, [_vp]),
+    "lf_feature_match_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, C.c_uint64, C.c_double, _vp, _vp, _vp, _i, _pi]),
     "lf_match_pairs_hybrid_device_pm": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "lf_relmotion_pairs_device": (_i, [_vp, _vp, _vp, _i]),
     "lf_pair_get_motion": (_i, [_vp, _i, _vp, _vp]),
@@ -409,6 +412,25 @@ class Context:
         self._chk(lib().lf_feature_match_pairs_device(self._h, int(d_desc_ptr), int(d_ndesc_ptr), desc_cap, q.ctypes.data,
                                                       t.ctypes.data, len(q), float(nn_distance_ratio), int(d_mq), int(d_mt),
                                                       int(d_md), int(d_nm)), "lf_feature_match_pairs_device")
+
+    def point_stream(self, enable=True):
+        """The point front end (orb_extract_device, project_keypoints_device) on a second stream of the context (node.cpp:208-217)."""
+        self._chk(lib().lf_ctx_point_stream(self._h, int(bool(enable))), "lf_ctx_point_stream")
+
+    def point_join(self):
+        self._chk(lib().lf_ctx_point_join(self._h), "lf_ctx_point_join")
+
+    def feature_match_node_pair(self, desc_newer, id_newer, desc_older, id_older, nn_distance_ratio=0.75):
+        """Node::featureMatching for two host-resident nodes ([n,32] uint8 ORB descriptors each) -> (queryIdx, trainIdx, distance)."""
+        a = np.ascontiguousarray(desc_newer, np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(desc_older, np.uint8).reshape(-1, 32)
+        cap = max(len(a), 1)
+        q, t, d = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        n = C.c_int()
+        self._chk(lib().lf_feature_match_node_pair(self._h, a.ctypes.data if len(a) else None, len(a), int(id_newer),
+                                                   b.ctypes.data if len(b) else None, len(b), int(id_older), float(nn_distance_ratio),
+                                                   q.ctypes.data, t.ctypes.data, d.ctypes.data, cap, C.byref(n)), "lf_feature_match_node_pair")
+        return q[:n.value].copy(), t[:n.value].copy(), d[:n.value].copy()
 
     def match_pairs_hybrid_device_pm(self, query_frames, train_frames, d_points_ptr, pt_cap, d_pm_q, d_pm_t, d_npm,
                                      pm_stride, K):

@@ -52,6 +52,13 @@ struct lf_ctx {
   bool hybrid_ready = false;         // hybrid (points + lines) buffers are allocated on first use
   int *d_pm_q = nullptr, *d_pm_t = nullptr, *d_npm = nullptr;
   float *d_pts_stage = nullptr;      // lf_match_node_pair_hybrid staging: 2 x LF_NODE_PT_CAP float4
+  // the point front end (ORB extraction, projectTo3D) on its own stream, next to the line front end (lf_ctx_point_stream)
+  hipStream_t pstream = nullptr;
+  hipEvent_t ev_pts_in = nullptr, ev_pts_done = nullptr, ev_pts_free = nullptr;
+  bool pts_async = false, pts_pending = false, pts_free_rec = false;
+  uint8_t *d_fm_stage = nullptr;     // lf_feature_match_node_pair staging: 2 x 1024 descriptors of 32 bytes (first use)
+  int32_t *d_fm_n = nullptr, *d_fm_q = nullptr, *d_fm_t = nullptr, *d_fm_cnt = nullptr;
+  float *d_fm_d = nullptr;
   bool last_hybrid = false;
   PairBuffers last_pb;               // the buffers of the last pair launch (train side may be an external map)
   unsigned char *d_adjacent = nullptr;   // [maxB] adjacentFrame flags of lf_line_matching_device
@@ -114,6 +121,9 @@ static int dev_alloc(lf_ctx *c, T **p, size_t count) {
     int r_ = dev_alloc(ctx, &(ptr), (size_t)(count));   \
     if (r_ != LF_OK) return r_;                         \
   } while (0)
+
+static void pt_stream_join(lf_ctx *c);
+static void pt_stream_consumed(lf_ctx *c);
 
 extern "C" {
 
@@ -458,6 +468,11 @@ void lf_ctx_destroy(lf_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   (void)lf_comm_destroy(c);
+  if (c->pstream) {
+    (void)hipStreamSynchronize(c->pstream);
+    (void)hipEventDestroy(c->ev_pts_in); (void)hipEventDestroy(c->ev_pts_done); (void)hipEventDestroy(c->ev_pts_free);
+    (void)hipStreamDestroy(c->pstream);
+  }
   for (void *p : c->allocs) (void)hipFree(p);
   for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->ev_stage_ids) (void)hipEventDestroy(c->ev_stage_ids);
@@ -487,6 +502,7 @@ int lf_ctx_set_params(lf_ctx *c, const lf_params *p) {
 
 int lf_ctx_synchronize(lf_ctx *c) {
   if (!c) return LF_ERR_INVALID;
+  pt_stream_join(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LF_OK;
 }
@@ -757,6 +773,7 @@ static int match_pairs_impl(lf_ctx *c, const int32_t *query_frames, const int32_
     }
   }
   HIPCHK(c, hipSetDevice(c->device));
+  if (pcall.hy) pt_stream_join(c);
   {   // pair lists through the pinned staging area (the caller's arrays may be temporaries)
     const unsigned sl = c->stage_pairs_next++ % LF_PAIR_STAGE_SLOTS;
     if (c->stage_pairs_pending[sl]) HIPCHK(c, hipEventSynchronize(c->ev_stage_pairs[sl]));
@@ -795,6 +812,7 @@ static int match_pairs_impl(lf_ctx *c, const int32_t *query_frames, const int32_
   }
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   lf_pair_launch(c->pcn, pb, n_pairs, c->stream, pcall.solver, pcall.lm_q == nullptr);
+  if (pcall.hy) pt_stream_consumed(c);
   c->last_hybrid = pcall.hy != nullptr;
   c->last_pb = pb;
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
@@ -837,6 +855,53 @@ int lf_match_pairs_hybrid_device_pm(lf_ctx *c, const int32_t *query_frames, cons
   return match_pairs_impl(c, query_frames, train_frames, n_pairs, pc);
 }
 
+// ---- the point front end next to the line front end.  Node::Node extracts the key points while detect3DLines runs in a
+// second thread (src/node.cpp:208-217, joined at :313-316).  Here: lf_orb_extract_device / lf_project_keypoints_device are
+// enqueued on a second stream of the context; they start after everything enqueued on the context's stream BEFORE the call
+// (their inputs), run beside what is enqueued after it (lf_detect3d_batch_device), and are joined -- stream-side, no host
+// wait -- before their first consumer on the context's stream (feature matching, the hybrid solver, the getters) or by
+// lf_ctx_point_join.  The next point-side call waits for the consumers of the previous one.
+static hipStream_t pt_stream_begin(lf_ctx *c) {
+  if (!c->pts_async) return c->stream;
+  if (!c->pts_pending) {
+    (void)hipEventRecord(c->ev_pts_in, c->stream);
+    (void)hipStreamWaitEvent(c->pstream, c->ev_pts_in, 0);
+    if (c->pts_free_rec) (void)hipStreamWaitEvent(c->pstream, c->ev_pts_free, 0);
+    c->pts_pending = true;
+  }
+  return c->pstream;
+}
+static void pt_stream_join(lf_ctx *c) {
+  if (!c->pts_async || !c->pts_pending) return;
+  (void)hipEventRecord(c->ev_pts_done, c->pstream);
+  (void)hipStreamWaitEvent(c->stream, c->ev_pts_done, 0);
+  c->pts_pending = false;
+}
+static void pt_stream_consumed(lf_ctx *c) {      // the consumers of the point-side outputs are enqueued on c->stream
+  if (!c->pts_async) return;
+  (void)hipEventRecord(c->ev_pts_free, c->stream);
+  c->pts_free_rec = true;
+}
+int lf_ctx_point_stream(lf_ctx *c, int enable) {
+  if (!c) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  pt_stream_join(c);
+  if (enable && !c->pstream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->pstream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_pts_in, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_pts_done, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_pts_free, hipEventDisableTiming));
+  }
+  c->pts_async = enable != 0;
+  return LF_OK;
+}
+int lf_ctx_point_join(lf_ctx *c) {
+  if (!c) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  pt_stream_join(c);
+  return LF_OK;
+}
+
 int lf_project_keypoints_device(lf_ctx *c, const float *d_depth, size_t depth_frame_stride, int depth_row_stride,
                                 int n_frames, const float *d_kp_xy, const int32_t *d_nkp, int kp_cap, const double K[9],
                                 double depth_scaling, int max_keypoints, float *d_points_out, int32_t *d_npts_out,
@@ -854,7 +919,7 @@ int lf_project_keypoints_device(lf_ctx *c, const float *d_depth, size_t depth_fr
   memset(&pb, 0, sizeof pb);
   pb.depth = d_depth; pb.depth_frame_stride = depth_frame_stride; pb.depth_row_stride = depth_row_stride;
   pb.kp_xy = d_kp_xy; pb.nkp = d_nkp; pb.points = d_points_out; pb.npts = d_npts_out; pb.kept = d_kept_out;
-  lf_points_project_launch(pc, pb, n_frames, c->stream);
+  lf_points_project_launch(pc, pb, n_frames, pt_stream_begin(c));
   HIPCHK(c, hipGetLastError());
   return LF_OK;
 }
@@ -880,6 +945,7 @@ int lf_feature_match_pairs_device(lf_ctx *c, const uint8_t *d_desc, const int32_
     if (query_frames[i] < 0 || query_frames[i] >= c->last_batch || train_frames[i] < 0 || train_frames[i] >= c->last_batch)
       return LF_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  pt_stream_join(c);
   {   // pair lists through the pinned staging area
     const unsigned sl = c->stage_pairs_next++ % LF_PAIR_STAGE_SLOTS;
     if (c->stage_pairs_pending[sl]) HIPCHK(c, hipEventSynchronize(c->ev_stage_pairs[sl]));
@@ -900,6 +966,50 @@ int lf_feature_match_pairs_device(lf_ctx *c, const uint8_t *d_desc, const int32_
   pb.fm_q = d_match_q; pb.fm_t = d_match_t; pb.fm_d = d_match_dist; pb.fm_n = d_nmatch;
   lf_points_match_launch(pc, pb, n_pairs, c->stream);
   HIPCHK(c, hipGetLastError());
+  return LF_OK;
+}
+
+// Node::featureMatching for two HOST-resident nodes (descriptors of the newer node = query, of the older = train): the
+// descriptors travel to a staging area laid out as frame slots 0 / 1, the node ids key the random distance offset.
+int lf_feature_match_node_pair(lf_ctx *c, const uint8_t *desc_newer, int n_newer, uint64_t id_newer, const uint8_t *desc_older,
+                               int n_older, uint64_t id_older, double nn_distance_ratio, int32_t *query_idx, int32_t *train_idx,
+                               float *dist, int cap, int *n_out) {
+  if (!c || !n_out || n_newer < 0 || n_older < 0 || (n_newer && !desc_newer) || (n_older && !desc_older) || cap < 0 ||
+      (cap && (!query_idx || !train_idx || !dist)))
+    return LF_ERR_INVALID;
+  const int DC = 1024;                                   // desc_cap of the staging area = the matcher's maximum
+  if (n_newer > DC || n_older > DC) return LF_ERR_CAPACITY;
+  if (c->maxB < 2) return LF_ERR_CAPACITY;
+  *n_out = 0;
+  if (n_newer == 0 || n_older == 0) return LF_OK;        // (the reference returns with no matches: node.cpp:573-577)
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->d_fm_stage) {
+    ALLOC(c, c->d_fm_stage, (size_t)2 * DC * 32);
+    ALLOC(c, c->d_fm_n, 2);
+    ALLOC(c, c->d_fm_q, DC); ALLOC(c, c->d_fm_t, DC); ALLOC(c, c->d_fm_d, DC); ALLOC(c, c->d_fm_cnt, 1);
+  }
+  const uint64_t ids[2] = {id_newer, id_older};
+  const int32_t nd[2] = {n_newer, n_older};
+  HIPCHK(c, hipMemcpyAsync(c->d_fm_stage, desc_newer, (size_t)32 * n_newer, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_fm_stage + (size_t)DC * 32, desc_older, (size_t)32 * n_older, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_fm_n, nd, sizeof nd, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_frame_ids, ids, sizeof ids, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->last_batch < 2) c->last_batch = 2;
+  const int32_t q = 0, t = 1;
+  int r = lf_feature_match_pairs_device(c, c->d_fm_stage, c->d_fm_n, DC, &q, &t, 1, nn_distance_ratio, c->d_fm_q, c->d_fm_t, c->d_fm_d, c->d_fm_cnt);
+  if (r != LF_OK) return r;
+  int n = 0;
+  HIPCHK(c, hipMemcpyAsync(&n, c->d_fm_cnt, sizeof n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_out = n;
+  if (n > cap) return LF_ERR_CAPACITY;
+  if (n) {
+    HIPCHK(c, hipMemcpyAsync(query_idx, c->d_fm_q, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(train_idx, c->d_fm_t, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dist, c->d_fm_d, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   return LF_OK;
 }
 
@@ -1526,9 +1636,10 @@ int lf_orb_extract_device(lf_ctx *c, const uint8_t *d_gray, size_t gray_frame_st
   ob.gray = d_gray; ob.gray_frame_stride = gray_frame_stride; ob.gray_row_stride = gray_row_stride;
   ob.depth = d_depth; ob.depth_frame_stride = depth_frame_stride; ob.depth_row_stride = depth_row_stride;
   ob.kp_xy = d_kp_xy; ob.kp_meta = d_kp_meta; ob.desc = d_desc; ob.nkp = c->d_orb_nkp;
-  lf_orb_launch(oc, ob, n_frames, c->stream);
+  hipStream_t pst = pt_stream_begin(c);
+  lf_orb_launch(oc, ob, n_frames, pst);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(d_nkp, c->ob.nsel, sizeof(int) * (size_t)n_frames, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_nkp, c->ob.nsel, sizeof(int) * (size_t)n_frames, hipMemcpyDeviceToDevice, pst));
   c->orb_last = n_frames;
   return LF_OK;
 }
@@ -1536,6 +1647,7 @@ int lf_orb_extract_device(lf_ctx *c, const uint8_t *d_gray, size_t gray_frame_st
 int lf_orb_check(lf_ctx *c) {
   if (!c || !c->orb_ready || c->orb_last < 1) return LF_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
+  pt_stream_join(c);
   std::vector<int> h((size_t)2 * c->orb_last), ns((size_t)c->orb_last);
   HIPCHK(c, hipMemcpyAsync(h.data(), c->d_orb_nkp, sizeof(int) * h.size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(ns.data(), c->ob.nsel, sizeof(int) * ns.size(), hipMemcpyDeviceToHost, c->stream));
@@ -1553,6 +1665,7 @@ int lf_orb_get_level(lf_ctx *c, int frame, int level, int blurred, uint8_t *out,
   if (!out) return LF_OK;
   if (cap_bytes < bytes) return LF_ERR_CAPACITY;
   HIPCHK(c, hipSetDevice(c->device));
+  pt_stream_join(c);
   const uint8_t *src = (blurred ? c->ob.blur : c->ob.pyr) + (size_t)frame * c->oc.total + c->oc.loff[level];
   HIPCHK(c, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -52,6 +52,8 @@ class Node:
         self._ctx = ctx
         self.lines = np.zeros(0, capi.REC_DTYPE)
         self.feature_locations_3d_ = np.zeros((0, 4), np.float32)
+        self.feature_descriptors_ = np.zeros((0, 32), np.uint8)      # cv::Mat feature_descriptors_ (ORB rows), one per 3D point
+        self.nn_distance_ratio = 0.75                                # ParameterServer "nn_distance_ratio"
         self.detect3DLines(gray_uchar, depth_float, self.params.line_segment_len_thresh, self.K,
                            self.params.ratio_of_collinear_pts, self.params.line3d_length_thresh,
                            self.params.depth_scaling, "LSD")
@@ -117,8 +119,23 @@ class Node:
         return self._ctx.refine_pair(self.lines, earlier_node.lines, lm[:, 0], lm[:, 1], transformation_estimate, iterations,
                                      self.feature_locations_3d_, earlier_node.feature_locations_3d_, pm[:, 0], pm[:, 1], self.K)
 
+    def featureMatching(self, other, matches=None):
+        """unsigned int Node::featureMatching(const Node* other, std::vector<cv::DMatch>* matches) (node.cpp:568-641, ORB /
+        BRUTEFORCE branch).  Appends (queryIdx, trainIdx, distance) tuples; returns the count."""
+        q, t, d = self._ctx.feature_match_node_pair(self.feature_descriptors_, self.id_, other.feature_descriptors_, other.id_,
+                                                    self.nn_distance_ratio)
+        out = matches if matches is not None else []
+        out.extend(zip(q.tolist(), t.tolist(), d.tolist()))
+        return len(out)
+
     def matchNodePair(self, older_node, point_matches=None):
-        """point_matches: MatchingResult::all_matches as (queryIdx, trainIdx[, distance]) tuples, or None."""
+        """point_matches: MatchingResult::all_matches as (queryIdx, trainIdx[, distance]) tuples, or None -- then, with
+        descriptors on both nodes, featureMatching supplies them as in the reference (node.cpp:1504)."""
+        if (point_matches is None and len(self.feature_descriptors_) and len(older_node.feature_descriptors_)
+                and len(self.feature_descriptors_) == len(self.feature_locations_3d_)
+                and len(older_node.feature_descriptors_) == len(older_node.feature_locations_3d_)):
+            point_matches = []
+            self.featureMatching(older_node, point_matches)
         r, mq, mt, md, inl, pinl = self._pair(older_node, point_matches)
         mr = MatchingResult()
         if point_matches is not None:

@@ -9,13 +9,13 @@
  * (OpenCV 2.4, Eigen, Armadillo, PCL absent), and its tests hold no vectors for this stage, so
  * this file is "parity unpinned" against the reference binary: it is a restatement from the
  * source text.  Third-party pieces it has to restate from their published algorithms:
- *   cv::SVD (3x3 symmetric)      -> Jacobi eigen-decomposition, lf_linalg.h
- *   cv::Mat::inv (LU)            -> Gaussian elimination with partial pivoting, lf_linalg.h
+ *   cv::SVD (3x3 symmetric)      -> Jacobi eigen-decomposition, o_linalg.h (the oracle's own statement)
+ *   cv::Mat::inv (LU)            -> OpenCV's LU order, o_linalg.h
  *   cv::Sobel ksize 5, cv::LineIterator, cv::clipLine  (OpenCV 2.4 imgproc / core drawing)
  *   dlevmar_dif                  (external/levmar-2.6/lm_core.c:438-846, misc_core.c:137-171) --
  *                                 restated below; cross-checked against the compiled levmar where
  *                                 that is available (tests/test_oracle_front.py)
- *   rand()                       -> lf_rand31 counter-based generator (the reference's stream is
+ *   rand()                       -> o_rand31 counter-based generator (the reference's stream is
  *                                 unseeded and racy under OpenMP, SURVEY.md hard part C)
  */
 #include <math.h>
@@ -25,7 +25,7 @@
 #include <float.h>
 
 #include "../include/linefront.h"
-#include "../lineslam_amd/csrc/lf_linalg.h"
+#include "o_linalg.h"   /* the oracle's own Jacobi / LU / counter generator (NOT the product's lf_linalg.h) */
 
 #define O_EPS 1e-10 /* lineslam.h:37 */
 
@@ -39,7 +39,7 @@ static void o_make_rpt(const double pos[3], const double cov[9], orpt *o) {
   int i, j;
   for (i = 0; i < 3; i++) o->pos[i] = pos[i];
   for (i = 0; i < 9; i++) { o->cov[i] = cov[i]; A[i] = cov[i]; }
-  lf_jacobi3(A, V, w);
+  o_jacobi(3, A, V, w);
   for (i = 0; i < 3; i++) o->W_sqrt[i] = sqrt(w[i]);
   for (i = 0; i < 3; i++)
     for (j = 0; j < 3; j++) o->DU[3 * i + j] = (1 / o->W_sqrt[i]) * V[3 * j + i]; /* D * U^T */
@@ -144,7 +144,7 @@ static void o_line3d_svd(const orpt *pts, const int *idx, int n, double mean[3],
     for (k = 0; k < 3; k++) d[k] = pts[idx[i]].pos[k] - mean[k];
     for (k = 0; k < 3; k++) for (l = 0; l < 3; l++) S[3 * k + l] += d[k] * d[l];
   }
-  lf_jacobi3(S, V, w);
+  o_jacobi(3, S, V, w);
   for (k = 0; k < 3; k++) drct[k] = V[3 * k + 0];
 }
 
@@ -152,7 +152,7 @@ static void o_line3d_svd(const orpt *pts, const int *idx, int n, double mean[3],
 static void o_random_unique(int *v, int n, int num, uint64_t seed, uint64_t stream, uint64_t *ctr) {
   int b = 0, left = n;
   while (num--) {
-    int r = b + (int)(lf_rand31(seed, stream, (*ctr)++) % (uint32_t)left);
+    int r = b + (int)(o_rand31(seed, stream, (*ctr)++) % (uint32_t)left);
     int t = v[b]; v[b] = v[r]; v[r] = t;
     ++b; --left;
   }
@@ -352,7 +352,7 @@ int oracle_msld(const double *xG, const double *yG, int width, int height, const
     n++;
   }
   if (n == 0) {
-    for (i = 0; i < 72; i++) des[i] = (double)lf_rand31(seed, stream, 1000 + (uint64_t)i);
+    for (i = 0; i < 72; i++) des[i] = (double)o_rand31(seed, stream, 1000 + (uint64_t)i);
     free(GDM);
     return 0;
   }
@@ -651,8 +651,8 @@ int oracle_mle_line3d(const orpt *pts, int n, int maxIter, double A[3], double B
   if (e1 > e2) { int t = e1; e1 = e2; e2 = t; }
   opts[0] = 1E-03; opts[1] = 1E-10; opts[2] = 1E-20; opts[3] = 1E-20; opts[4] = 1E-06;
   data.pts = pts; data.n = n; data.idx1 = e1; data.idx2 = e2;
-  lf_inv3(pts[e1].cov, data.ci1);
-  lf_inv3(pts[e2].cov, data.ci2);
+  o_inv3(pts[e1].cov, data.ci1);
+  o_inv3(pts[e2].cov, data.ci2);
   /* paraVec: positions of the points with index idx_end1 then idx_end2 (if equal: 3 params only;
      cannot happen for >= 2 distinct points) */
   for (k = 0; k < 3; k++) { para[k] = pts[e1].pos[k]; para[3 + k] = pts[e2].pos[k]; }
@@ -668,7 +668,7 @@ int oracle_mle_line3d(const orpt *pts, int n, int maxIter, double A[3], double B
     for (r = 0; r < 3; r++) for (k = 0; k < 6; k++) for (l = 0; l < 6; l++) H[k * 6 + l] += J[r * 6 + k] * J[r * 6 + l];
   }
   for (i = 0; i < 36; i++) I6[i] = (i % 7 == 0) ? 1.0 : 0.0;
-  if (!lf_solve6(H, I6, 6)) for (i = 0; i < 36; i++) I6[i] = NAN;
+  if (!o_lu_solve(6, H, 6, I6)) for (i = 0; i < 36; i++) I6[i] = NAN;
   for (r = 0; r < 3; r++) for (k = 0; k < 3; k++) { covA[3 * r + k] = I6[r * 6 + k]; covB[3 * r + k] = I6[(r + 3) * 6 + 3 + k]; }
   return nit;
 }
@@ -769,7 +769,7 @@ int oracle_detect3d(const uint8_t *gray, int gstride, const float *depth, int ds
       if (cand_info) { cand_info[8 * (size_t)i + 0] = numSmp; cand_info[8 * (size_t)i + 1] = np; }
       { double need = numSmp * P->ratio_of_collinear_pts; if (need < 10.0) need = 10.0; if (np < need) continue; } /* :289 */
       for (j = 0; j < np; j++) o_comp_pt3d_cov(pts3[j], K[0], P, &rp[j]);
-      ninl = o_extract3dline(rp, np, P, P->rng_seed, LF_STREAM_LINE3D(frame_id, i), A, B, inl);
+      ninl = o_extract3dline(rp, np, P, P->rng_seed, O_STREAM_LINE3D(frame_id, i), A, B, inl);
       if (cand_info) { cand_info[8 * (size_t)i + 2] = ninl; for (k = 0; k < 3; k++) cand_info[8 * (size_t)i + 3 + k] = A[k]; }
       if (ninl / numSmp > P->ratio_of_collinear_pts &&
           sqrt((A[0] - B[0]) * (A[0] - B[0]) + (A[1] - B[1]) * (A[1] - B[1]) + (A[2] - B[2]) * (A[2] - B[2])) > P->line3d_length_thresh)
@@ -808,16 +808,16 @@ int oracle_detect3d(const uint8_t *gray, int gstride, const float *depth, int ds
         lf_line_record *R = &recs[li];
         double info[10], A9[9], V[9], wv[3], A[3], B[3];
         int r2, c2;
-        oracle_msld(gx, gy, w, h, R->p, R->q, R->r, P->msld_sample_interval, P->rng_seed, LF_STREAM_LINE3D(frame_id, si), R->des);
+        oracle_msld(gx, gy, w, h, R->p, R->q, R->r, P->msld_sample_interval, P->rng_seed, O_STREAM_LINE3D(frame_id, si), R->des);
         for (k = 0; k < 3; k++) { A[k] = sg[si].A[k]; B[k] = sg[si].B[k]; }
         oracle_mle_line3d(sg[si].sup, sg[si].ninl, P->line3d_mle_iter_num, A, B, R->covA, R->covB, info);
         for (k = 0; k < 3; k++) { R->A[k] = A[k]; R->B[k] = B[k]; }
         /* rndA / rndB = RandomPoint3d(A, covA) */
         for (k = 0; k < 9; k++) A9[k] = R->covA[k];
-        lf_jacobi3(A9, V, wv);
+        o_jacobi(3, A9, V, wv);
         for (r2 = 0; r2 < 3; r2++) { R->Wsa[r2] = sqrt(wv[r2]); for (c2 = 0; c2 < 3; c2++) R->DUa[3 * r2 + c2] = (1 / R->Wsa[r2]) * V[3 * c2 + r2]; }
         for (k = 0; k < 9; k++) A9[k] = R->covB[k];
-        lf_jacobi3(A9, V, wv);
+        o_jacobi(3, A9, V, wv);
         for (r2 = 0; r2 < 3; r2++) { R->Wsb[r2] = sqrt(wv[r2]); for (c2 = 0; c2 < 3; c2++) R->DUb[3 * r2 + c2] = (1 / R->Wsb[r2]) * V[3 * c2 + r2]; }
       }
     }
@@ -837,22 +837,12 @@ int oracle_omp_threads(int n) { (void)n; return 1; }
 #endif
 
 /* exported helpers for primitive-level tests */
-void oracle_jacobi3(const double *A, double *V, double *w) { double T[9]; int i; for (i = 0; i < 9; i++) T[i] = A[i]; lf_jacobi3(T, V, w); }
-void oracle_jacobi4(const double *A, double *V, double *w) { double T[16]; int i; for (i = 0; i < 16; i++) T[i] = A[i]; lf_jacobi4(T, V, w); }
-int oracle_solve6(const double *A, const double *b, double *x) { double T[36], B[6]; int i, r; for (i = 0; i < 36; i++) T[i] = A[i]; for (i = 0; i < 6; i++) B[i] = b[i]; r = lf_solve6(T, B, 1); for (i = 0; i < 6; i++) x[i] = B[i]; return r; }
-uint32_t oracle_rand31(uint64_t seed, uint64_t stream, uint64_t ctr) { return lf_rand31(seed, stream, ctr); }
-/* the two statements of levmar's AX_EQ_B_LU: the transcription above (oracle's own) and the product's scalar form
- * (lf_linalg.h, what k_relmotion runs and what k_mle's lane-distributed form must equal) -- tests hold them bit-equal */
+void oracle_jacobi3(const double *A, double *V, double *w) { double T[9]; int i; for (i = 0; i < 9; i++) T[i] = A[i]; o_jacobi(3, T, V, w); }
+void oracle_jacobi4(const double *A, double *V, double *w) { double T[16]; int i; for (i = 0; i < 16; i++) T[i] = A[i]; o_jacobi(4, T, V, w); }
+int oracle_solve6(const double *A, const double *b, double *x) { double T[36], B[6]; int i, r; for (i = 0; i < 36; i++) T[i] = A[i]; for (i = 0; i < 6; i++) B[i] = b[i]; r = o_lu_solve(6, T, 1, B); for (i = 0; i < 6; i++) x[i] = B[i]; return r; }
+uint32_t oracle_rand31(uint64_t seed, uint64_t stream, uint64_t ctr) { return o_rand31(seed, stream, ctr); }
+/* levmar's AX_EQ_B_LU as transcribed above (the product's scalar form is exported by product_hooks.c for the cross-check) */
 int oracle_lu_netlib(const double *A, const double *b, double *x, int m) { return o_ax_eq_b_lu(A, b, x, m); }
-int oracle_lu_product(const double *A, const double *b, double *x, int m) {
-  double T[49], B[7]; int i, r;
-  if (m != 6 && m != 7) return -1;
-  for (i = 0; i < m * m; i++) T[i] = A[i];
-  for (i = 0; i < m; i++) B[i] = b[i];
-  r = (m == 6) ? lf_lu6(T, B) : lf_lu7(T, B);
-  for (i = 0; i < m; i++) x[i] = B[i];
-  return r;
-}
 
 /* MLEstimateLine3d's levmar problem (costFun_MLEstimateLine3d on the support points, utils.cpp:980-1012) run twice from
  * the same start with the SAME cost function o_mle_cost: by the restatement oracle_levmar_dif, and by a compiled
@@ -878,8 +868,8 @@ void oracle_mle_levmar_pair(const double *pts, int n, double focal, const lf_par
   if (e1 > e2) { int t = e1; e1 = e2; e2 = t; }
   opts[0] = 1E-03; opts[1] = 1E-10; opts[2] = 1E-20; opts[3] = 1E-20; opts[4] = 1E-06;
   data.pts = rp; data.n = n; data.idx1 = e1; data.idx2 = e2;
-  lf_inv3(rp[e1].cov, data.ci1);
-  lf_inv3(rp[e2].cov, data.ci2);
+  o_inv3(rp[e1].cov, data.ci1);
+  o_inv3(rp[e2].cov, data.ci2);
   for (k = 0; k < 3; k++) { own_p[k] = ref_p[k] = rp[e1].pos[k]; own_p[3 + k] = ref_p[3 + k] = rp[e2].pos[k]; }
   nit[0] = oracle_levmar_dif(o_mle_cost, own_p, 6, n, P->line3d_mle_iter_num, opts, own_info, &data);
   nit[1] = compiled ? compiled(o_mle_cost_nc, ref_p, x0, 6, n, P->line3d_mle_iter_num, opts, ref_info, 0, 0, &data) : -2;

@@ -8,7 +8,7 @@
  * Parity status: "parity unpinned" -- OpenCV is absent.  knnMatch is restated from OpenCV 2.4's batchDistance
  * (modules/core/src/stat.cpp): candidates are visited in train order and inserted into the sorted k-best list
  * BEHIND entries of equal distance, i.e. the lower train index wins ties.  Pinned by known-answer tests against a
- * numpy brute force (tests/test_oracle_points.py).  rand() -> lf_rand31(seed, stream, query index).
+ * numpy brute force (tests/test_oracle_points.py).  rand() -> o_rand31(seed, stream, query index).
  */
 #include <math.h>
 #include <stdint.h>
@@ -16,7 +16,7 @@
 #include <string.h>
 
 #include "../include/linefront.h"
-#include "../lineslam_amd/csrc/lf_linalg.h"
+#include "o_linalg.h"   /* the oracle's own counter generator (NOT the product's lf_linalg.h) */
 
 static int o_hamming256(const uint8_t *a, const uint8_t *b) {
   int d = 0, i;
@@ -46,7 +46,7 @@ int oracle_feature_match(const uint8_t *qdesc, int nq, const uint8_t *tdesc, int
         if (taken[b1]) continue;
         taken[b1] = 1;
         out_q[n] = i; out_t[n] = b1;
-        out_d[n] = (float)(dist_ratio_fac + (float)lf_rand31(seed, stream, (uint64_t)i) / (1000.0 * 2147483647.0));
+        out_d[n] = (float)(dist_ratio_fac + (float)o_rand31(seed, stream, (uint64_t)i) / (1000.0 * 2147483647.0));
         n++;
       }
     }

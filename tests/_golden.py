@@ -21,8 +21,22 @@ def _npz(name):
     return _cache[name]
 
 
+POSE_FILES = ("pose_fixtures.npz", "pose_fixtures_extra.npz")    # round 2: 55 pairs; round 3: 150 more (make_pose_golden.py --extra)
+
+
+def _pose_file(name):
+    for f in POSE_FILES:
+        if os.path.exists(os.path.join(HERE, "golden", f)) and name + "_ok" in _npz(f).files:
+            return _npz(f)
+    raise KeyError(name)
+
+
 def pose_names():
-    return [str(n) for n in _npz("pose_fixtures.npz")["names"]]
+    out = []
+    for f in POSE_FILES:
+        if os.path.exists(os.path.join(HERE, "golden", f)):
+            out += [str(n) for n in _npz(f)["names"]]
+    return out
 
 
 def _recs(z, name, side):
@@ -42,7 +56,7 @@ def _recs(z, name, side):
 def pose_case(name):
     """dict(train, query: lf_line_record arrays; train_pts, query_pts: [n,4] f32; pm, lm: [k,2] (queryIdx, trainIdx);
     id_train, id_query; expected: ok, best_iter, rounds, tf [4,4] f32, rmse, pin, lin; T_true)."""
-    z = _npz("pose_fixtures.npz")
+    z = _pose_file(name)
     ok = z[name + "_ok"]
     return dict(train=_recs(z, name, "t"), query=_recs(z, name, "q"), train_pts=z[name + "_t_pts"], query_pts=z[name + "_q_pts"],
                 pm=z[name + "_pm"], lm=z[name + "_lm"], id_train=int(z[name + "_ids"][0]), id_query=int(z[name + "_ids"][1]),

@@ -37,14 +37,18 @@ def rand_point_in_view(rs, zmin=0.8, zmax=4.0):
     return np.array([(u - CX) * z / F, (v - CY) * z / F, z])
 
 
-def make_pair(rs, n_lines, n_pts, max_deg, max_trans, outlier_frac, id_train, id_query, P, extra_lines=6, nan_pts=0):
+def make_pair(rs, n_lines, n_pts, max_deg, max_trans, outlier_frac, id_train, id_query, P, extra_lines=6, nan_pts=0, dir_spread_deg=None):
     R = rand_rot(rs, max_deg)
     t = rs.randn(3); t *= rs.uniform(0.002, max_trans) / np.linalg.norm(t)
     # x_train = R x_query + t
     tA, tB, qA, qB, tcA, tcB, qcA, qcB = ([] for _ in range(8))
+    d0 = rs.randn(3); d0 /= np.linalg.norm(d0)
     for _ in range(n_lines + extra_lines):
         mid = rand_point_in_view(rs)
         d = rs.randn(3); d /= np.linalg.norm(d)
+        if dir_spread_deg is not None:          # near-degenerate geometry: all directions within a narrow cone (motion.cpp:367-420)
+            d = d0 + np.tan(np.deg2rad(dir_spread_deg)) * d * rs.uniform(0, 1)
+            d /= np.linalg.norm(d)
         ln = rs.uniform(0.15, 0.9)
         A, B = mid - 0.5 * ln * d, mid + 0.5 * ln * d
         if min(A[2], B[2]) < 0.5:
@@ -127,6 +131,27 @@ def pose_cases():
     return cs
 
 
+def pose_cases_extra():
+    """round 3: 150 more pairs -- larger line maps, the compiled maxima of the point side (256 / 400 / 512 matches), and
+    near-degenerate line geometry (all directions inside a 5 / 2 / 10 degree cone: the 3-line solver's angle gates,
+    motion.cpp:367-420).  Tuples as pose_cases() + the direction spread (None: isotropic)."""
+    cs = []
+    rs = np.random.RandomState(70)
+    for k in range(86):
+        nl = int(rs.choice([10, 11, 20, 48, 80, 100, 128, 160, 200, 250]))
+        lc = k % 5 == 4
+        cs.append(("xlines%02d" % k, nl, 0, 15.0 if lc else 4.0, 0.5 if lc else 0.08, float(rs.choice([0.0, 0.1, 0.25, 0.4, 0.6])),
+                   300 + k, (300 + k + 70 + k % 9) if lc else (301 + k + k % 4), 0, None))
+    for k in range(40):
+        nl = int(rs.choice([0, 3, 8, 20, 60, 120]))
+        npt = [256, 400, 512, 511, 300, 90, 150, 257][k % 8]
+        cs.append(("xhybrid%02d" % k, nl, npt, 5.0, 0.1, float(rs.choice([0.0, 0.15, 0.35])), 600 + k, 601 + k, 6 if k % 4 == 0 else 0, None))
+    for k in range(24):
+        nl = int(rs.choice([12, 24, 40, 64]))
+        cs.append(("xcone%02d" % k, nl, 0, 3.0, 0.06, float(rs.choice([0.0, 0.2])), 800 + k, 801 + k, 0, [5.0, 2.0, 10.0, 5.0][k % 4]))
+    return cs
+
+
 def rot_angle(Ra, Rb):
     """angle of Ra^T Rb, from the skew part (well conditioned near zero, unlike arccos of the trace)"""
     M = np.asarray(Ra, np.float64).T @ np.asarray(Rb, np.float64)
@@ -186,9 +211,11 @@ def main():
     out = {}
     names = []
     t0 = time.time()
-    for ci, (name, nl, npt, mdeg, mtr, ofr, idt, idq, nanp) in enumerate([] if "--mle-only" in sys.argv else pose_cases()):
-        rs = np.random.RandomState(1000 + ci)
-        train, query, pm, lm, T = make_pair(rs, nl, npt, mdeg, mtr, ofr, idt, idq, P, nan_pts=nanp)
+    extra = "--extra" in sys.argv
+    cases = [c + (None,) for c in pose_cases()] if not extra else pose_cases_extra()
+    for ci, (name, nl, npt, mdeg, mtr, ofr, idt, idq, nanp, cone) in enumerate([] if "--mle-only" in sys.argv else cases):
+        rs = np.random.RandomState((5000 if extra else 1000) + ci)
+        train, query, pm, lm, T = make_pair(rs, nl, npt, mdeg, mtr, ofr, idt, idq, P, nan_pts=nanp, dir_spread_deg=cone)
         r = I.pts_lines_ransac(train, query, pm, lm, P)
         names.append(name)
         for side, fr in (("t", train), ("q", query)):
@@ -221,7 +248,9 @@ def main():
             rot_angle(tf[:3, :3], T[:3, :3]), np.linalg.norm(tf[:3, 3] - T[:3, 3]), time.time() - t0), flush=True)
     if names:
         out["names"] = np.array(names)
-        np.savez_compressed(os.path.join(HERE, "pose_fixtures.npz"), **out)
+        np.savez_compressed(os.path.join(HERE, "pose_fixtures_extra.npz" if extra else "pose_fixtures.npz"), **out)
+    if extra:
+        return
 
     # ---- a11 / a17: support points -> MLE end points + covariances
     m = {}

@@ -55,6 +55,46 @@ def test_node_pair_with_point_matches(built_lib):
     assert found and np.array_equal(T, mr.final_trafo) and inl == mr.inlier_matches
 
 
+def test_match_node_pair_does_its_own_feature_matching(built_lib):
+    """Node::matchNodePair calls featureMatching itself (node.cpp:1504): with ORB descriptors on both nodes and no match list
+    handed in, the mirror runs lf_feature_match_node_pair (== the oracle's featureMatching) and solves on those matches."""
+    import _oracle as O
+    from lineslam_amd.node import Node
+    g, d, poses = synth.sequence(2, seed=5)
+    older, newer = Node(g[0], d[0], synth.K_TUM, 0), Node(g[1], d[1], synth.K_TUM, 1)
+    rng = np.random.default_rng(4)
+    n = 160
+    Pw = np.c_[rng.uniform(-1, 1, n), rng.uniform(-0.7, 0.7, n), rng.uniform(1.2, 3.0, n), np.ones(n)]
+    Pw = (poses[0] @ Pw.T).T
+    base = rng.integers(0, 256, (n, 32), dtype=np.uint8)                # one 256-bit descriptor per landmark ...
+    ident = {}
+    for node, pose in ((older, poses[0]), (newer, poses[1])):
+        pc = (np.linalg.inv(pose) @ Pw.T).T
+        pc[:, :3] += rng.normal(0, 0.002, (n, 3))
+        pc[:, 3] = 1
+        perm = rng.permutation(n)
+        desc = base.copy()
+        for i in range(n):                                               # ... seen with a few bits flipped per view
+            for bit in rng.integers(0, 256, 3):
+                desc[i, bit // 8] ^= np.uint8(1 << (bit % 8))
+        node.feature_locations_3d_ = np.ascontiguousarray(pc.astype(np.float32)[perm])
+        node.feature_descriptors_ = np.ascontiguousarray(desc[perm])
+        ident[node.id_] = perm
+    fm = []
+    assert newer.featureMatching(older, fm) == len(fm) > 100
+    oq, ot, od = O.feature_match_oracle(newer.feature_descriptors_, older.feature_descriptors_, 0.75, seed=newer.params.rng_seed,
+                                        stream=(1 << 32) ^ 0 ^ 0x4000000000000000)
+    assert [m[0] for m in fm] == oq.tolist() and [m[1] for m in fm] == ot.tolist()
+    assert np.array_equal(np.array([m[2] for m in fm], np.float32).view(np.uint32), od.view(np.uint32))
+    assert all(ident[1][q] == ident[0][t] for q, t, _ in fm)              # every match joins the two views of one landmark
+    mr_auto = newer.matchNodePair(older)                                  # no list: the library matches the descriptors itself
+    mr_given = newer.matchNodePair(older, fm)
+    assert mr_auto.all_matches == fm and mr_auto.inlier_matches == mr_given.inlier_matches and len(mr_auto.inlier_matches) > 80
+    assert np.array_equal(mr_auto.final_trafo, mr_given.final_trafo) and mr_auto.edge_id1 == 0
+    Tgt = np.linalg.inv(poses[0]) @ poses[1]
+    assert np.linalg.norm(mr_auto.final_trafo[:3, 3] - Tgt[:3, 3]) < 0.02
+
+
 def test_cpp_mirror_builds_and_agrees(built_lib, tmp_path):
     """include/linefront_compat.hpp (the C++ Node mirror) through examples/compat_smoke.cpp vs the Python mirror."""
     import os

@@ -112,6 +112,33 @@ def test_lapack_order_lu_two_statements_agree_bit_for_bit():
     assert lib.oracle_lu_product(C.c_void_p(Z.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(x.ctypes.data), 6) == 0
 
 
+def test_oracle_linalg_is_a_second_statement_of_the_products():
+    """oracle/o_linalg.h (what front_oracle.c / point_oracle.c compile since round 3) against the product's lf_linalg.h
+    (exported by oracle/product_hooks.c): Jacobi 3x3 / 4x4, cv::Mat::inv's LU with 1..6 right-hand sides, the 3x3 inverse and
+    the counter generator -- two independently written routines each, identical bits on random inputs."""
+    lib = O.oracle_lib("lf")
+    rng = np.random.default_rng(11)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    for n, mine, theirs in ((3, lib.oracle_jacobi3, lib.product_jacobi3), (4, lib.oracle_jacobi4, lib.product_jacobi4)):
+        for t in range(300):
+            B = rng.normal(size=(n, n)) * 10.0 ** rng.uniform(-4, 2)
+            A = B @ B.T if t % 3 else np.diag(rng.uniform(0, 1, n))       # (diagonal input: no rotation at all)
+            V1, w1, V2, w2 = np.zeros((n, n)), np.zeros(n), np.zeros((n, n)), np.zeros(n)
+            mine(vp(A), vp(V1), vp(w1)); theirs(vp(A), vp(V2), vp(w2))
+            assert V1.tobytes() == V2.tobytes() and w1.tobytes() == w2.tobytes()
+    lib.product_solve6.restype = C.c_int
+    lib.oracle_solve6.restype = C.c_int
+    for t in range(300):
+        A = rng.normal(size=(6, 6)); b = rng.normal(size=6); x1, x2 = np.zeros(6), np.zeros(6)
+        assert lib.oracle_solve6(vp(A), vp(b), vp(x1)) == 1 and lib.product_solve6(vp(A), vp(b), 1, vp(x2)) == 1
+        assert x1.tobytes() == x2.tobytes()
+    lib.oracle_rand31.restype = lib.product_rand31.restype = C.c_uint32
+    lib.oracle_rand31.argtypes = lib.product_rand31.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    for t in range(2000):
+        a = [int(v) for v in rng.integers(0, 2 ** 62, 3)]
+        assert lib.oracle_rand31(*a) == lib.product_rand31(*a)
+
+
 def test_rand31_is_a_31_bit_counter_generator():
     lib = O.oracle_lib("lf")
     lib.oracle_rand31.restype = C.c_uint32

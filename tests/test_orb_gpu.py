@@ -98,3 +98,55 @@ def test_orb_feeds_the_hybrid_solver_on_the_device(built_lib, orb):
         T = np.array(list(r.T), np.float64).reshape(4, 4)
         Tgt = np.linalg.inv(poses[i]) @ poses[i + 1]
         assert np.linalg.norm(T[:3, 3] - Tgt[:3, 3]) < 0.03
+
+
+def test_point_stream_beside_the_line_front_end_gives_the_same_results(built_lib, orb):
+    """lf_ctx_point_stream: ORB extraction + projectTo3D on the context's second stream, issued BEFORE detect3d and joined
+    stream-side in front of the feature matching (Node::Node's two threads, node.cpp:208-217 / 313-316) -- three rounds on one
+    context, every output equal to the serial order of a plain context."""
+    import torch
+    from lineslam_amd import capi
+    _, g, d, poses, P, (dg, dd), _ = orb
+    K = synth.K_TUM
+    cap = 600
+    q, t = np.arange(1, NF, dtype=np.int32), np.arange(0, NF - 1, dtype=np.int32)
+    ids = np.arange(NF, dtype=np.uint64)
+
+    def run(ctx, side, rounds):
+        st = torch.cuda.Stream()
+        outs = []
+        with torch.cuda.stream(st):
+            pass
+        ctx2 = capi.Context(640, 480, max_batch=NF, params=P, stream=st.cuda_stream) if ctx is None else ctx
+        if side:
+            ctx2.point_stream(True)
+        xy = torch.zeros((NF, cap, 2), dtype=torch.float32, device="cuda"); desc = torch.zeros((NF, cap, 32), dtype=torch.uint8, device="cuda")
+        nkp = torch.zeros(NF, dtype=torch.int32, device="cuda"); pts = torch.zeros((NF, cap, 4), dtype=torch.float32, device="cuda")
+        npts = torch.zeros(NF, dtype=torch.int32, device="cuda"); kept = torch.zeros((NF, cap), dtype=torch.int32, device="cuda")
+        mq = torch.zeros((NF, cap), dtype=torch.int32, device="cuda"); mt = torch.zeros_like(mq)
+        md = torch.zeros((NF, cap), dtype=torch.float32, device="cuda"); nm = torch.zeros(NF, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            for _ in range(rounds):
+                ctx2.orb_extract_device(dg.data_ptr(), dd.data_ptr(), NF, xy.data_ptr(), desc.data_ptr(), nkp.data_ptr(), cap)
+                ctx2.project_keypoints_device(dd.data_ptr(), NF, xy.data_ptr(), nkp.data_ptr(), cap, K, pts.data_ptr(), npts.data_ptr(), kept.data_ptr())
+                ctx2.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), NF, K, ids)
+                ctx2.point_join()
+                dsel = torch.gather(desc, 1, kept.long().clamp_(0, cap - 1).unsqueeze(-1).expand(-1, -1, 32)).contiguous()
+                ctx2.feature_match_pairs_device(dsel.data_ptr(), npts.data_ptr(), cap, q, t, mq.data_ptr(), mt.data_ptr(), md.data_ptr(),
+                                                nm.data_ptr(), nn_distance_ratio=0.75)
+                ctx2.match_pairs_hybrid_device_pm(q, t, pts.data_ptr(), cap, mq.data_ptr(), mt.data_ptr(), nm.data_ptr(), cap, K)
+        ctx2.synchronize()
+        torch.cuda.synchronize()
+        res = [ctx2.pair_result(i) for i in range(NF - 1)]
+        out = (xy.cpu().numpy(), desc.cpu().numpy(), nkp.cpu().numpy(), pts.cpu().numpy().view(np.uint32), npts.cpu().numpy(), nm.cpu().numpy(),
+               [bytes(bytearray(r.T)) for r in res], [(r.valid, r.n_point_matches, r.n_point_inliers, r.n_inliers) for r in res],
+               [ctx2.frame_lines(k).tobytes() for k in range(NF)])
+        ctx2.close()
+        return out
+    a = run(None, False, 1)
+    b = run(None, True, 3)
+    for x, y in zip(a[:6], b[:6]):
+        assert np.array_equal(x, y)
+    assert a[6] == b[6] and a[7] == b[7] and a[8] == b[8]
+    assert all(v[0] and v[2] > 40 for v in a[7])
