@@ -405,6 +405,26 @@ LF_API int lf_orb_extract_device(lf_ctx *ctx, const uint8_t *d_gray, size_t gray
                                  const float *d_depth, size_t depth_frame_stride, int depth_row_stride, int n_frames,
                                  int fast_threshold, int max_keypoints, float *d_kp_xy, float *d_kp_meta, uint8_t *d_desc,
                                  int32_t *d_nkp, int kp_cap);
+/* The same extractor behind the reference's threshold adapter (ParameterServer adjuster_max_iterations > 0, features.cpp:86-98):
+ * VideoDynamicAdaptedFeatureDetector around DetectorAdjuster("AORB", 20) (src/feature_adjuster.cpp:107-186) -- the FAST threshold
+ * is a STATE of the detector: x 0.7 (floor 2) when a detection returns fewer than min_features key points, the detection then
+ * repeated at most max_iters times; x 1.3 (ceiling 10000) when it returns more than max_features; the next frame -- and the
+ * next call -- starts with what the previous one left.  lf_orb_adjuster_init: the reference's values for `max_keypoints`
+ * (min = max_keypoints, max = 1.5 max_keypoints).  reset_state != 0 (or the first call): start from adj->thresh; otherwise from
+ * the state the context keeps on the device (lf_orb_adjuster_state reads it back: synchronises).  d_thresholds_out [n] (DEVICE,
+ * may be NULL): the threshold of the detection whose key points were returned, per frame.  Frames are taken in order: the
+ * thresholds are found by a sequential pass over per-frame score histograms, the detections run batched.  Asynchronous.
+ * The grid wrapper (VideoGridAdaptedFeatureDetector, detector_grid_resolution > 1: per-cell pyramids) is not built. */
+typedef struct lf_orb_adjuster {
+  double thresh, min_thresh, max_thresh, increase_factor, decrease_factor;
+  int32_t min_features, max_features, max_iters;
+} lf_orb_adjuster;
+LF_API void lf_orb_adjuster_init(lf_orb_adjuster *a, int max_keypoints, int max_iters);
+LF_API int lf_orb_extract_adjusted_device(lf_ctx *ctx, const uint8_t *d_gray, size_t gray_frame_stride, int gray_row_stride,
+                                          const float *d_depth, size_t depth_frame_stride, int depth_row_stride, int n_frames,
+                                          const lf_orb_adjuster *adj, int reset_state, int max_keypoints, float *d_kp_xy,
+                                          float *d_kp_meta, uint8_t *d_desc, int32_t *d_nkp, int kp_cap, int32_t *d_thresholds_out);
+LF_API int lf_orb_adjuster_state(lf_ctx *ctx, double *thresh);
 /* LF_ERR_CAPACITY if a frame of the last lf_orb_extract_device call had more corners than the extractor can rank
  * (16384 after non-maximum suppression) or more key points than kp_cap; LF_OK otherwise.  Synchronises. */
 LF_API int lf_orb_check(lf_ctx *ctx);

@@ -85,6 +85,9 @@ SYMBOLS = {
     "lf_ingest_tum_device": (_i, [_vp, _vp, _vp, _i, C.c_double, _vp, _vp]),
     "lf_project_keypoints_device": (_i, [_vp, _vp, C.c_size_t, _i, _i, _vp, _vp, _i, _vp, C.c_double, _i, _vp, _vp, _vp]),
     "lf_feature_match_pairs_device": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, C.c_double, _vp, _vp, _vp, _vp]),
+    "lf_orb_adjuster_init": (None, [_vp, _i, _i]),
+    "lf_orb_extract_adjusted_device": (_i, [_vp, _vp, C.c_size_t, _i, _vp, C.c_size_t, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "lf_orb_adjuster_state": (_i, [_vp, _vp]),
     "lf_ctx_point_stream": (_i, [_vp, _i]),
     "lf_ctx_point_join": (_i, [_vp]),
     "lf_feature_match_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, C.c_uint64, C.c_double, _vp, _vp, _vp, _i, _pi]),
@@ -121,6 +124,17 @@ SYMBOLS = {
     "lf_allgather_keyframes": (_i, [_vp, _vp, _i, C.c_uint64, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _pi, _pi]),
     "lf_line_matching_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, C.c_uint64, _i, _vp, _vp, _vp, _i, _pi]),
 }
+
+
+class LfOrbAdjuster(C.Structure):
+    _fields_ = [("thresh", C.c_double), ("min_thresh", C.c_double), ("max_thresh", C.c_double), ("increase_factor", C.c_double),
+                ("decrease_factor", C.c_double), ("min_features", C.c_int32), ("max_features", C.c_int32), ("max_iters", C.c_int32)]
+
+
+def orb_adjuster(max_keypoints=600, max_iters=5):
+    a = LfOrbAdjuster()
+    lib().lf_orb_adjuster_init(C.byref(a), int(max_keypoints), int(max_iters))
+    return a
 
 
 class _DevArray:
@@ -382,6 +396,21 @@ class Context:
                                               n_frames, int(fast_threshold), int(max_keypoints), _vp(d_kp_xy_ptr),
                                               _vp(d_kp_meta_ptr) if d_kp_meta_ptr else None, _vp(d_desc_ptr), _vp(d_nkp_ptr), int(kp_cap)),
                   "lf_orb_extract_device")
+
+    def orb_extract_adjusted_device(self, d_gray_ptr, d_depth_ptr, n_frames, d_kp_xy_ptr, d_desc_ptr, d_nkp_ptr, kp_cap, adjuster,
+                                    reset_state=False, d_kp_meta_ptr=0, max_keypoints=600, d_thresholds_ptr=0):
+        """orb_extract_device behind VideoDynamicAdaptedFeatureDetector (adjuster = LfOrbAdjuster): the FAST threshold adapts from
+        frame to frame; the state stays on the device (orb_adjuster_state reads it back)."""
+        w, h = self.width, self.height
+        self._chk(lib().lf_orb_extract_adjusted_device(self._h, _vp(d_gray_ptr), w * h, w, _vp(d_depth_ptr) if d_depth_ptr else None, w * h, w,
+                                                       n_frames, C.byref(adjuster), int(bool(reset_state)), int(max_keypoints), _vp(d_kp_xy_ptr),
+                                                       _vp(d_kp_meta_ptr) if d_kp_meta_ptr else None, _vp(d_desc_ptr), _vp(d_nkp_ptr), int(kp_cap),
+                                                       _vp(d_thresholds_ptr) if d_thresholds_ptr else None), "lf_orb_extract_adjusted_device")
+
+    def orb_adjuster_state(self):
+        t = C.c_double()
+        self._chk(lib().lf_orb_adjuster_state(self._h, C.byref(t)), "lf_orb_adjuster_state")
+        return t.value
 
     def orb_check(self):
         self._chk(lib().lf_orb_check(self._h), "lf_orb_check")

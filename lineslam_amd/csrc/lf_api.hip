@@ -56,6 +56,9 @@ struct lf_ctx {
   hipStream_t pstream = nullptr;
   hipEvent_t ev_pts_in = nullptr, ev_pts_done = nullptr, ev_pts_free = nullptr;
   bool pts_async = false, pts_pending = false, pts_free_rec = false;
+  bool orb_adj_set = false; double h_orb_adj = 0.0;
+  int *d_orb_thr = nullptr;          // [maxB] per-frame FAST thresholds of the adjusted extractor
+  double *d_orb_adj = nullptr;       // [1] DetectorAdjuster::thresh_ (device-resident state, carried from call to call)
   uint8_t *d_fm_stage = nullptr;     // lf_feature_match_node_pair staging: 2 x 1024 descriptors of 32 bytes (first use)
   int32_t *d_fm_n = nullptr, *d_fm_q = nullptr, *d_fm_t = nullptr, *d_fm_cnt = nullptr;
   float *d_fm_d = nullptr;
@@ -1616,6 +1619,8 @@ static int orb_prepare(lf_ctx *c) {
   ALLOC(c, b.cand, B * LF_ORB_CAND_CAP); ALLOC(c, b.ncand, B); ALLOC(c, b.hist, B * LF_ORB_LEVELS * 256);
   ALLOC(c, b.sel, B * LF_ORB_KP_MAX * 4); ALLOC(c, b.nsel, B);
   ALLOC(c, c->d_orb_nkp, 2 * B);
+  ALLOC(c, c->d_orb_thr, B);
+  ALLOC(c, c->d_orb_adj, 1);
   c->orb_ready = true;
   return LF_OK;
 }
@@ -1641,6 +1646,61 @@ int lf_orb_extract_device(lf_ctx *c, const uint8_t *d_gray, size_t gray_frame_st
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(d_nkp, c->ob.nsel, sizeof(int) * (size_t)n_frames, hipMemcpyDeviceToDevice, pst));
   c->orb_last = n_frames;
+  return LF_OK;
+}
+
+void lf_orb_adjuster_init(lf_orb_adjuster *a, int max_keypoints, int max_iters) {
+  if (!a) return;
+  a->thresh = 20.0; a->min_thresh = 2.0; a->max_thresh = 10000.0;          // DetectorAdjuster("AORB", 20), features.cpp:75-76, feature_adjuster.h:15
+  a->increase_factor = 1.3; a->decrease_factor = 0.7;
+  a->min_features = max_keypoints;                                            // features.cpp:88-90: "shall not get below max"
+  a->max_features = (int)(max_keypoints * 1.5);
+  a->max_iters = max_iters;
+}
+int lf_orb_extract_adjusted_device(lf_ctx *c, const uint8_t *d_gray, size_t gray_frame_stride, int gray_row_stride, const float *d_depth,
+                                   size_t depth_frame_stride, int depth_row_stride, int n_frames, const lf_orb_adjuster *adj, int reset_state,
+                                   int max_keypoints, float *d_kp_xy, float *d_kp_meta, uint8_t *d_desc, int32_t *d_nkp, int kp_cap,
+                                   int32_t *d_thresholds_out) {
+  if (!c || !d_gray || !d_kp_xy || !d_desc || !d_nkp || !adj || n_frames < 1 || gray_row_stride < c->W || kp_cap < 1 || max_keypoints < 1 ||
+      (d_depth && depth_row_stride < c->W))
+    return LF_ERR_INVALID;
+  if (!(adj->min_thresh >= 1.0) || !(adj->max_thresh > adj->min_thresh) || !(adj->increase_factor > 1.0) || !(adj->decrease_factor > 0.0) ||
+      !(adj->decrease_factor < 1.0) || adj->max_iters < 1 || adj->min_features < 0 || adj->max_features < adj->min_features)
+    return LF_ERR_INVALID;
+  if (n_frames > c->maxB) return LF_ERR_CAPACITY;
+  if (max_keypoints > LF_ORB_KP_MAX) return LF_ERR_UNSUPPORTED;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->orb_ready) { int r = orb_prepare(c); if (r != LF_OK) return r; }
+  hipStream_t pst = pt_stream_begin(c);
+  if (reset_state || !c->orb_adj_set) {
+    c->h_orb_adj = adj->thresh;                             // (a member: the copy is asynchronous)
+    HIPCHK(c, hipMemcpyAsync(c->d_orb_adj, &c->h_orb_adj, sizeof(double), hipMemcpyHostToDevice, pst));
+    c->orb_adj_set = true;
+  }
+  OrbConsts oc = c->oc;
+  oc.max_keypoints = max_keypoints; oc.kp_cap = kp_cap;
+  OrbBuffers ob = c->ob;
+  ob.gray = d_gray; ob.gray_frame_stride = gray_frame_stride; ob.gray_row_stride = gray_row_stride;
+  ob.depth = d_depth; ob.depth_frame_stride = depth_frame_stride; ob.depth_row_stride = depth_row_stride;
+  ob.kp_xy = d_kp_xy; ob.kp_meta = d_kp_meta; ob.desc = d_desc; ob.nkp = c->d_orb_nkp;
+  ob.thr_frame = c->d_orb_thr; ob.adj_state = c->d_orb_adj;
+  OrbAdjuster a;
+  a.min_thresh = adj->min_thresh; a.max_thresh = adj->max_thresh; a.inc = adj->increase_factor; a.dec = adj->decrease_factor;
+  a.min_features = adj->min_features; a.max_features = adj->max_features; a.max_iters = adj->max_iters;
+  a.base_threshold = (int)adj->min_thresh;                  // the lowest threshold a detection can be made with
+  lf_orb_launch_adjusted(oc, ob, a, n_frames, pst);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(d_nkp, c->ob.nsel, sizeof(int) * (size_t)n_frames, hipMemcpyDeviceToDevice, pst));
+  if (d_thresholds_out) HIPCHK(c, hipMemcpyAsync(d_thresholds_out, c->d_orb_thr, sizeof(int) * (size_t)n_frames, hipMemcpyDeviceToDevice, pst));
+  c->orb_last = n_frames;
+  return LF_OK;
+}
+int lf_orb_adjuster_state(lf_ctx *c, double *thresh) {
+  if (!c || !thresh || !c->orb_ready || !c->orb_adj_set) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  pt_stream_join(c);
+  HIPCHK(c, hipMemcpyAsync(thresh, c->d_orb_adj, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return LF_OK;
 }
 

@@ -40,6 +40,12 @@ struct OrbBuffers {
   float *kp_meta;                 // [B][kp_cap][4]   out (may be null): response, angle [deg], octave, size
   uint8_t *desc;                  // [B][kp_cap][32]  out
   int *nkp;                       // [B] out; [B + f] = 1 if frame f had more than LF_ORB_CAND_CAP corners (overflow)
+  // VideoDynamicAdaptedFeatureDetector (src/feature_adjuster.cpp:107-186): per-frame FAST thresholds chosen on the device
+  int *thr_frame;                 // [B] threshold of the detection whose key points are returned (null: c.fast_threshold for all)
+  double *adj_state;              // [1] DetectorAdjuster::thresh_, carried from frame to frame and from call to call
 };
+struct OrbAdjuster { double min_thresh, max_thresh, inc, dec; int min_features, max_features, max_iters, base_threshold; };
 
 void lf_orb_launch(const OrbConsts &c, const OrbBuffers &b, int n_frames, hipStream_t stream);
+// the same with the dynamically adapted FAST threshold: b.thr_frame / b.adj_state must be set
+void lf_orb_launch_adjusted(const OrbConsts &c, const OrbBuffers &b, const OrbAdjuster &a, int n_frames, hipStream_t stream);

@@ -157,6 +157,12 @@ __global__ void __launch_bounds__(256) k_orb_fast(OrbConsts c, OrbBuffers b, int
 
 // 3x3 strict non-maximum suppression (fast.cpp) + KeyPointsFilter::runByImageBorder(edgeThreshold 31): candidates of all levels
 // into one per-frame list (unordered: the selection sorts), FAST score histograms per level for retainBest(2 n)
+// MODE 0: candidates + histogram at the threshold the score image was made with.  MODE 1: histogram only (the adjuster's
+// counting pass at its base threshold).  MODE 2: candidates + histogram of the corners with score >= thr_frame[f] -- a corner
+// at threshold t is a pixel whose score (largest threshold it survives, minus one) is >= t, and raising the threshold can
+// neither free a suppressed pixel (its stronger neighbour is still a corner) nor suppress a new one, so the non-maximum-
+// suppressed corners at t are those of the base threshold with score >= t, exactly.
+template <int MODE>
 __global__ void __launch_bounds__(256) k_orb_nms(OrbConsts c, OrbBuffers b, int l) {
   const int f = blockIdx.y, W = c.lw[l], H = c.lh[l];
   const uint8_t *sc = b.score + (size_t)f * c.total + c.loff[l];
@@ -166,12 +172,50 @@ __global__ void __launch_bounds__(256) k_orb_nms(OrbConsts c, OrbBuffers b, int 
   if (!(x >= LF_ORB_EDGE && x < W - LF_ORB_EDGE && y >= LF_ORB_EDGE && y < H - LF_ORB_EDGE)) return;
   const int s = sc[i];
   if (!s) return;
+  if (MODE == 2 && s < b.thr_frame[f]) return;
   if (s > sc[i + 1] && s > sc[i - 1] && s > sc[i - W - 1] && s > sc[i - W] && s > sc[i - W + 1] && s > sc[i + W - 1] && s > sc[i + W] &&
       s > sc[i + W + 1]) {
-    const int at = atomicAdd(&b.ncand[f], 1);
-    if (at < LF_ORB_CAND_CAP) b.cand[(size_t)f * LF_ORB_CAND_CAP + at] = ((unsigned)s << 24) | ((unsigned)l << 19) | ((unsigned)y << 10) | (unsigned)x;
+    if (MODE != 1) {
+      const int at = atomicAdd(&b.ncand[f], 1);
+      if (at < LF_ORB_CAND_CAP) b.cand[(size_t)f * LF_ORB_CAND_CAP + at] = ((unsigned)s << 24) | ((unsigned)l << 19) | ((unsigned)y << 10) | (unsigned)x;
+    }
     atomicAdd(&b.hist[((size_t)f * LF_ORB_LEVELS + l) * 256 + s], 1);
   }
+}
+
+// ---- VideoDynamicAdaptedFeatureDetector::detectImpl + DetectorAdjuster (src/feature_adjuster.cpp:107-186): the FAST threshold
+// is a STATE of the detector -- multiplied by 0.7 when a detection returns fewer than min_features key points (and the
+// detection repeated, at most max_iters times), by 1.3 when it returns more than max_features -- and the next frame starts
+// with what the previous one left.  The number of key points AorbFeatureDetector::detect returns at threshold t is
+// sum over the levels of min(#corners of the level with score >= t, nfeaturesPerLevel): suffix sums of the score histograms
+// (one thread per frame and level), then ONE thread walks the frames in order.
+__global__ void __launch_bounds__(64) k_orb_suffix(OrbConsts c, OrbBuffers b, int B) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= B * LF_ORB_LEVELS) return;
+  int *h = b.hist + (size_t)i * 256;
+  int acc = 0;
+  for (int s = 255; s >= 0; s--) { acc += h[s]; h[s] = acc; }      // h[t] = corners with score >= t
+}
+__global__ void k_orb_adjust(OrbConsts c, OrbBuffers b, OrbAdjuster a, int B) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double thresh = *b.adj_state;
+  for (int f = 0; f < B; f++) {
+    const int *h = b.hist + (size_t)f * LF_ORB_LEVELS * 256;
+    int iter = a.max_iters, t;
+    do {                                                    // detect at least once
+      t = (int)thresh;                                      // static_cast<int>(thresh_), feature_adjuster.cpp:86
+      int tc = t < 0 ? 0 : (t > 255 ? 255 : t);             // cv::FAST clamps its threshold
+      if (tc < a.base_threshold) tc = a.base_threshold;     // (cannot happen: base_threshold <= min_thresh)
+      int n = 0;
+      for (int l = 0; l < LF_ORB_LEVELS; l++) { const int nl = h[l * 256 + tc]; n += nl < c.nper[l] ? nl : c.nper[l]; }
+      if (n < a.min_features) { thresh *= a.dec; if (thresh < a.min_thresh) thresh = a.min_thresh; }            // tooFew
+      else if (n > a.max_features) { thresh *= a.inc; if (thresh > a.max_thresh) thresh = a.max_thresh; break; }   // tooMany
+      else break;
+      iter--;
+    } while (iter > 0 && thresh > a.min_thresh && thresh < a.max_thresh);
+    b.thr_frame[f] = t < 0 ? 0 : (t > 255 ? 255 : t);
+  }
+  *b.adj_state = thresh;
 }
 
 // ---------------------------------------------------------------------------------------------------- selection
@@ -439,7 +483,7 @@ __global__ void __launch_bounds__(64) k_orb_describe(OrbConsts c, OrbBuffers b) 
   }
 }
 
-void lf_orb_launch(const OrbConsts &c, const OrbBuffers &b, int B, hipStream_t st) {
+static void orb_pyramid_and_scores(const OrbConsts &c, const OrbBuffers &b, int B, hipStream_t st) {
   static bool pattern_up = false;
   if (!pattern_up) { (void)hipMemcpyToSymbol(HIP_SYMBOL(c_orb_pattern), LF_ORB_PATTERN, 1024); pattern_up = true; }
   (void)hipMemsetAsync(b.ncand, 0, sizeof(int) * (size_t)B, st);
@@ -451,8 +495,27 @@ void lf_orb_launch(const OrbConsts &c, const OrbBuffers &b, int B, hipStream_t s
     hipLaunchKernelGGL(k_orb_blur, dim3((c.lw[l] + OB_TW - 1) / OB_TW, (c.lh[l] + OB_TH - 1) / OB_TH, B), dim3(256), 0, st, c, b, l);
     hipLaunchKernelGGL(k_orb_fast, dim3((c.lw[l] * c.lh[l] + 255) / 256, B), dim3(256), 0, st, c, b, l);
   }
-  for (int l = 0; l < LF_ORB_LEVELS; l++)
-    hipLaunchKernelGGL(k_orb_nms, dim3((c.lw[l] * c.lh[l] + 255) / 256, B), dim3(256), 0, st, c, b, l);
+}
+static void orb_select_and_describe(const OrbConsts &c, const OrbBuffers &b, int B, hipStream_t st) {
   hipLaunchKernelGGL(k_orb_select, dim3(B), dim3(OS_N), 0, st, c, b);
   hipLaunchKernelGGL(k_orb_describe, dim3(c.kp_cap < LF_ORB_KP_MAX ? c.kp_cap : LF_ORB_KP_MAX, B), dim3(64), 0, st, c, b);
+}
+void lf_orb_launch(const OrbConsts &c, const OrbBuffers &b, int B, hipStream_t st) {
+  orb_pyramid_and_scores(c, b, B, st);
+  for (int l = 0; l < LF_ORB_LEVELS; l++)
+    hipLaunchKernelGGL(k_orb_nms<0>, dim3((c.lw[l] * c.lh[l] + 255) / 256, B), dim3(256), 0, st, c, b, l);
+  orb_select_and_describe(c, b, B, st);
+}
+void lf_orb_launch_adjusted(const OrbConsts &c0, const OrbBuffers &b, const OrbAdjuster &a, int B, hipStream_t st) {
+  OrbConsts c = c0;
+  c.fast_threshold = a.base_threshold;                      // ONE score image, at the lowest threshold the adjuster can reach
+  orb_pyramid_and_scores(c, b, B, st);
+  for (int l = 0; l < LF_ORB_LEVELS; l++)                    // count: score histograms of the corners at the base threshold
+    hipLaunchKernelGGL(k_orb_nms<1>, dim3((c.lw[l] * c.lh[l] + 255) / 256, B), dim3(256), 0, st, c, b, l);
+  hipLaunchKernelGGL(k_orb_suffix, dim3((B * LF_ORB_LEVELS + 63) / 64), dim3(64), 0, st, c, b, B);
+  hipLaunchKernelGGL(k_orb_adjust, dim3(1), dim3(64), 0, st, c, b, a, B);
+  (void)hipMemsetAsync(b.hist, 0, sizeof(int) * (size_t)B * LF_ORB_LEVELS * 256, st);
+  for (int l = 0; l < LF_ORB_LEVELS; l++)                    // the corners of every frame at ITS threshold
+    hipLaunchKernelGGL(k_orb_nms<2>, dim3((c.lw[l] * c.lh[l] + 255) / 256, B), dim3(256), 0, st, c, b, l);
+  orb_select_and_describe(c, b, B, st);
 }

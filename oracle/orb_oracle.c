@@ -280,12 +280,15 @@ static void o_descriptor(const uint8_t *img, int w, float px, float py, float an
 /* Node::Node, ORB branch.  gray [h][w]; depth [h][dstride] floats or NULL (no removeDepthless); outputs at most
  * max_keypoints rows: kp_xy (x, y in level-0 pixels), kp_meta (response, angle [deg], octave, size), desc (32 bytes).
  * levels_out / blurred_out (optional): the eight pyramid levels / their blurred versions, concatenated.            */
-int oracle_orb_extract(const uint8_t *gray, int w, int h, const float *depth, int dstride, int fast_threshold, int nfeatures,
-                       int max_keypoints, float *kp_xy, float *kp_meta, uint8_t *desc, uint8_t *levels_out, uint8_t *blurred_out) {
-  uint8_t *lev[ORB_LEVELS], *blur[ORB_LEVELS], *score;
-  int lw[ORB_LEVELS], lh[ORB_LEVELS], nper[ORB_LEVELS], umax[ORB_HALF + 2], l, n_all = 0, order = 0, i, n_out;
+/* AorbFeatureDetector::detect (aorb.cpp:727-940) on one frame: pyramid, FAST + non-maximum suppression + border filter, the
+ * two retainBest steps per level, Harris responses, angles; key points in level order (coordinates scaled to level 0).
+ * Returns their number -- what VideoDynamicAdaptedFeatureDetector counts.  lev / blur [ORB_LEVELS]: malloc'd here when
+ * want_images (the caller frees), else freed here.                                                                    */
+static int o_orb_detect(const uint8_t *gray, int w, int h, int fast_threshold, int nfeatures, o_kp *all, uint8_t **lev, uint8_t **blur,
+                        int *lw, int *lh, int want_images, uint8_t *levels_out, uint8_t *blurred_out) {
+  uint8_t *score;
+  int nper[ORB_LEVELS], umax[ORB_HALF + 2], l, n_all = 0, order = 0, i;
   size_t off = 0;
-  o_kp *all = (o_kp *)malloc(sizeof(o_kp) * (size_t)w * h / 4 + 64);
   {   /* nfeaturesPerLevel (aorb.cpp:612-624) */
     float factor = (float)(1.0 / (double)1.2f);
     float nd = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)ORB_LEVELS));
@@ -297,12 +300,12 @@ int oracle_orb_extract(const uint8_t *gray, int w, int h, const float *depth, in
   for (l = 0; l < ORB_LEVELS; l++) {
     oracle_orb_level_size(w, h, l, &lw[l], &lh[l]);
     lev[l] = (uint8_t *)malloc((size_t)lw[l] * lh[l]);
-    blur[l] = (uint8_t *)malloc((size_t)lw[l] * lh[l]);
+    blur[l] = want_images ? (uint8_t *)malloc((size_t)lw[l] * lh[l]) : 0;
     if (l == 0) memcpy(lev[0], gray, (size_t)w * h);
     else oracle_orb_resize(lev[l - 1], lw[l - 1], lh[l - 1], lev[l], lw[l], lh[l]);
-    oracle_orb_blur(lev[l], lw[l], lh[l], blur[l]);
+    if (want_images) oracle_orb_blur(lev[l], lw[l], lh[l], blur[l]);
     if (levels_out) memcpy(levels_out + off, lev[l], (size_t)lw[l] * lh[l]);
-    if (blurred_out) memcpy(blurred_out + off, blur[l], (size_t)lw[l] * lh[l]);
+    if (blurred_out && want_images) memcpy(blurred_out + off, blur[l], (size_t)lw[l] * lh[l]);
     off += (size_t)lw[l] * lh[l];
   }
   score = (uint8_t *)malloc((size_t)w * h);
@@ -334,6 +337,45 @@ int oracle_orb_extract(const uint8_t *gray, int w, int h, const float *depth, in
     }
     n_all += n;
   }
+  free(score);
+  if (!want_images) for (l = 0; l < ORB_LEVELS; l++) free(lev[l]);
+  return n_all;
+}
+
+/* VideoDynamicAdaptedFeatureDetector::detectImpl around DetectorAdjuster("AORB", thresh) (src/feature_adjuster.cpp:107-186), frame
+ * after frame with ONE detector object, i.e. the threshold state carried along: every detection is really run
+ * (AorbFeatureDetector::detect at static_cast<int>(thresh_)) and counted.  thr_out[f] = the threshold of the LAST detection of
+ * frame f (whose key points the caller receives); *thresh_io = DetectorAdjuster::thresh_ before / after.               */
+void oracle_orb_adjust_thresholds(const uint8_t *gray, int n_frames, int w, int h, int nfeatures, double *thresh_io, double min_thresh,
+                                  double max_thresh, double inc, double dec, int min_features, int max_features, int max_iters,
+                                  int *thr_out, int *count_out) {
+  o_kp *all = (o_kp *)malloc(sizeof(o_kp) * (size_t)w * h / 4 + 64);
+  uint8_t *lev[ORB_LEVELS], *blur[ORB_LEVELS];
+  int lw[ORB_LEVELS], lh[ORB_LEVELS], f;
+  double thresh = *thresh_io;
+  for (f = 0; f < n_frames; f++) {
+    int iter = max_iters, t, n;
+    do {
+      t = (int)thresh;
+      n = o_orb_detect(gray + (size_t)f * w * h, w, h, t, nfeatures, all, lev, blur, lw, lh, 0, 0, 0);
+      if (n < min_features) { thresh *= dec; if (thresh < min_thresh) thresh = min_thresh; }
+      else if (n > max_features) { thresh *= inc; if (thresh > max_thresh) thresh = max_thresh; break; }
+      else break;
+      iter--;
+    } while (iter > 0 && thresh > min_thresh && thresh < max_thresh);
+    thr_out[f] = t < 0 ? 0 : (t > 255 ? 255 : t);
+    if (count_out) count_out[f] = n;
+  }
+  *thresh_io = thresh;
+  free(all);
+}
+
+int oracle_orb_extract(const uint8_t *gray, int w, int h, const float *depth, int dstride, int fast_threshold, int nfeatures,
+                       int max_keypoints, float *kp_xy, float *kp_meta, uint8_t *desc, uint8_t *levels_out, uint8_t *blurred_out) {
+  uint8_t *lev[ORB_LEVELS], *blur[ORB_LEVELS];
+  int lw[ORB_LEVELS], lh[ORB_LEVELS], l, n_all, i, n_out;
+  o_kp *all = (o_kp *)malloc(sizeof(o_kp) * (size_t)w * h / 4 + 64);
+  n_all = o_orb_detect(gray, w, h, fast_threshold, nfeatures, all, lev, blur, lw, lh, 1, levels_out, blurred_out);
   /* Node: removeDepthless, retainBest(max_keypoints) + resize */
   if (depth) {
     int m = 0;
@@ -370,6 +412,6 @@ int oracle_orb_extract(const uint8_t *gray, int w, int h, const float *depth, in
     }
   }
   for (l = 0; l < ORB_LEVELS; l++) { free(lev[l]); free(blur[l]); }
-  free(score); free(all);
+  free(all);
   return n_out;
 }

@@ -342,3 +342,18 @@ def edlines_oracle(gray_u8, flavour="ref", cap=4096, debug=False):
         lib.oracle_edlines(C.c_void_p(g.ctypes.data), C.c_int(w), C.c_int(h), C.c_void_p(segs.ctypes.data), C.c_int(cap), None, None, None, None)
     out = segs[:min(n, cap)].copy()
     return (out, S, G, D, E) if debug else out
+
+
+def orb_adjust_oracle(gray_frames_u8, thresh=20.0, min_thresh=2.0, max_thresh=10000.0, inc=1.3, dec=0.7, min_features=600, max_features=900,
+                      max_iters=5, nfeatures=10000, flavour="lf"):
+    """oracle_orb_adjust_thresholds: VideoDynamicAdaptedFeatureDetector over consecutive frames with one detector object (every
+    detection really run and counted).  Returns (thresholds [n] of the returned detections, counts [n], final thresh_)."""
+    lib = oracle_lib(flavour)
+    g = np.ascontiguousarray(gray_frames_u8, np.uint8)
+    n, h, w = g.shape
+    thr, cnt = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    st = C.c_double(thresh)
+    lib.oracle_orb_adjust_thresholds(C.c_void_p(g.ctypes.data), C.c_int(n), C.c_int(w), C.c_int(h), C.c_int(nfeatures), C.byref(st),
+                                     C.c_double(min_thresh), C.c_double(max_thresh), C.c_double(inc), C.c_double(dec), C.c_int(min_features),
+                                     C.c_int(max_features), C.c_int(max_iters), C.c_void_p(thr.ctypes.data), C.c_void_p(cnt.ctypes.data))
+    return thr, cnt, st.value

@@ -150,3 +150,51 @@ def test_point_stream_beside_the_line_front_end_gives_the_same_results(built_lib
         assert np.array_equal(x, y)
     assert a[6] == b[6] and a[7] == b[7] and a[8] == b[8]
     assert all(v[0] and v[2] > 40 for v in a[7])
+
+
+def test_dynamically_adapted_threshold_follows_the_reference_adapter(built_lib, orb):
+    """lf_orb_extract_adjusted_device = the extractor behind VideoDynamicAdaptedFeatureDetector (feature_adjuster.cpp:107-186):
+    the thresholds the device derives from its score histograms equal the ones of the oracle's detector object that really
+    repeats the detections, frame after frame and across two calls (the state stays on the device); the key points of every
+    frame are those of the plain extractor at that frame's threshold, bit for bit."""
+    import torch
+    from lineslam_amd import capi
+    ctx, g, d, _, _, (dg, dd), _ = orb
+    # frames with different corner counts -- the synthetic frames, low-contrast copies (too few corners) and noisy copies (too
+    # many) -- in an order that makes the threshold travel both ways: 20 -> 26 -> 33 -> (three repeated detections) 11 -> 15 -> 19
+    rng = np.random.default_rng(3)
+    lo = lambda a, k: (a.astype(np.float32) * k + 128 * (1 - k)).astype(np.uint8)
+    hi = lambda a, s: np.clip(a.astype(np.int32) + rng.integers(-s, s + 1, a.shape), 0, 255).astype(np.uint8)
+    frames = np.stack([g[0], hi(g[2], 14), hi(g[2], 14), lo(g[1], 0.35), g[0], lo(g[1], 0.5), hi(g[2], 8), g[3], lo(g[1], 0.35), g[1]])
+    depth = np.stack([d[0], d[2], d[2], d[1], d[0], d[1], d[2], d[3], d[1], d[1]])
+    n = len(frames)
+    big = capi.Context(640, 480, max_batch=n, params=capi.default_params(launch=True))
+    fg, fd = torch.from_numpy(frames).cuda(), torch.from_numpy(depth).cuda()
+    cap = 600
+    xy = torch.zeros((n, cap, 2), dtype=torch.float32, device="cuda"); desc = torch.zeros((n, cap, 32), dtype=torch.uint8, device="cuda")
+    nkp = torch.zeros(n, dtype=torch.int32, device="cuda"); thr = torch.zeros(n, dtype=torch.int32, device="cuda")
+    adj = capi.orb_adjuster(max_keypoints=600, max_iters=5)
+    assert (adj.thresh, adj.min_thresh, adj.max_thresh, adj.min_features, adj.max_features) == (20.0, 2.0, 10000.0, 600, 900)
+    # first call: frames 0..5; second call continues with the device-resident state on frames 6..9
+    big.orb_extract_adjusted_device(fg.data_ptr(), fd.data_ptr(), 6, xy.data_ptr(), desc.data_ptr(), nkp.data_ptr(), cap, adj, reset_state=True,
+                                    d_thresholds_ptr=thr.data_ptr())
+    big.orb_check()
+    t1, k1 = thr[:6].cpu().numpy().copy(), nkp[:6].cpu().numpy().copy()
+    xy1, de1 = xy[:6].cpu().numpy().copy(), desc[:6].cpu().numpy().copy()
+    s1 = big.orb_adjuster_state()
+    big.orb_extract_adjusted_device(fg[6:].data_ptr(), fd[6:].data_ptr(), 4, xy.data_ptr(), desc.data_ptr(), nkp.data_ptr(), cap, adj,
+                                    reset_state=False, d_thresholds_ptr=thr.data_ptr())
+    big.orb_check()
+    t2, k2 = thr[:4].cpu().numpy().copy(), nkp[:4].cpu().numpy().copy()
+    xy2, de2 = xy[:4].cpu().numpy().copy(), desc[:4].cpu().numpy().copy()
+    s2 = big.orb_adjuster_state()
+    want_t, want_n, want_s = O.orb_adjust_oracle(frames)
+    o1, _, so1 = O.orb_adjust_oracle(frames[:6])
+    assert np.array_equal(np.concatenate([t1, t2]), want_t) and np.array_equal(t1, o1)
+    assert s1 == so1 and s2 == want_s
+    assert len(set(want_t.tolist())) >= 3 and want_t.min() < 20 < want_t.max()          # the threshold really moved, both ways
+    for f, (t, k, xyf, def_) in enumerate(list(zip(t1, k1, xy1, de1)) + list(zip(t2, k2, xy2, de2))):
+        oxy, ometa, odesc = O.orb_oracle(frames[f], depth[f], fast_threshold=int(t))
+        assert k == len(oxy), (f, t, k, len(oxy))
+        assert np.array_equal(xyf[:k], oxy) and np.array_equal(def_[:k], odesc), f
+    big.close()
