@@ -338,10 +338,19 @@ __global__ void __launch_bounds__(OS_N) k_orb_select(OrbConsts c, OrbBuffers b) 
       keys[i] = k;
     }
   }
-  o_sort(keys, n2);
-  // the first max_keypoints of that order (KeyPointsFilter::retainBest + resize, node.cpp:260-263); count the valid ones
+  __syncthreads();
   for (int i = tid; i < n2; i += OS_N) if (keys[i] != ~0ull) atomicAdd(&s_n, 1);
   __syncthreads();
+  // KeyPointsFilter::retainBest(max_keypoints) + resize ONLY when there are more key points than that (node.cpp:257-263):
+  // then the order is by response; otherwise the list keeps AORB's detection order (level by level, row-major)
+  const bool keep_order = s_n <= c.max_keypoints;
+  if (keep_order)
+    for (int i = tid; i < n2; i += OS_N) { const u64 k = keys[i]; if (k != ~0ull) keys[i] = ((k & 0x3fffffull) << 32) | ((k >> 22) & 0xffffffffull); }
+  o_sort(keys, n2);
+  if (keep_order) {
+    for (int i = tid; i < n2; i += OS_N) { const u64 k = keys[i]; if (k != ~0ull) keys[i] = ((k & 0xffffffffull) << 22) | (k >> 32); }
+    __syncthreads();
+  }
   int m = s_n < c.max_keypoints ? s_n : c.max_keypoints;
   if (m > LF_ORB_KP_MAX) m = LF_ORB_KP_MAX;
   // key C: cluster by octave keeping the rank inside an octave (OrbDescriptorExtractor::compute), border filter on level 0
