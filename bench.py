@@ -78,6 +78,9 @@ def parse():
                     help="BASELINE configs[2] instead of configs[1]: fused point + line odometry -- projectTo3D, Hamming "
                          "feature matching and the hybrid RANSAC / LM solver on the key points of the HIP ORB extractor; "
                          "not the headline workload")
+    ap.add_argument("--adjuster-iters", type=int, default=0,
+                    help="with --points: ParameterServer adjuster_max_iterations -- > 0 puts the ORB detector behind the reference's "
+                         "VideoDynamicAdaptedFeatureDetector (FAST threshold adapted from frame to frame, 600..900 key points)")
     ap.add_argument("--serial-points", action="store_true",
                     help="with --points: the point front end on the context's own stream instead of beside the line front end")
     ap.add_argument("--default-params", action="store_true",
@@ -232,7 +235,9 @@ def main():
                 pts=torch.zeros((F, NK, 4), dtype=torch.float32, device="cuda"), npts=torch.zeros(F, dtype=torch.int32, device="cuda"),
                 kept=torch.zeros((F, NK), dtype=torch.int32, device="cuda"),
                 mq=torch.zeros((F, NK), dtype=torch.int32, device="cuda"), mt=torch.zeros((F, NK), dtype=torch.int32, device="cuda"),
-                md=torch.zeros((F, NK), dtype=torch.float32, device="cuda"), nm=torch.zeros(F, dtype=torch.int32, device="cuda")))
+                md=torch.zeros((F, NK), dtype=torch.float32, device="cuda"), nm=torch.zeros(F, dtype=torch.int32, device="cuda"),
+                thr=torch.zeros(F, dtype=torch.int32, device="cuda")))
+        orb_adj = capi.orb_adjuster(max_keypoints=NK, max_iters=max(1, a.adjuster_iters))
 
     n_lc = min(64, F)   # loop-closure queries per step on every rank (config 4 style: local frames vs all keyframes)
     lc_q, lc_t = parallel.loop_closure_pairs(n_lc, F - 1, world, len(kf)) if dist_on else (None, None)
@@ -281,8 +286,12 @@ def main():
             st = pts_state[ctxs.index(ctx)]
             # Node::Node, ORB branch: AORB detection + removeDepthless + retainBest(600) + ORB descriptors, on the device -- on the
             # context's point stream, beside the line front end issued right after it (node.cpp:208-217: two threads)
-            ctx.orb_extract_device(dg.data_ptr(), dd.data_ptr(), F, st["kp"].data_ptr(), st["desc"].data_ptr(), st["nkp"].data_ptr(), NK,
-                                   fast_threshold=20, max_keypoints=NK)
+            if a.adjuster_iters > 0:     # every pass starts the sequence again: the adapter starts from its initial threshold
+                ctx.orb_extract_adjusted_device(dg.data_ptr(), dd.data_ptr(), F, st["kp"].data_ptr(), st["desc"].data_ptr(), st["nkp"].data_ptr(),
+                                                NK, orb_adj, reset_state=True, max_keypoints=NK, d_thresholds_ptr=st["thr"].data_ptr())
+            else:
+                ctx.orb_extract_device(dg.data_ptr(), dd.data_ptr(), F, st["kp"].data_ptr(), st["desc"].data_ptr(), st["nkp"].data_ptr(), NK,
+                                       fast_threshold=20, max_keypoints=NK)
             ctx.project_keypoints_device(dd.data_ptr(), F, st["kp"].data_ptr(), st["nkp"].data_ptr(), NK, K, st["pts"].data_ptr(),
                                          st["npts"].data_ptr(), st["kept"].data_ptr(), max_keypoints=NK)
         ctx.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), F, K, ids)
@@ -435,7 +444,10 @@ def main():
         Ts = [np.array(list(r.T), np.float64).reshape(4, 4) for r in res]
         est = ate.chain_odometry(Ts, valid)
         gt = np.linalg.inv(poses[0])[None] @ poses
-        point_stats = {"point_matches_per_pair": float(np.mean([r.n_point_matches for r in res])),
+        point_stats = {"detector": ("AORB behind VideoDynamicAdaptedFeatureDetector (adjuster_max_iterations %d): thresholds %d..%d, mean %.1f" % (
+                           a.adjuster_iters, int(pts_state[0]["thr"].min()), int(pts_state[0]["thr"].max()), float(pts_state[0]["thr"].float().mean())))
+                       if a.adjuster_iters > 0 else "AORB at the adjuster's start threshold 20 (adjuster_max_iterations 0, the default)",
+                       "point_matches_per_pair": float(np.mean([r.n_point_matches for r in res])),
                        "point_inliers_per_pair": float(np.mean([r.n_point_inliers for r in res])),
                        "line_inliers_per_pair": float(np.mean([r.n_inliers for r in res]))} if a.points else None
         sw = max(float(np.mean(sweep_ms)), 1e-6)          # (--detector edlines: there is no sweep; the roofline object is about LSD)
