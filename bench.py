@@ -529,6 +529,18 @@ def main():
             if cp:
                 out["quality"]["ate_rmse_m_vs_cpu_reference_port"] = ate.ate_rmse(est_g[:, :3, 3], est_c[:, :3, 3])
                 out["quality"]["pairs_with_identical_validity_vs_cpu"] = int(sum(bool(x) == b for x, (b, _) in zip(valid[:len(cp)], cp)))
+                # per pair (no chaining): the GPU pose against the CPU path's pose of the same pair -- north_star: 1e-4 rad / 1e-3 m
+                dr, dtr = [], []
+                for Tg, vg, (vc, Tc) in zip(Ts[:len(cp)], valid[:len(cp)], cp):
+                    if vg and vc:
+                        M = np.asarray(Tg, np.float64)[:3, :3].T @ np.asarray(Tc, np.float64)[:3, :3]
+                        sk = 0.5 * np.linalg.norm([M[2, 1] - M[1, 2], M[0, 2] - M[2, 0], M[1, 0] - M[0, 1]])
+                        dr.append(float(np.arctan2(sk, (np.trace(M) - 1) / 2)))
+                        dtr.append(float(np.linalg.norm(np.asarray(Tg, np.float64)[:3, 3] - np.asarray(Tc, np.float64)[:3, 3])))
+                if dr:
+                    out["quality"]["pair_pose_vs_cpu_reference_port"] = {"max_rot_rad": max(dr), "max_trans_m": max(dtr),
+                                                                        "median_rot_rad": float(np.median(dr)), "median_trans_m": float(np.median(dtr)),
+                                                                        "pairs": len(dr)}
     for c in ctxs:
         c.close()
     if dist_on:
