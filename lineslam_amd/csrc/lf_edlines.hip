@@ -688,6 +688,12 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
       nout++;
     }
   }
+  if (overflow) {
+    // an internal capacity was exceeded: the frame is reported as over capacity (nsegs > seg_cap: the getters return
+    // LF_ERR_CAPACITY), and the rows that were not written become zero-length segments -- the 3D stage treats all seg_cap
+    // rows of an over-capacity frame as present, and its length filter drops these instead of reading stale rows
+    for (int i = (nout < c.seg_cap ? nout : c.seg_cap); i < c.seg_cap; i++) { double *o = segs + 5 * (size_t)i; o[0] = o[1] = o[2] = o[3] = o[4] = 0.0; }
+  }
   b.nsegs[f] = overflow ? c.seg_cap + 1 : nout;
 }
 
