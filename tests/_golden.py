@@ -91,3 +91,25 @@ def mle_cases():
                      levmar_covB=z["levmar_covB" + s])
         out.append(d)
     return out
+
+
+def match_cases():
+    """tests/golden/match_fixtures.npz (make_match_golden.py, oracle/match_indep.py): list of dicts
+    (query, train: lf_line_record arrays with the members Node::lineMatching reads; adjacent; mq, mt, md expected)."""
+    z = _npz("match_fixtures.npz")
+    nf, npairs = (int(v) for v in z["count"])
+    frames = []
+    for k in range(nf):
+        n = len(z["f%d_p" % k])
+        r = np.zeros(n, REC_DTYPE)
+        for f in ("p", "q", "lineEq2d", "r", "des"):
+            r[f] = z["f%d_%s" % (k, f)]
+        r["lid"] = np.arange(n)
+        # 3D members are not read by the matcher; harmless finite values
+        r["A"] = [0, 0, 1]; r["B"] = [0.1, 0, 1]
+        frames.append(r)
+    out = []
+    for n in range(npairs):
+        a, b, adj = (int(v) for v in z["pair%02d" % n])
+        out.append(dict(query=frames[a], train=frames[b], adjacent=bool(adj), ids=(a, b), mq=z["mq%02d" % n], mt=z["mt%02d" % n], md=z["md%02d" % n]))
+    return out
