@@ -35,7 +35,7 @@ def test_independent_matrix_equals_the_oracles():
     assert np.array_equal(D == 100.0, Di == 100.0)          # the same pairs pass the three gates
     assert np.array_equal(np.isnan(D), np.isnan(Di))        # (NaN descriptors: the unguarded sqrt of computeMSLD)
     assert np.allclose(D, Di, rtol=1e-12, atol=0, equal_nan=True)
-    assert (D < 100).sum() > 1000
+    assert (D < 100).sum() > 500
 
 
 def test_fixture_generator_is_reproducible():
