@@ -36,6 +36,16 @@ typedef double lf_d2 __attribute__((ext_vector_type(2)));
 // small wave-level helpers (wave = 64 lanes on gfx950)
 // work counters of the sweeps (regions grown, window steps, rectangle evaluations, pixels): for tools/lsd_perf.py and
 // tools/lsd_mw_stats.py only -- build with LF_EXTRA_CFLAGS=-DLF_SWEEP_STATS=1; off, their scalar registers and adds are gone
+// out-of-line phases of the sweep (build options for the register-pressure experiments of DESIGN.md section 4)
+#ifndef LF_NI_IMPROVE
+#define LF_NI_IMPROVE
+#endif
+#ifndef LF_NI_R2R
+#define LF_NI_R2R
+#endif
+#ifndef LF_NI_GROW
+#define LF_NI_GROW
+#endif
 #ifndef LF_SWEEP_STATS
 #define LF_SWEEP_STATS 0
 #endif
@@ -366,7 +376,7 @@ __device__ __forceinline__ double d_angle_diff(double a, double b) {          //
 // the tolerance tau of refine() -- always takes the exact path (the wrap quirk of isaligned for angle
 // differences in (pi, 3pi/2] matters once prec > pi/2).
 template <class FV>
-__device__ int d_region_grow(const FV &f, int sx, int sy, double prec, double cos_prec, double *reg_angle_io,
+__device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec, double cos_prec, double *reg_angle_io,
                              u64 *n_steps) {
   uint32_t *ring = f.ring;
   const int N = f.N, M = f.M, lane = f.lane;
@@ -527,7 +537,7 @@ __device__ __noinline__ void d_rect_theta(double Ixx, double Iyy, double Ixy, do
   *theta_out = theta; *dx_out = dx; *dy_out = dy;
 }
 template <class FV>
-__device__ void d_region2rect(const FV &f, int n, double reg_angle, double prec, double p,
+__device__ LF_NI_R2R void d_region2rect(const FV &f, int n, double reg_angle, double prec, double p,
                               int plev, Rect *rec) {
   const int N = f.N, lane = f.lane;
   double x = 0.0, y = 0.0, sum = 0.0;
@@ -804,7 +814,7 @@ __device__ void d_rect_nfa_finer5(const FV &f, const Rect &r, double logNT, u64 
 
 // rect_improve (lsd.cpp:1662-1768)
 template <class FV>
-__device__ double d_rect_improve(const FV &f, Rect *rec, double logNT, double eps, u64 *n_nfa,
+__device__ LF_NI_IMPROVE double d_rect_improve(const FV &f, Rect *rec, double logNT, double eps, u64 *n_nfa,
                                  u64 *n_px) {
   Rect r;
   const double delta = 0.5, delta_2 = delta / 2.0;

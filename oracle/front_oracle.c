@@ -484,6 +484,67 @@ static double o_l2nrmxmy(double *e, const double *y, int n) {
   }
   return sum0 + sum1 + sum2 + sum3;
 }
+/* levmar's OWN LU, used when levmar-2.6 is built without LAPACK (Ax_eq_b_LU_noLapack, external/levmar-2.6/Axb_core.c:1123-1277):
+ * Crout's method with implicit row scaling (work[i] = 1 / largest |entry| of row i), pivot = LAST row of the maximal scaled
+ * |sum| (`>=`), a zero pivot replaced by LM_REAL_EPSILON (DBL_EPSILON, levmar.h), forward substitution skipping leading zeros
+ * of the right-hand side, back substitution with a division.  The reference DEFINES HAVE_LAPACK, so this is not what it runs;
+ * it is what lets the restatement of dlevmar_dif be held bit for bit against the reference's levmar compiled from nothing but
+ * its own files (oracle/_ref/liblevmar_nolapack_ref.so, tests/test_mle_golden_cpu.py).                                  */
+static int o_ax_eq_b_lu_nolapack(const double *A, const double *B, double *x, int m) {
+  double a[64], work[8], max, sum, tmp;
+  int idx[8], i, j, k, maxi = -1;
+  for (i = 0; i < m * m; i++) a[i] = A[i];
+  for (i = 0; i < m; i++) x[i] = B[i];
+  for (i = 0; i < m; ++i) {
+    max = 0.0;
+    for (j = 0; j < m; ++j)
+      if ((tmp = fabs(a[i * m + j])) > max) max = tmp;
+    if (max == 0.0) return 0;
+    work[i] = 1.0 / max;
+  }
+  for (j = 0; j < m; ++j) {
+    for (i = 0; i < j; ++i) {
+      sum = a[i * m + j];
+      for (k = 0; k < i; ++k) sum -= a[i * m + k] * a[k * m + j];
+      a[i * m + j] = sum;
+    }
+    max = 0.0;
+    for (i = j; i < m; ++i) {
+      sum = a[i * m + j];
+      for (k = 0; k < j; ++k) sum -= a[i * m + k] * a[k * m + j];
+      a[i * m + j] = sum;
+      if ((tmp = work[i] * fabs(sum)) >= max) { max = tmp; maxi = i; }
+    }
+    if (j != maxi) {
+      for (k = 0; k < m; ++k) { tmp = a[maxi * m + k]; a[maxi * m + k] = a[j * m + k]; a[j * m + k] = tmp; }
+      work[maxi] = work[j];
+    }
+    idx[j] = maxi;
+    if (a[j * m + j] == 0.0) a[j * m + j] = DBL_EPSILON;
+    if (j != m - 1) {
+      tmp = 1.0 / (a[j * m + j]);
+      for (i = j + 1; i < m; ++i) a[i * m + j] *= tmp;
+    }
+  }
+  for (i = k = 0; i < m; ++i) {
+    j = idx[i];
+    sum = x[j];
+    x[j] = x[i];
+    if (k != 0)
+      for (j = k - 1; j < i; ++j) sum -= a[i * m + j] * x[j];
+    else if (sum != 0.0)
+      k = i + 1;
+    x[i] = sum;
+  }
+  for (i = m - 1; i >= 0; --i) {
+    sum = x[i];
+    for (j = i + 1; j < m; ++j) sum -= a[i * m + j] * x[j];
+    x[i] = sum / a[i * m + i];
+  }
+  return 1;
+}
+static int o_lu_mode = 0;      /* 0: LAPACK order (what the reference's configuration runs); 1: levmar's in-tree LU */
+void oracle_set_lu_mode(int mode) { o_lu_mode = mode; }
 /* tests only: replace AX_EQ_B_LU by a caller-supplied solver (tests/test_oracle_front.py plugs in the LAPACK that the
  * compiled levmar was linked with, to separate "the restatement of dlevmar_dif" from "the rounding of one LAPACK build") */
 typedef int (*o_lu_fn)(const double *A, const double *B, double *x, int m);
@@ -545,7 +606,7 @@ int oracle_levmar_dif(o_lm_func func, double *p, int m, int n, int itmax, const 
       mu = tau * tmp;
     }
     for (i = 0; i < m; ++i) jacTjac[i * m + i] += mu;
-    issolved = (m <= 8) ? (o_lu_hook ? o_lu_hook(jacTjac, jacTe, Dp, m) : o_ax_eq_b_lu(jacTjac, jacTe, Dp, m)) : 0; ++nlss;   /* lm_core.c:706 */
+    issolved = (m <= 8) ? (o_lu_hook ? o_lu_hook(jacTjac, jacTe, Dp, m) : (o_lu_mode ? o_ax_eq_b_lu_nolapack(jacTjac, jacTe, Dp, m) : o_ax_eq_b_lu(jacTjac, jacTe, Dp, m))) : 0; ++nlss;   /* lm_core.c:706 */
     if (issolved) {
       for (i = 0, Dp_L2 = 0.0; i < m; ++i) { pDp[i] = p[i] + (tmp = Dp[i]); Dp_L2 += tmp * tmp; }
       if (Dp_L2 <= eps2_sq * p_L2) { stop = 2; break; }
@@ -583,7 +644,9 @@ int oracle_levmar_dif(o_lm_func func, double *p, int m, int n, int itmax, const 
   }
   if (k >= itmax) stop = 3;
   if (info) {
-    info[0] = init_p_eL2; info[1] = p_eL2; info[2] = jacTe_inf; info[3] = Dp_L2; info[4] = mu;
+    /* lm_core.c:815-831: the diagonal restored, info[4] = mu / max J^T J (i,i) */
+    for (i = 0, tmp = DBL_MIN; i < m; ++i) if (tmp < diag[i]) tmp = diag[i];
+    info[0] = init_p_eL2; info[1] = p_eL2; info[2] = jacTe_inf; info[3] = Dp_L2; info[4] = mu / tmp;
     info[5] = (double)k; info[6] = (double)stop; info[7] = (double)nfev; info[8] = (double)njap; info[9] = (double)nlss;
   }
   free(e);

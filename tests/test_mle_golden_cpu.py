@@ -129,3 +129,39 @@ def test_dlevmar_dif_restatement_is_bit_exact_given_the_same_lapack():
         assert np.abs(op - rp).max() < 2e-5, (k, np.abs(op - rp).max())
     assert same >= len(cases) // 2, same          # measured: 29 of 40
 
+
+
+def test_dlevmar_dif_restatement_is_bit_exact_against_levmar_built_from_its_own_files():
+    """The pin of a18 that needs no external library at all: oracle/_ref/liblevmar_nolapack_ref.so is the reference's levmar-2.6
+    compiled from where it lies in the configuration levmar documents for systems without LAPACK (oracle/levmar_nolapack.h: its
+    own LU, Axb_core.c:1123-1277).  With that LU restated as well (oracle_set_lu_mode(1)) the restatement of dlevmar_dif and the
+    compiled reference, driven with the same C cost function on the 40 MLE problems, return bit-identical parameters and
+    bit-identical info[0..9] (initial / final error, ||J^T e||, ||Dp||^2, mu / max diag, iterations, stop reason, function /
+    Jacobian evaluations, linear systems solved) -- 40 of 40.  The product differs from this pin in ONE routine, the linear solver,
+    which follows the LAPACK configuration the reference is built with (HAVE_LAPACK) and is unit-tested on its own."""
+    import pytest
+    path = os.path.join(O.ODIR, "_ref", "liblevmar_nolapack_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/liblevmar_nolapack_ref.so not built (needs /root/reference)")
+    ref = C.CDLL(path)
+    fn = C.cast(ref.dlevmar_dif, C.c_void_p)
+    lib = O.oracle_lib("lf")
+    P = capi.default_params(launch=True)
+    n_it = []
+    try:
+        lib.oracle_set_lu_mode(1)
+        for k, c in enumerate(G.mle_cases()):
+            p = np.ascontiguousarray(c["pts"], np.float64).reshape(-1, 3)
+            AB = np.ascontiguousarray(c["init"], np.float64)
+            op, oi, rp, ri = np.zeros(6), np.zeros(10), np.zeros(6), np.zeros(10)
+            nit = (C.c_int * 2)()
+            lib.oracle_mle_levmar_pair(C.c_void_p(p.ctypes.data), len(p), C.c_double(525.0), C.byref(P), C.c_void_p(AB.ctypes.data), fn,
+                                       C.c_void_p(op.ctypes.data), C.c_void_p(oi.ctypes.data), C.c_void_p(rp.ctypes.data),
+                                       C.c_void_p(ri.ctypes.data), nit)
+            assert nit[0] == nit[1], k
+            assert op.tobytes() == rp.tobytes(), k
+            assert oi.tobytes() == ri.tobytes(), (k, oi, ri)
+            n_it.append(nit[0])
+    finally:
+        lib.oracle_set_lu_mode(0)
+    assert len(n_it) == 40 and min(n_it) > 20 and max(n_it) == 100          # long, path-dependent runs: 47 .. 100 iterations
