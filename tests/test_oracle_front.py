@@ -69,6 +69,57 @@ def test_levmar_restatement_matches_reference_levmar():
     assert same_path >= 7, same_path
 
 
+def test_levmar_restatement_bit_exact_vs_levmar_built_without_lapack():
+    """dlevmar_dif for m = 6 and m = 7 (computeRelativeMotion_Ransac's quaternion + translation problem has seven parameters)
+    against the reference's levmar compiled from its own files in its no-LAPACK configuration (oracle/_ref/
+    liblevmar_nolapack_ref.so), its in-tree LU restated (oracle_set_lu_mode(1)): the SAME Python cost callback drives both;
+    parameters and info[0..9] bit-identical on every problem."""
+    path = os.path.join(O.ODIR, "_ref", "liblevmar_nolapack_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/liblevmar_nolapack_ref.so not built (needs /root/reference)")
+    ref = C.CDLL(path)
+    lib = O.oracle_lib("lf")
+    rng = np.random.default_rng(17)
+    ref.dlevmar_dif.restype = C.c_int
+    lib.oracle_levmar_dif.restype = C.c_int
+    try:
+        lib.oracle_set_lu_mode(1)
+        for trial in range(10):
+            if trial % 2 == 0:
+                cost, p0, n = _line_problem(rng)
+                m, itmax, opts = 6, 100, (C.c_double * 5)(1e-3, 1e-10, 1e-20, 1e-20, 1e-6)
+            else:                                   # seven parameters: unit quaternion (not normalised by the solver) + translation
+                n, m, itmax = 36, 7, 50
+                src = rng.normal(0, 1, (n // 3, 3))
+                qt = np.concatenate([[1, 0.05, -0.02, 0.03], [0.1, -0.05, 0.02]])
+
+                def rot(qv):
+                    w, x, y, z = qv / np.linalg.norm(qv)
+                    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+                dst = src @ rot(qt[:4]).T + qt[4:] + rng.normal(0, 0.01, src.shape)
+
+                def cost(p, hx, mm, nn, _, src=src, dst=dst):
+                    pv = np.array([p[i] for i in range(7)])
+                    r = (src @ rot(pv[:4]).T + pv[4:] - dst).ravel()
+                    for i in range(nn):
+                        hx[i] = r[i]
+                p0 = np.array([1.0, 0, 0, 0, 0, 0, 0])
+                opts = (C.c_double * 5)(1e-3, 1e-12, 1e-12, 1e-12, 1e-6)
+            cb = LMFUNC(cost)
+            pa, pb = p0.copy(), p0.copy()
+            ia, ib = (C.c_double * 10)(), (C.c_double * 10)()
+            x = np.zeros(n)
+            ra = ref.dlevmar_dif(cb, pa.ctypes.data_as(C.POINTER(C.c_double)), x.ctypes.data_as(C.POINTER(C.c_double)), m, n, itmax, opts, ia,
+                                 None, None, None)
+            rb = lib.oracle_levmar_dif(cb, pb.ctypes.data_as(C.POINTER(C.c_double)), m, n, itmax, opts, ib, None)
+            assert ra == rb and pa.tobytes() == pb.tobytes(), (trial, pa, pb)
+            assert bytes(ia) == bytes(ib), (trial, list(ia), list(ib))
+    finally:
+        lib.oracle_set_lu_mode(0)
+
+
 def test_jacobi_and_solve_vs_numpy():
     lib = O.oracle_lib("lf")
     rng = np.random.default_rng(0)
