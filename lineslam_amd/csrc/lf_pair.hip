@@ -258,10 +258,17 @@ void lf_pair_descdiff_launch(const PairConsts &c, const PairBuffers &b, int pair
 
 // ------------------------------------------------------------------------------ k_pose
 struct PoseShared {
-  int idx[LF_MAX_MATCHES];
-  unsigned char smp[LF_RANSAC_MAX_ITERS * 3];
+  int idx[LF_MAX_MATCHES];        // scratch inlier list of the re-scoring loop
   int set[LF_MAX_MATCHES];        // current inlier list (indices into the match list)
   ResShared rs;
+};
+// k_ransac -> k_pose: the winner of the hypothesis stage, five ints behind the pair's compact measurements
+#define R_WIN_OFF (LF_MAX_MATCHES * R_CM)
+static_assert(R_WIN_OFF + 4 <= LF_PAIR_WS_DOUBLES, "the winner record fits the pair's workspace");
+struct RansacShared {
+  int idx[LF_MAX_MATCHES];
+  unsigned char smp[LF_RANSAC_MAX_ITERS * 3];
+  int wcnt[16], wit[16];
 };
 
 // getTransformFromHybridMatchesG2O (transformation_estimation.cpp:218-461), line edges only; the
@@ -293,6 +300,9 @@ __device__ void r_refine(ResShared &S, const double *cm, const lf_params &P, con
     r_perturbed_poses(S, &S.X[cur]);
     __syncthreads();
     r_blocks(S, cm, set, n, &S.X[cur], S.L[cur], R, wgt, hd, hub, &mxl);
+#ifdef LF_POSE_PROFILE
+    if (blockIdx.x == 7 && threadIdx.x == 0) g_pprof[15]++;
+#endif
     PT(5);
     if (it == 0) {   // computeLambdaInit: tau * max |diagonal entry|
       double mx = r_block_max(S, mxl);           // (barrier inside: hb visible)
@@ -306,6 +316,9 @@ __device__ void r_refine(ResShared &S, const double *cm, const lf_params &P, con
       double dp[6], scale = 0;
       // the oracle stops eliminating at the first failing match; any failure rejects the step
       int ok2 = __syncthreads_or(r_eliminate(S, n, lambda, R)) ? 0 : 1;   // (barrier: S.sg visible)
+#ifdef LF_POSE_PROFILE
+      if (blockIdx.x == 7 && threadIdx.x == 0) g_pprof[14]++;
+#endif
       PT(7);
       if (ok2) {
         double A[36];
@@ -325,8 +338,8 @@ __device__ void r_refine(ResShared &S, const double *cm, const lf_params &P, con
         __syncthreads();                       // the trial landmarks are complete
         r_errchi(cm, set, n, &S.X[cur ^ 1], S.L[cur ^ 1], wgt, hd, hub, S.red[1]);
         __syncthreads();
-        scale = p_sum_published(S.red[0], n, scale);
-        tempChi = p_sum_published(S.red[1], n, 0.0);
+        tempChi = 0.0;
+        p_sum2_published(S.red[0], S.red[1], n, &scale, &tempChi);
       }
       PT(10);
       rho = (currentChi - tempChi);
@@ -390,10 +403,10 @@ __device__ int r_score(ResShared &S, const double *cm, int nLn, const float *tf,
 }
 
 // the three-line model of RANSAC iteration `it` (sample table in LDS) as the float matrix the reference scores with
-__device__ __forceinline__ int r_model(const PoseShared &S, const double *cm, int it, float *tf) {
+__device__ __forceinline__ int r_model(const int *smp3, const double *cm, float *tf) {
   double la[18], lb[18], R[9], t[3];
   for (int s = 0; s < 3; s++) {
-    const double *c = cm + (size_t)S.smp[3 * it + s] * R_CM;
+    const double *c = cm + (size_t)smp3[s] * R_CM;
     for (int cc = 0; cc < 3; cc++) { la[6 * s + cc] = c[cc]; la[6 * s + 3 + cc] = c[3 + cc]; lb[6 * s + cc] = c[24 + cc]; lb[6 * s + 3 + cc] = c[27 + cc]; }
   }
   if (!lf_rel_motion_lines(la, lb, 3, R, t)) return 0;
@@ -402,98 +415,149 @@ __device__ __forceinline__ int r_model(const PoseShared &S, const double *cm, in
   return 1;
 }
 
-#ifndef LF_POSE_PRIO
-#define LF_POSE_PRIO 2      // wave issue priority (s_setprio): latency-bound at one wavefront per SIMD
+// the gates of computeRelativeMotion_Ransac before the hypothesis loop (motion.cpp:621-633): shared by k_ransac and k_pose
+struct PoseGate { int nLn, n_all, min_inlier, lw, maxIter; bool go; long long id_t, id_q; };
+__device__ __forceinline__ PoseGate r_gate(const PairConsts &c, const PairBuffers &b, int pr, int fq, int ft) {
+  PoseGate g;
+  const lf_params &P = c.P;
+  g.nLn = b.nmatches[pr];
+  g.n_all = g.nLn;
+  if (g.nLn > c.match_cap) g.nLn = c.match_cap;
+  if (g.nLn > LF_MAX_MATCHES) g.nLn = LF_MAX_MATCHES;
+  g.id_t = (long long)b.frame_ids_t[ft]; g.id_q = (long long)b.frame_ids[fq];
+  g.min_inlier = P.min_feature_matches; g.lw = P.line_match_number_weight; g.maxIter = P.ransac_iters_line_motion;
+  if (g.maxIter > LF_RANSAC_MAX_ITERS) g.maxIter = LF_RANSAC_MAX_ITERS;
+  g.go = !(0 + g.nLn * g.lw < g.min_inlier);                                                          // motion.cpp:621-624
+  if (g.min_inlier > 0.7 * (0 + g.nLn * g.lw)) g.min_inlier = (int)(0.7 * (0 + g.nLn * g.lw));        // :626-628
+  { long long d = g.id_t - g.id_q; if (d < 0) d = -d; if (d > 50) g.min_inlier = P.min_matches_loopclose; }   // :631-633
+  if (g.nLn < 3) g.go = false;
+  return g;
+}
+
+// ------------------------------------------------------------------------------ k_ransac
+// The hypothesis stage of computeRelativeMotion_Ransac (motion.cpp:635-723) as its own launch: one workgroup per pair, one
+// three-line hypothesis per thread (500 by the launch file), each scored against every match.  It needs no LDS beyond the
+// sample table and ~1/4 of the registers of the refinement, so several of its wavefronts share a SIMD with each other and
+// with the front end's kernels, where inside k_pose (one wavefront per SIMD, the CU's whole register file) its dependent
+// fp64 chains ran alone.  It also lays down the pair's compact measurements; k_pose picks both up from the pair's workspace.
+#ifndef RS_N
+#define RS_N 256
 #endif
-__global__ void __launch_bounds__(RT_N) k_pose(PairConsts c, PairBuffers b) {
-  __builtin_amdgcn_s_setprio(LF_POSE_PRIO);
-  __shared__ PoseShared S;
+__global__ void __launch_bounds__(RS_N) k_ransac(PairConsts c, PairBuffers b) {
+  __shared__ RansacShared S;
   const int pr = blockIdx.x, tid = threadIdx.x, lane = p_lane();
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];
-  lf_pair_result *res = b.results + pr;
   const lf_line_record *train = b.recs_t + (size_t)ft * b.line_cap_t, *query = b.recs + (size_t)fq * c.line_cap;
   const int *mq = b.match_q + (size_t)pr * c.match_cap, *mt = b.match_t + (size_t)pr * c.match_cap;
   double *cm = b.ws + (size_t)pr * LF_PAIR_WS_DOUBLES;      // [nLn][R_CM]: the only workspace of the pair
+  int *win = (int *)(cm + R_WIN_OFF);
   const lf_params &P = c.P;
-  int nLn = b.nmatches[pr];
-  const int n_all = nLn;
-  if (nLn > c.match_cap) nLn = c.match_cap;
-  if (nLn > LF_MAX_MATCHES) nLn = LF_MAX_MATCHES;
-  const long long id_t = (long long)b.frame_ids_t[ft], id_q = (long long)b.frame_ids[fq];
+  const PoseGate g = r_gate(c, b, pr, fq, ft);
+  const int nLn = g.nLn, maxIter = g.maxIter;
+  const double thr = P.max_mah_dist_for_inliers;
+  if (!g.go) { if (tid == 0) { win[0] = -1; win[1] = 0; } return; }
+  // ---- the measurements of the matched lines, 48 contiguous doubles per match (read by every later phase)
+  for (int e = tid; e < nLn * 2; e += RS_N) {
+    const int k = e >> 1, h = e & 1;
+    const lf_line_record *r = h ? &train[mt[k]] : &query[mq[k]];
+    double *o = cm + (size_t)k * R_CM + 24 * h;
+    for (int j = 0; j < 3; j++) { o[j] = r->A[j]; o[3 + j] = r->B[j]; }
+    for (int j = 0; j < 9; j++) { o[6 + j] = r->DUa[j]; o[15 + j] = r->DUb[j]; }
+  }
+  // ---- sample sequence (serial; partial Fisher-Yates state carries over, :635-658)
+  for (int i = tid; i < nLn; i += RS_N) S.idx[i] = i;
+  __syncthreads();
+  if (tid == 0) {
+    const uint64_t stream = LF_STREAM_PAIR((uint64_t)g.id_q, (uint64_t)g.id_t);
+    uint64_t ctr = 0;
+    for (int it = 0; it < maxIter; it++) {
+      int bpos = 0, left = nLn;
+      for (int s = 0; s < 3; s++) {
+        int r = bpos + (int)(lf_rand31(P.rng_seed, stream, ctr++) % (uint32_t)left);
+        int t = S.idx[bpos]; S.idx[bpos] = S.idx[r]; S.idx[r] = t;
+        ++bpos; --left;
+      }
+      S.smp[3 * it] = (unsigned char)S.idx[0]; S.smp[3 * it + 1] = (unsigned char)S.idx[1]; S.smp[3 * it + 2] = (unsigned char)S.idx[2];
+    }
+  }
+  __threadfence_block();
+  __syncthreads();                              // (also: the workgroup's own cm writes are visible to it)
+  // ---- one hypothesis per thread
+  int my_cnt = -1, my_it = 1 << 30;
+  for (int it = tid; it < maxIter; it += RS_N) {
+    float tf[16];
+    const int s3[3] = {S.smp[3 * it], S.smp[3 * it + 1], S.smp[3 * it + 2]};
+    if (!r_model(s3, cm, tf)) continue;
+    int nc = 0;
+    for (int i = 0; i < nLn; ++i) {
+      double add;
+      const double *m = cm + (size_t)i * R_CM;
+      nc += lf_line_inlier(tf, m, m + 3, m + 24, m + 27, m + 30, m + 39, thr, &add);
+    }
+    if (nc > my_cnt) { my_cnt = nc; my_it = it; }   // strictly greater: earliest iteration wins inside a thread
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {   // arg-max: count desc, iteration asc -- wavefront, then the wavefronts
+    int oc = __shfl_xor(my_cnt, o, 64), oi = __shfl_xor(my_it, o, 64);
+    if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
+  }
+  if (lane == 0) { S.wcnt[tid >> 6] = my_cnt; S.wit[tid >> 6] = my_it; }
+  __syncthreads();
+  if (tid == 0) {
+    my_cnt = S.wcnt[0]; my_it = S.wit[0];
+    for (int w = 1; w < RS_N / 64; w++) {
+      int oc = S.wcnt[w], oi = S.wit[w];
+      if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
+    }
+    const int best = my_cnt > 0 ? my_it : -1;
+    win[0] = best; win[1] = my_cnt > 0 ? my_cnt : 0;
+    for (int s = 0; s < 3; s++) win[2 + s] = best >= 0 ? S.smp[3 * best + s] : 0;
+  }
+}
+
+#ifndef LF_POSE_PRIO
+#define LF_POSE_PRIO 2      // wave issue priority (s_setprio): latency-bound at one wavefront per SIMD
+#endif
+#ifdef LF_POSE_WAVES        // register budget for LF_POSE_WAVES wavefronts per SIMD; the LDS block becomes dynamic so that the
+#define LF_POSE_ATTR __attribute__((amdgpu_waves_per_eu(LF_POSE_WAVES, LF_POSE_WAVES)))   // compiler does not widen it back
+#else
+#define LF_POSE_ATTR
+#endif
+// The refinement stage (motion.cpp:725-839): the winner of k_ransac re-scored, getTransformFromHybridMatchesG2O on its inliers,
+// and the re-scoring loop -- resident, one workgroup per pair and per CU (lf_pose_res.h).
+__global__ void __launch_bounds__(RT_N) LF_POSE_ATTR k_pose(PairConsts c, PairBuffers b) {
+  __builtin_amdgcn_s_setprio(LF_POSE_PRIO);
+#ifdef LF_POSE_WAVES
+  extern __shared__ double s_pose_dyn[];
+  PoseShared &S = *reinterpret_cast<PoseShared *>(s_pose_dyn);
+#else
+  __shared__ PoseShared S;
+#endif
+  const int pr = blockIdx.x, tid = threadIdx.x;
+  const int fq = b.pair_q[pr], ft = b.pair_t[pr];
+  lf_pair_result *res = b.results + pr;
+  const double *cm = b.ws + (size_t)pr * LF_PAIR_WS_DOUBLES;      // [nLn][R_CM], laid down by k_ransac
+  const int *win = (const int *)(cm + R_WIN_OFF);
+  const lf_params &P = c.P;
+  const PoseGate g = r_gate(c, b, pr, fq, ft);
+  const int nLn = g.nLn, n_all = g.n_all, lw = g.lw, min_inlier = g.min_inlier;
+  const long long id_t = g.id_t, id_q = g.id_q;
   float tf_out[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) tf_out[i] = (i % 5 == 0) ? 1.0f : 0.0f;
   float rmse_out = 1e9f;
   int valid = 0, n_inl = 0, best_iter = -1, rounds = 0;
-  int min_inlier = P.min_feature_matches, lw = P.line_match_number_weight, maxIter = P.ransac_iters_line_motion;
-  if (maxIter > LF_RANSAC_MAX_ITERS) maxIter = LF_RANSAC_MAX_ITERS;
   const double thr = P.max_mah_dist_for_inliers;
 #ifdef LF_POSE_PROFILE
   if (blockIdx.x == 7 && tid == 0) g_pprev = __builtin_amdgcn_s_memtime();
 #endif
-  bool go = !(0 + nLn * lw < min_inlier);                                                   // motion.cpp:621-624
-  if (min_inlier > 0.7 * (0 + nLn * lw)) min_inlier = (int)(0.7 * (0 + nLn * lw));          // :626-628
-  { long long d = id_t - id_q; if (d < 0) d = -d; if (d > 50) min_inlier = P.min_matches_loopclose; }   // :631-633
-  if (nLn < 3) go = false;
-  if (go) {
-    // ---- the measurements of the matched lines, 48 contiguous doubles per match (read by every later phase)
-    for (int e = tid; e < nLn * 2; e += RT_N) {
-      const int k = e >> 1, h = e & 1;
-      const lf_line_record *r = h ? &train[mt[k]] : &query[mq[k]];
-      double *o = cm + (size_t)k * R_CM + 24 * h;
-      for (int j = 0; j < 3; j++) { o[j] = r->A[j]; o[3 + j] = r->B[j]; }
-      for (int j = 0; j < 9; j++) { o[6 + j] = r->DUa[j]; o[15 + j] = r->DUb[j]; }
-    }
-    // ---- sample sequence (serial; partial Fisher-Yates state carries over, :635-658)
-    for (int i = tid; i < nLn; i += RT_N) S.idx[i] = i;
-    __syncthreads();
-    if (tid == 0) {
-      const uint64_t stream = LF_STREAM_PAIR((uint64_t)id_q, (uint64_t)id_t);
-      uint64_t ctr = 0;
-      for (int it = 0; it < maxIter; it++) {
-        int bpos = 0, left = nLn;
-        for (int s = 0; s < 3; s++) {
-          int r = bpos + (int)(lf_rand31(P.rng_seed, stream, ctr++) % (uint32_t)left);
-          int t = S.idx[bpos]; S.idx[bpos] = S.idx[r]; S.idx[r] = t;
-          ++bpos; --left;
-        }
-        S.smp[3 * it] = (unsigned char)S.idx[0]; S.smp[3 * it + 1] = (unsigned char)S.idx[1]; S.smp[3 * it + 2] = (unsigned char)S.idx[2];
-      }
-    }
-    __threadfence_block();
-    __syncthreads();
-    // ---- one hypothesis per thread
-    int my_cnt = -1, my_it = 1 << 30;
-    for (int it = tid; it < maxIter; it += RT_N) {
-      float tf[16];
-      if (!r_model(S, cm, it, tf)) continue;
-      int nc = 0;
-      for (int i = 0; i < nLn; ++i) {
-        double add;
-        const double *m = cm + (size_t)i * R_CM;
-        nc += lf_line_inlier(tf, m, m + 3, m + 24, m + 27, m + 30, m + 39, thr, &add);
-      }
-      if (nc > my_cnt) { my_cnt = nc; my_it = it; }   // strictly greater: earliest iteration wins inside a thread
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {   // arg-max: count desc, iteration asc -- wavefront, then the wavefronts
-      int oc = __shfl_xor(my_cnt, o, 64), oi = __shfl_xor(my_it, o, 64);
-      if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
-    }
-    if (lane == 0) { S.rs.wcnt[tid >> 6] = my_cnt; S.rs.wit[tid >> 6] = my_it; }
-    __syncthreads();
-    my_cnt = S.rs.wcnt[0]; my_it = S.rs.wit[0];
-#pragma unroll
-    for (int w = 1; w < RW_N; w++) {
-      int oc = S.rs.wcnt[w], oi = S.rs.wit[w];
-      if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
-    }
-    __syncthreads();
-    int nbest = my_cnt > 0 ? my_cnt : 0;
-    best_iter = (my_cnt > 0) ? my_it : -1;
+  if (g.go) {
+    best_iter = win[0];
+    const int s3[3] = {win[2], win[3], win[4]};
+    const int nbest = win[1];
     if (0 + nbest >= 3) {                                                                    // :725-728
       float tf_best[16], sse_best = 0;
-      r_model(S, cm, best_iter, tf_best);      // recompute the winning model (uniform) and its inlier list / sse
+      r_model(s3, cm, tf_best);                // recompute the winning model (uniform) and its inlier list / sse
       double sse_unused;
       int nb = r_score(S.rs, cm, nLn, tf_best, thr, S.set, &sse_best, &sse_unused);
       float refined_tf[16];
@@ -529,8 +593,10 @@ __global__ void __launch_bounds__(RT_N) k_pose(PairConsts c, PairBuffers b) {
 #ifdef LF_POSE_PROFILE
   PT(13);
   if (blockIdx.x == 7 && tid == 0) {
+    printf("k_pose blocks (kticks): newer evals %.1f vn %.1f older evals %.1f vo hw hp %.1f bl, put %.1f sum+barriers %.1f\n", g_pprof[1] / 1e3, g_pprof[2] / 1e3, g_pprof[3] / 1e3, g_pprof[4] / 1e3, g_pprof[8] / 1e3, g_pprof[5] / 1e3);
+    printf("k_pose elim (kticks): gather %.1f solve6 %.1f W Vi, T %.1f ordered sum %.1f tail %.1f | %d linearisations, %d eliminations\n", g_pprof[1] / 1e3, g_pprof[2] / 1e3, g_pprof[3] / 1e3, g_pprof[4] / 1e3, g_pprof[7] / 1e3, (int)g_pprof[15], (int)g_pprof[14]);
     printf("k_pose prof (kticks) n=%d: pre-blocks %.1f blocks %.1f lambda %.1f elim %.1f solve %.1f backsub+chi %.1f accept %.1f | ransac %.1f rescoring/other %.1f\n", nLn,
-           g_pprof[0] / 1e3, g_pprof[5] / 1e3, g_pprof[6] / 1e3, g_pprof[7] / 1e3, g_pprof[9] / 1e3, g_pprof[10] / 1e3, g_pprof[11] / 1e3, g_pprof[12] / 1e3, g_pprof[13] / 1e3);
+           g_pprof[0] / 1e3, (g_pprof[5] + g_pprof[8]) / 1e3, g_pprof[6] / 1e3, (g_pprof[1] + g_pprof[2] + g_pprof[3] + g_pprof[4] + g_pprof[7]) / 1e3, g_pprof[9] / 1e3, g_pprof[10] / 1e3, g_pprof[11] / 1e3, g_pprof[12] / 1e3, g_pprof[13] / 1e3);
     for (int i = 0; i < 16; i++) g_pprof[i] = 0;
   }
 #endif
@@ -561,7 +627,14 @@ void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipS
   else if (solver == LF_SOLVER_RELMOTION) lf_pair_relmotion_launch(c, b, n_pairs, st);
   else {
 #ifndef LF_EXP_SKIP_POSE   // (throughput experiments only)
+    hipLaunchKernelGGL(k_ransac, dim3(n_pairs), dim3(RS_N), 0, st, c, b);
+#ifdef LF_POSE_WAVES
+    static bool attr_set = false;
+    if (!attr_set) { hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PoseShared)); attr_set = true; }
+    hipLaunchKernelGGL(k_pose, dim3(n_pairs), dim3(RT_N), sizeof(PoseShared), st, c, b);
+#else
     hipLaunchKernelGGL(k_pose, dim3(n_pairs), dim3(RT_N), 0, st, c, b);
+#endif
 #endif
   }
 }

@@ -22,6 +22,9 @@
 #define RP_ROWS (PG_N * RW_N)         // matches per pass of the workgroup
 #define RP_N ((LF_MAX_MATCHES + RP_ROWS - 1) / RP_ROWS)   // passes that cover LF_MAX_MATCHES
 #define R_ROW 42
+#ifndef RQ
+#define RQ 1                          // passes a lane runs TOGETHER in the elimination and the back-substitution: RQ independent
+#endif                                // 6x6 solves in one instruction stream hide each other's fp64 latency (one wavefront per SIMD)
 #define R_CM 48                       // compact measurement: nA nB nMa nMb oA oB oMa oMb
 static_assert(RP_N * RP_ROWS >= LF_MAX_MATCHES, "four passes cover the match list");
 
@@ -29,23 +32,31 @@ struct ResShared {
   double wb[LF_MAX_MATCHES * R_ROW];        // W (row-major 6x6, rows = pose) | bl of the current linearisation
   double L[2][LF_MAX_MATCHES * 6];          // landmarks: current set and the trial step's
   double red[2][LF_MAX_MATCHES + 8];        // per-match terms of the ordered sums (zero padded to a multiple of 8)
-  double tile[RP_ROWS * R_ROW];             // one row per match of the running pass
+  double tile[RQ * RP_ROWS * R_ROW];        // one row per match of the RQ passes running together
   double hb[42], sg[42];                    // Hpp | bp of the linearisation; S | g of the current damping
   double wred[RW_N];
   lf_se3 xp[12];
   lf_se3 X[2];                               // the older camera's pose: current and the trial step's
   int wcnt[RW_N], wit[RW_N];
 };
-struct ResRegs { double v[RP_N][6]; };   // row d of V of the lane's match, per pass (static indices only)
+#ifndef RP_VI
+#define RP_VI 5                       // passes whose Vi column stays in registers between r_eliminate and r_backsub (the rest solve again)
+#endif
+struct ResRegs {
+  double v[RP_N][6];                  // row d of V of the lane's match, per pass (static indices only)
+  double vi[RP_VI > 0 ? RP_VI : 1][6];   // column d of (V + lambda I)^-1 of the last elimination, per pass
+};
 // (the pass number is wave-uniform: a scalar branch to the copy from / to the pass's fixed registers; the empty asm keeps
 // the branches apart -- merged, they become one access with a selected address and the arrays fall back to memory)
-__device__ __forceinline__ void r_get6(const double (&arr)[RP_N][6], int p, double *out) {
-#define R_CASE(q) case q: _Pragma("unroll") for (int k = 0; k < 6; k++) out[k] = arr[q < RP_N ? q : 0][k]; asm volatile("; pass " #q); break;
+template <int NP>
+__device__ __forceinline__ void r_get6(const double (&arr)[NP][6], int p, double *out) {
+#define R_CASE(q) case q: _Pragma("unroll") for (int k = 0; k < 6; k++) out[k] = arr[q < NP ? q : 0][k]; asm volatile("; pass " #q); break;
   switch (p) { R_CASE(0) R_CASE(1) R_CASE(2) R_CASE(3) R_CASE(4) R_CASE(5) default: R_CASE(6) }
 #undef R_CASE
 }
-__device__ __forceinline__ void r_put6(double (&arr)[RP_N][6], int p, const double *in) {
-#define R_CASE(q) case q: _Pragma("unroll") for (int k = 0; k < 6; k++) arr[q < RP_N ? q : 0][k] = in[k]; asm volatile("; pass " #q); break;
+template <int NP>
+__device__ __forceinline__ void r_put6(double (&arr)[NP][6], int p, const double *in) {
+#define R_CASE(q) case q: _Pragma("unroll") for (int k = 0; k < 6; k++) arr[q < NP ? q : 0][k] = in[k]; asm volatile("; pass " #q); break;
   switch (p) { R_CASE(0) R_CASE(1) R_CASE(2) R_CASE(3) R_CASE(4) R_CASE(5) default: R_CASE(6) }
 #undef R_CASE
 }
@@ -59,6 +70,16 @@ __device__ __forceinline__ void r_meas(const double *cm, int k, lf_line_meas *m)
 // the evaluation loops of r_blocks: unrolled (the selects on the evaluation number fold away); measured faster than rolled
 // at one wavefront per SIMD -- the independent evaluations are the instruction-level parallelism that hides the fp64 latency
 #define R_EV_PRAGMA _Pragma("unroll")
+#if defined(LF_POSE_PROFILE) && LF_POSE_PROFILE == 2      // finer split of r_eliminate (slots 1..4) ...
+#define PTE(k) PT(k)
+#define PTB(k) do { } while (0)
+#elif defined(LF_POSE_PROFILE) && LF_POSE_PROFILE == 3    // ... or of r_blocks
+#define PTE(k) do { } while (0)
+#define PTB(k) PT(k)
+#else
+#define PTE(k) do { } while (0)
+#define PTB(k) do { } while (0)
+#endif
 struct ResTask { int i, d, g, row; bool act; };
 __device__ __forceinline__ ResTask r_task(int pass, int n) {
   ResTask t;
@@ -97,26 +118,94 @@ __device__ __forceinline__ double r_block_max(ResShared &S, double mx) {
   return mx;
 }
 
+// lf_solve6 (lf_linalg.h) on Q independent systems at once, one right-hand side each: the SAME operations on every entry, in
+// the same order, so each system's result has the bits lf_solve6 gives it; the Q instruction streams share basic blocks
+// (the only branch is the wave-uniform "some lane swaps rows"), which is what lets the scheduler interleave them.  A
+// singular system clears ok[q] and keeps computing (inf / nan, never used) instead of returning early.
+template <int Q>
+__device__ __forceinline__ void r_solve6q(double (&A)[Q][36], double (&B)[Q][6], int (&ok)[Q]) {
+  double rp[Q][6];
+#pragma unroll
+  for (int q = 0; q < Q; q++) ok[q] = 1;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    int piv[Q];
+    bool swaps = false;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      piv[q] = k;
+      double big = lf_fabs(A[q][7 * k]);
+#pragma unroll
+      for (int i = k + 1; i < 6; i++) {
+        const double v = lf_fabs(A[q][6 * i + k]);
+        if (v > big) { big = v; piv[q] = i; }
+      }
+      if (!(big > 0.0)) ok[q] = 0;
+      swaps = swaps || piv[q] != k;
+    }
+    if (LF_ANY(swaps)) {
+#pragma unroll
+      for (int q = 0; q < Q; q++)
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) {
+          const bool sw = i == piv[q];
+#pragma unroll
+          for (int j = k; j < 6; j++) { const double a = A[q][6 * k + j], b = A[q][6 * i + j]; A[q][6 * k + j] = sw ? b : a; A[q][6 * i + j] = sw ? a : b; }
+          { const double a = B[q][k], b = B[q][i]; B[q][k] = sw ? b : a; B[q][i] = sw ? a : b; }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; q++) rp[q][k] = 1.0 / A[q][7 * k];
+#pragma unroll
+    for (int q = 0; q < Q; q++)
+#pragma unroll
+      for (int i = k + 1; i < 6; i++) {
+        const double f = A[q][6 * i + k] * rp[q][k];
+        const bool nz = f != 0.0;
+#pragma unroll
+        for (int j = k + 1; j < 6; j++) { const double v = A[q][6 * i + j] - f * A[q][6 * k + j]; A[q][6 * i + j] = nz ? v : A[q][6 * i + j]; }
+        { const double v = B[q][i] - f * B[q][k]; B[q][i] = nz ? v : B[q][i]; }
+      }
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--)
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      double s = B[q][i];
+#pragma unroll
+      for (int k = i + 1; k < 6; k++) s -= A[q][6 * i + k] * B[q][k];
+      B[q][i] = s * rp[q][i];
+    }
+}
+
 // lf_match_chi2 of match i at (X, L = Lsrc + 6 i) into red[i]: two threads per match, one per edge (newer camera: the
 // landmark itself; older camera: X^-1 L), the two robustified terms added in the order of the sequential code.
 __device__ __forceinline__ void r_errchi(const double *cm, const int *set, int n, const lf_se3 *X, const double *Lsrc,
                                          double wgt, double hd, int hub, double *red) {
   const int tid = threadIdx.x, h = tid & 1;
-  for (int b0 = 0; b0 < n; b0 += RT_N / 2) {
-  const int i0 = b0 + (tid >> 1), i = i0 < n ? i0 : 0;
-  const double *c = cm + (size_t)set[i] * R_CM + 24 * h;
-  double PA[3], PB[3], e[6], cc = 0, r0, w;
-  if (h) { lf_se3_inv_apply(X, Lsrc + 6 * i, PA); lf_se3_inv_apply(X, Lsrc + 6 * i + 3, PB); }
-  else {
+  constexpr int RE_N = (LF_MAX_MATCHES + RT_N / 2 - 1) / (RT_N / 2);   // matches per thread pair: both evaluated in ONE instruction
+  double r0[RE_N];                                                      // stream (the second is a repeat of match 0 when n <= 128)
+  int i0[RE_N];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { PA[k] = Lsrc[6 * i + k]; PB[k] = Lsrc[6 * i + 3 + k]; }
+  for (int r = 0; r < RE_N; r++) {
+    i0[r] = r * (RT_N / 2) + (tid >> 1);
+    const int i = i0[r] < n ? i0[r] : 0;
+    const double *c = cm + (size_t)set[i] * R_CM + 24 * h;
+    double PA[3], PB[3], e[6], cc = 0, w;
+    if (h) { lf_se3_inv_apply(X, Lsrc + 6 * i, PA); lf_se3_inv_apply(X, Lsrc + 6 * i + 3, PB); }
+    else {
+#pragma unroll
+      for (int k = 0; k < 3; k++) { PA[k] = Lsrc[6 * i + k]; PB[k] = Lsrc[6 * i + 3 + k]; }
+    }
+    lf_line_edge_error(c + 6, c + 15, c, c + 3, PA, PB, e);
+#pragma unroll
+    for (int k = 0; k < 6; k++) cc += e[k] * (wgt * e[k]);
+    lf_huber(cc, hd, hub, &r0[r], &w);
   }
-  lf_line_edge_error(c + 6, c + 15, c, c + 3, PA, PB, e);
 #pragma unroll
-  for (int k = 0; k < 6; k++) cc += e[k] * (wgt * e[k]);
-  lf_huber(cc, hd, hub, &r0, &w);
-  const double other = __shfl_xor(r0, 1, 64);
-  if (h == 0 && i0 < n) red[i0] = r0 + other;
+  for (int r = 0; r < RE_N; r++) {
+    const double other = __shfl_xor(r0[r], 1, 64);
+    if (h == 0 && i0[r] < n) red[i0[r]] = r0[r] + other;
   }
 }
 
@@ -177,6 +266,7 @@ R_EV_PRAGMA
           else cn[k] = scalar * (ep[k] - e[k]);
         }
       }
+      PTB(1);
       for (int k = 0; k < 6; k++) cc += en[k] * (wgt * en[k]);
       lf_huber(cc, hd, hub, &r0, &wn);
       wn = wn * wgt;
@@ -187,6 +277,7 @@ R_EV_PRAGMA
       p_wave_order();
       for (int k = 0; k < 6; k++) { const double wen = wn * en[k]; sbl_n += cn[k] * wen; }
     }
+    PTB(2);
     // ---- edge to the older camera (pose X): X^-1 L against oA oB oMa oMb; differences along the landmark and the pose
     double eo[6], co[6], cp[6], wo, vo[6], hw[6], hp[6];
     {
@@ -204,6 +295,7 @@ R_EV_PRAGMA
           else cp[k] = scalar * (ep[k] - e[k]);
         }
       }
+      PTB(3);
       for (int k = 0; k < 6; k++) cc += eo[k] * (wgt * eo[k]);
       lf_huber(cc, hd, hub, &r0, &wo);
       wo = wo * wgt;
@@ -222,6 +314,7 @@ R_EV_PRAGMA
 #pragma unroll
     for (int j = 0; j < 6; j++) { double s = 0; for (int k = 0; k < 6; k++) s += cp[k] * (wo * row[6 * k + j]); hp[j] = s; }
     p_wave_order();
+    PTB(4);
     double sbl_o = 0, sbp = 0;
     for (int k = 0; k < 6; k++) { const double weo = wo * eo[k]; sbl_o += co[k] * weo; sbp += cp[k] * weo; }
     double *wbrow = S.wb + i * R_ROW;
@@ -239,6 +332,7 @@ R_EV_PRAGMA
       }
     }
     if (t.act) { wbrow[36 + d] = -(sbl_n + sbl_o); row[36 + d] = -sbp; }
+    PTB(8);
     __syncthreads();
     if (tid < 42) { const int left = n - pass * RP_ROWS; acc = r_stage_walk<false>(S.tile, tid, left < RP_ROWS ? left : RP_ROWS, acc); }
     __syncthreads();
@@ -256,51 +350,84 @@ __device__ int r_eliminate(ResShared &S, int n, double lambda, ResRegs &R) {
   int bad = 0;
   double acc = 0.0;
   if (tid < 42) { acc = S.hb[tid]; if (tid < 36 && tid % 7 == 0) acc = acc + lambda; }
-  for (int pass = 0; pass * RP_ROWS < n; pass++) {
-    const ResTask t = r_task(pass, n);
-    const int i = t.act ? t.i : 0, d = t.d;
-    double *row = S.tile + t.row * R_ROW;
-    const double *wbrow = S.wb + i * R_ROW;
-    double A[36], x[6], wvc[6], wv[6];
-    {
-      double Vr[6];
-      r_get6(R.v, pass, Vr);
-      if (t.act) {
+  for (int pass = 0; pass * RP_ROWS < n; pass += RQ) {
+    ResTask t[RQ];
+    double *row[RQ];
+    const double *wbrow[RQ];
 #pragma unroll
-        for (int j = 0; j < 6; j++) row[6 * d + j] = Vr[j];
+    for (int q = 0; q < RQ; q++) {
+      t[q] = r_task(pass + q, n);
+      row[q] = S.tile + (q * RP_ROWS + t[q].row) * R_ROW;
+      wbrow[q] = S.wb + (t[q].act ? t[q].i : 0) * R_ROW;
+    }
+    const int d = t[0].d;
+    double A[RQ][36], x[RQ][6], wvc[RQ][6], wv[RQ][6];
+    int ok[RQ];
+#pragma unroll
+    for (int q = 0; q < RQ; q++) {
+      double Vr[6];
+      r_get6(R.v, pass + q, Vr);
+      if (t[q].act) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) row[q][6 * d + j] = Vr[j];
+      }
+    }
+    p_wave_order();
+    double W[RQ][R_ROW];      // W | bl of the match, fetched with the V gather: the LDS latency of the products after the solve
+#pragma unroll                //   would otherwise be exposed read by read (one wavefront per SIMD: nothing else to issue)
+    for (int q = 0; q < RQ; q++) {
+#pragma unroll
+      for (int k = 0; k < 36; k++) A[q][k] = row[q][k];
+#pragma unroll
+      for (int k = 0; k < R_ROW; k++) W[q][k] = wbrow[q][k];
+    }
+    p_wave_order();
+#pragma unroll
+    for (int q = 0; q < RQ; q++)
+#pragma unroll
+      for (int k = 0; k < R_ROW; k++) asm volatile("" : "+v"(W[q][k]));   // (in registers from here on, not re-read later)
+    PTE(1);
+#pragma unroll
+    for (int q = 0; q < RQ; q++)
+#pragma unroll
+      for (int k = 0; k < 6; k++) { A[q][7 * k] += lambda; x[q][k] = (k == d) ? 1.0 : 0.0; }
+    r_solve6q<RQ>(A, x, ok);
+    PTE(2);
+#pragma unroll
+    for (int q = 0; q < RQ; q++) {
+      if (t[q].act && !ok[q]) bad = 1;
+      if (RP_VI > 0 && pass + q < RP_VI) r_put6(R.vi, pass + q, x[q]);
+#pragma unroll
+      for (int r = 0; r < 6; r++) { double s = 0; for (int k = 0; k < 6; k++) s += W[q][6 * r + k] * x[q][k]; wvc[q][r] = s; }
+      if (t[q].act) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) row[q][6 * k + d] = wvc[q][k];
       }
     }
     p_wave_order();
 #pragma unroll
-    for (int k = 0; k < 36; k++) A[k] = row[k];
+    for (int q = 0; q < RQ; q++)
+#pragma unroll
+      for (int k = 0; k < 6; k++) wv[q][k] = row[q][6 * d + k];
     p_wave_order();
 #pragma unroll
-    for (int k = 0; k < 6; k++) { A[7 * k] += lambda; x[k] = (k == d) ? 1.0 : 0.0; }
-    const int ok = lf_solve6(A, x, 1);
-    if (t.act && !ok) bad = 1;
+    for (int q = 0; q < RQ; q++) {
+      double u = 0, T[6];
 #pragma unroll
-    for (int r = 0; r < 6; r++) { double s = 0; for (int k = 0; k < 6; k++) s += wbrow[6 * r + k] * x[k]; wvc[r] = s; }
-    if (t.act) {
+      for (int k = 0; k < 6; k++) u += wv[q][k] * W[q][36 + k];
 #pragma unroll
-      for (int k = 0; k < 6; k++) row[6 * k + d] = wvc[k];
+      for (int j = 0; j < 6; j++) { double s2 = 0; for (int k = 0; k < 6; k++) s2 += wv[q][k] * W[q][6 * j + k]; T[j] = s2; }
+      if (t[q].act) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) row[q][6 * d + j] = T[j];
+        row[q][36 + d] = u;
+      }
     }
-    p_wave_order();
-#pragma unroll
-    for (int k = 0; k < 6; k++) wv[k] = row[6 * d + k];
-    p_wave_order();
-    double u = 0, T[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) u += wv[k] * wbrow[36 + k];
-#pragma unroll
-    for (int j = 0; j < 6; j++) { double s2 = 0; for (int k = 0; k < 6; k++) s2 += wv[k] * wbrow[6 * j + k]; T[j] = s2; }
-    if (t.act) {
-#pragma unroll
-      for (int j = 0; j < 6; j++) row[6 * d + j] = T[j];
-      row[36 + d] = u;
-    }
+    PTE(3);
     __syncthreads();
-    if (tid < 42) { const int left = n - pass * RP_ROWS; acc = r_stage_walk<true>(S.tile, tid, left < RP_ROWS ? left : RP_ROWS, acc); }
+    if (tid < 42) { const int left = n - pass * RP_ROWS; acc = r_stage_walk<true>(S.tile, tid, left < RQ * RP_ROWS ? left : RQ * RP_ROWS, acc); }
     __syncthreads();
+    PTE(4);
   }
   if (tid < 42) S.sg[tid] = acc;
   return bad;
@@ -310,46 +437,87 @@ __device__ int r_eliminate(ResShared &S, int n, double lambda, ResRegs &R) {
 // the six column holders through the tile row, and writes component a of the trial landmark.
 __device__ void r_backsub(ResShared &S, int n, const double *dp, double lambda, const double *Lc, double *Lt, ResRegs &R,
                           double *red) {
-  for (int pass = 0; pass * RP_ROWS < n; pass++) {
-    const ResTask t = r_task(pass, n);
-    const int i = t.act ? t.i : 0, a = t.d;
-    double *row = S.tile + t.row * R_ROW;
-    const double *wbrow = S.wb + i * R_ROW;
-    double tt = 0, rr[6], vi[6], dl = 0, s = 0;
+  for (int pass = 0; pass * RP_ROWS < n; pass += RQ) {
+    ResTask t[RQ];
+    double *row[RQ];
+    const double *wbrow[RQ];
+    int i[RQ];
 #pragma unroll
-    for (int k = 0; k < 6; k++) tt += wbrow[6 * k + a] * dp[k];
-    const double bla = wbrow[36 + a], ra = bla - tt;
+    for (int q = 0; q < RQ; q++) {
+      t[q] = r_task(pass + q, n);
+      i[q] = t[q].act ? t[q].i : 0;
+      row[q] = S.tile + (q * RP_ROWS + t[q].row) * R_ROW;
+      wbrow[q] = S.wb + i[q] * R_ROW;
+    }
+    const int a = t[0].d;
+    double rr[RQ][6], bla[RQ];
 #pragma unroll
-    for (int k = 0; k < 6; k++) rr[k] = r_sib(ra, t, k);
-    {   // column a of Vi again, by the arithmetic of r_eliminate (same bits): the registers keep V only
-      double A[36], xc[6], Vr[6];
-      r_get6(R.v, pass, Vr);
-      if (t.act) {
+    for (int q = 0; q < RQ; q++) {
+      double tt = 0;
 #pragma unroll
-        for (int j = 0; j < 6; j++) row[6 * a + j] = Vr[j];
+      for (int k = 0; k < 6; k++) tt += wbrow[q][6 * k + a] * dp[k];
+      bla[q] = wbrow[q][36 + a];
+      const double ra = bla[q] - tt;
+#pragma unroll
+      for (int k = 0; k < 6; k++) rr[q][k] = r_sib(ra, t[q], k);
+    }
+    if (RP_VI > 0 && pass + RQ <= RP_VI) {   // column a of Vi as r_eliminate left it (same lambda: the back-substitution follows it)
+#pragma unroll
+      for (int q = 0; q < RQ; q++) {
+        double xc[6];
+        r_get6(R.vi, pass + q, xc);
+        if (t[q].act) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) row[q][6 * k + a] = xc[k];
+        }
+      }
+    } else {   // beyond the kept passes: column a of Vi again, by the arithmetic of r_eliminate (same bits)
+      double A[RQ][36], xc[RQ][6];
+      int ok[RQ];
+#pragma unroll
+      for (int q = 0; q < RQ; q++) {
+        double Vr[6];
+        r_get6(R.v, pass + q, Vr);
+        if (t[q].act) {
+#pragma unroll
+          for (int j = 0; j < 6; j++) row[q][6 * a + j] = Vr[j];
+        }
       }
       p_wave_order();
 #pragma unroll
-      for (int k = 0; k < 36; k++) A[k] = row[k];
+      for (int q = 0; q < RQ; q++)
+#pragma unroll
+        for (int k = 0; k < 36; k++) A[q][k] = row[q][k];
       p_wave_order();
 #pragma unroll
-      for (int k = 0; k < 6; k++) { A[7 * k] += lambda; xc[k] = (k == a) ? 1.0 : 0.0; }
-      lf_solve6(A, xc, 1);
-      if (t.act) {
+      for (int q = 0; q < RQ; q++)
 #pragma unroll
-        for (int k = 0; k < 6; k++) row[6 * k + a] = xc[k];
-      }
+        for (int k = 0; k < 6; k++) { A[q][7 * k] += lambda; xc[q][k] = (k == a) ? 1.0 : 0.0; }
+      r_solve6q<RQ>(A, xc, ok);
+#pragma unroll
+      for (int q = 0; q < RQ; q++)
+        if (t[q].act) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) row[q][6 * k + a] = xc[q][k];
+        }
     }
     p_wave_order();
+    double vi[RQ][6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) vi[k] = row[6 * a + k];
+    for (int q = 0; q < RQ; q++)
+#pragma unroll
+      for (int k = 0; k < 6; k++) vi[q][k] = row[q][6 * a + k];
     p_wave_order();
 #pragma unroll
-    for (int k = 0; k < 6; k++) dl += vi[k] * rr[k];
-    const double La = Lc[6 * i + a] + dl, term = dl * (lambda * dl + bla);
-    if (t.act) Lt[6 * i + a] = La;
+    for (int q = 0; q < RQ; q++) {
+      double dl = 0, s = 0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) s += r_sib(term, t, k);
-    if (t.act && a == 0) red[i] = s;
+      for (int k = 0; k < 6; k++) dl += vi[q][k] * rr[q][k];
+      const double La = Lc[6 * i[q] + a] + dl, term = dl * (lambda * dl + bla[q]);
+      if (t[q].act) Lt[6 * i[q] + a] = La;
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += r_sib(term, t[q], k);
+      if (t[q].act && a == 0) red[i[q]] = s;
+    }
   }
 }

@@ -49,6 +49,26 @@ __device__ __forceinline__ double p_sum_published(const double *red, int n, doub
   }
   return s;
 }
+// two ordered sums at once (each in match order, as p_sum_published): the two chains of dependent additions share the issue
+// slots, and the next eight terms of both are on their way from LDS while the current eight are added -- at one wavefront per
+// SIMD a lone chain pays the LDS latency and the fp64 latency of every term (red[] is zero padded past n8: the read-ahead stays
+// inside the array)
+__device__ __forceinline__ void p_sum2_published(const double *ra, const double *rb, int n, double *sa_io, double *sb_io) {
+  const int n8 = (n + 7) & ~7;
+  double sa = *sa_io, sb = *sb_io, qa[8], qb[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { qa[k] = ra[k]; qb[k] = rb[k]; }
+  for (int l = 0; l < n8; l += 8) {
+    double na[8], nb[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { na[k] = ra[l + 8 + k]; nb[k] = rb[l + 8 + k]; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { sa += qa[k]; sb += qb[k]; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { qa[k] = na[k]; qb[k] = nb[k]; }
+  }
+  *sa_io = sa; *sb_io = sb;
+}
 // maximum over the workgroup (order does not matter for a maximum)
 __device__ __forceinline__ double p_block_max(LmShared &S, double mx) {
 #pragma unroll

@@ -1,0 +1,7 @@
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r03r
+for V in "$@"; do
+echo "== $V"
+LF_EXTRA_CFLAGS="$V" python -m lineslam_amd.build --force > gpurun_out/r03r/build.log 2>&1 || tail -5 gpurun_out/r03r/build.log
+timeout 900 python -m pytest tests/test_pair_gpu.py tests/test_pose_golden_gpu.py -x -q 2>&1 | tail -1
+timeout 600 python bench.py --no-cpu --steps 10 --warmup 3 --h2d-steps 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('pipelined %.0f frames/s %.2f ms'%(d['value'], d['ms_per_step']), 'serial match_pose %.2f'%d['serial']['stage_ms']['match_pose'])"
+done
