@@ -34,6 +34,8 @@ struct lf_ctx {
   LsdConsts lc;
   LsdBuffers lb;
   std::vector<void *> allocs;
+  struct Guard { void *p; size_t bytes; const char *what; };
+  std::vector<Guard> guards;       // LF_DEBUG_GUARD=1: tails to check at destruction
   FrontConsts fc;
   FrontBuffers fb;
   uint64_t *d_frame_ids = nullptr;
@@ -110,20 +112,37 @@ static int fail_hip(lf_ctx *c, hipError_t e, const char *what) {
     if (e_ != hipSuccess) return fail_hip(ctx, e_, #call);  \
   } while (0)
 
+// LF_DEBUG_GUARD=1 in the environment: every device allocation gets a 4 KB tail filled with 0xA5, checked when the context is
+// destroyed (a kernel that writes past the end of its buffer is named on stderr with the buffer's expression and size)
+#define LF_GUARD_BYTES 4096
+static bool guard_on() { static int g = -1; if (g < 0) { const char *e = getenv("LF_DEBUG_GUARD"); g = (e && e[0] == '1') ? 1 : 0; } return g == 1; }
 template <typename T>
-static int dev_alloc(lf_ctx *c, T **p, size_t count) {
+static int dev_alloc(lf_ctx *c, T **p, size_t count, const char *what) {
   void *q = nullptr;
-  hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
+  const size_t bytes = count * sizeof(T);
+  hipError_t e = hipMalloc(&q, bytes + 256 + (guard_on() ? LF_GUARD_BYTES : 0));
   if (e != hipSuccess) return fail_hip(c, e, "hipMalloc");
   c->allocs.push_back(q);
+  if (guard_on()) {
+    (void)hipMemset((char *)q + bytes, 0xA5, 256 + LF_GUARD_BYTES);
+    c->guards.push_back({q, bytes, what});
+  }
   *p = reinterpret_cast<T *>(q);
   return LF_OK;
 }
-#define ALLOC(ctx, ptr, count)                          \
-  do {                                                  \
-    int r_ = dev_alloc(ctx, &(ptr), (size_t)(count));   \
-    if (r_ != LF_OK) return r_;                         \
+#define ALLOC(ctx, ptr, count)                                 \
+  do {                                                         \
+    int r_ = dev_alloc(ctx, &(ptr), (size_t)(count), #ptr);    \
+    if (r_ != LF_OK) return r_;                                \
   } while (0)
+static void guard_check(lf_ctx *c) {
+  std::vector<unsigned char> h(256 + LF_GUARD_BYTES);
+  for (const auto &g : c->guards) {
+    if (hipMemcpy(h.data(), (const char *)g.p + g.bytes, h.size(), hipMemcpyDeviceToHost) != hipSuccess) continue;
+    for (size_t i = 0; i < h.size(); i++)
+      if (h[i] != 0xA5) { fprintf(stderr, "linefront guard: %s (%zu bytes) overwritten at +%zu past its end\n", g.what, g.bytes, i); break; }
+  }
+}
 
 static void pt_stream_join(lf_ctx *c);
 static void pt_stream_consumed(lf_ctx *c);
@@ -307,9 +326,10 @@ static int upload_lsd_tables(lf_ctx *c) {
     for (int y = 0; y < lc.M; y++) for (int i = 0; i < n; i++) { ky[(size_t)y * n + i] = (i == h); jy[(size_t)y * n + i] = y; }
   }
   const size_t NM = (size_t)lc.N * lc.M;
-  std::vector<double> lg(NM + 2);
+  // (k_nfa_table tabulates n < LF_NFA_TAB_N whatever the image size: the table of log-gammas covers that as well)
+  std::vector<double> lg(NM + 2 > (size_t)LF_NFA_TAB_N + 2 ? NM + 2 : (size_t)LF_NFA_TAB_N + 2);
   lg[0] = 0.0;
-  for (size_t i = 1; i < NM + 2; i++) lg[i] = host_log_gamma((double)i);
+  for (size_t i = 1; i < lg.size(); i++) lg[i] = host_log_gamma((double)i);
   HIPCHK(c, hipMemcpyAsync((void *)c->lb.kx, kx.data(), kx.size() * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync((void *)c->lb.ky, ky.data(), ky.size() * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync((void *)c->lb.jx, jx.data(), jx.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -331,7 +351,7 @@ static int alloc_lsd(lf_ctx *c) {
   double *kx, *ky, *lgam; int *jx, *jy; LsdConsts *dc;
   ALLOC(c, kx, (size_t)lc.N * lc.ntaps); ALLOC(c, ky, (size_t)lc.M * lc.ntaps);
   ALLOC(c, jx, (size_t)lc.N * lc.ntaps); ALLOC(c, jy, (size_t)lc.M * lc.ntaps);
-  ALLOC(c, lgam, NM + 2); ALLOC(c, dc, 1);
+  ALLOC(c, lgam, NM + 2 > (size_t)LF_NFA_TAB_N + 2 ? NM + 2 : (size_t)LF_NFA_TAB_N + 2); ALLOC(c, dc, 1);
   b.kx = kx; b.ky = ky; b.jx = jx; b.jy = jy; b.lgam = lgam; b.dconsts = dc;
   {
     const char *e = getenv("LF_NFA_TABLE");   // 0: evaluate nfa() every time (A/B parity test of the table)
@@ -476,6 +496,7 @@ void lf_ctx_destroy(lf_ctx *c) {
     (void)hipEventDestroy(c->ev_pts_in); (void)hipEventDestroy(c->ev_pts_done); (void)hipEventDestroy(c->ev_pts_free);
     (void)hipStreamDestroy(c->pstream);
   }
+  if (!c->guards.empty()) guard_check(c);
   for (void *p : c->allocs) (void)hipFree(p);
   for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->ev_stage_ids) (void)hipEventDestroy(c->ev_stage_ids);

@@ -9,7 +9,9 @@
 #define LF_ORB_LEVELS 8
 #define LF_ORB_EDGE 31
 #define LF_ORB_HALF 15
+#ifndef LF_ORB_CAND_CAP
 #define LF_ORB_CAND_CAP 16384     // non-maximum-suppressed FAST corners per frame (all levels) the selection stage can sort in LDS
+#endif
 #define LF_ORB_KP_MAX 1024        // max_keypoints of one call
 
 struct OrbConsts {

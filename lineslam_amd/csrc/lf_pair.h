@@ -13,7 +13,7 @@
 #define LF_RANSAC_MAX_ITERS 1024  // sample table capacity
 #define LF_MOTION_STRIDE 16
 #define LF_MAX_PT_MATCHES 512     // point matches per pair handled by the hybrid pose kernel (8 per lane)
-#define LF_PAIR_WS_DOUBLES (LF_MAX_MATCHES * (120 + 36 + 42 + 6 + 6 + 28))   // per-pair LM workspace
+#define LF_PAIR_WS_DOUBLES (LF_MAX_MATCHES * 48 + 8)   // per pair: the matches' compact measurements (48 doubles each) + the RANSAC winner
 
 struct PairConsts {
   lf_params P;

@@ -7,13 +7,17 @@
 //   point scoring         : errorFunction2 (src/misc.cpp:699-786)
 //   point edges           : EdgeSE3PointXYZ (src/line/edge_se3_ptxyz.cpp:84-90), information =
 //                           inverse compPt3dCov (transformation_estimation.cpp:267,283)
-// Same mapping as k_pose (lf_pose_wg.h): samples generated serially, one hypothesis per thread, arg-max by shuffles +
-// LDS; LM with six lanes per LINE landmark and one thread per POINT landmark (its 3x3 blocks are small); every sum
-// in the oracle's order (points first, then lines -- the order in which the reference adds vertices and edges).
+// Same mapping as k_pose: samples generated serially, one hypothesis per thread, arg-max by shuffles + LDS; LM with the
+// resident passes of lf_pose_res.h for the LINE landmarks (six lanes per match, state in LDS / registers) and one thread per
+// POINT landmark (its 3x3 blocks are small; they live in the pair's HBM workspace); every sum in the oracle's order (points
+// first, then lines -- the order in which the reference adds vertices and edges).  One workgroup per CU (160 KB of LDS).
 #include "lf_pair.h"
 #include "lf_pose.h"
 #include <float.h>
 #include "lf_pose_wg.h"
+#define R_RED_N (LM_RED_N + 8)               // the ordered sums cover the point landmarks, then the line landmarks
+#include "lf_pose_res.h"                      // the LINE landmarks of the refinement are resident, as in k_pose
+static_assert(RT_N == PT_N, "the resident line passes and the point loops share the workgroup");
 
 #define HP_SLOT (LF_MAX_PT_MATCHES / PT_N)   // point landmarks per thread
 
@@ -23,10 +27,10 @@ struct HShared {
   int pset[LF_MAX_PT_MATCHES], lset[LF_MAX_MATCHES];     // current inlier lists
   int pcur[LF_MAX_PT_MATCHES], lcur[LF_MAX_MATCHES];     // scratch lists of the re-scoring loop
   int scnt[HP_SLOT + 1][PW_N];                           // inlier counts per (slot, wavefront) of h_score
-  LmShared lm;
+  ResShared rs;                                          // line landmarks + the sums / pose state of the refinement (lf_pose_res.h)
 };
 struct HCtx {
-  PoseCtx lc;                          // line side: records, matches, line workspace (lf_pose_wg.h)
+  const double *cm;                    // the line matches' compact measurements [nLn][R_CM] (in the pair's workspace)
   const lf_line_record *train, *query;
   const float *tpts, *qpts;            // float4 per point
   const int *mq, *mt, *pq, *pt;        // line / point matches (indices into records / point arrays)
@@ -42,13 +46,8 @@ struct HCtx {
 #define WP_L (WP_TU + LF_MAX_PT_MATCHES * 42)           /* [512][3]  */
 #define WP_LN (WP_L + LF_MAX_PT_MATCHES * 3)            /* [512][3]  */
 #define WP_M (WP_LN + LF_MAX_PT_MATCHES * 3)            /* [512][24] mn3 mo3 In9 Io9 */
-#define WL_B (WP_M + LF_MAX_PT_MATCHES * 24)            /* line blocks    [256][120] */
-#define WL_VI (WL_B + LF_MAX_MATCHES * 120)
-#define WL_TU (WL_VI + LF_MAX_MATCHES * 36)
-#define WL_L (WL_TU + LF_MAX_MATCHES * 42)
-#define WL_LN (WL_L + LF_MAX_MATCHES * 6)
-#define WL_E (WL_LN + LF_MAX_MATCHES * 6)               /* [256][PE_STRIDE] error records of the line matches */
-#define W_TOTAL (WL_E + LF_MAX_MATCHES * PE_STRIDE)
+#define WL_B (WP_M + LF_MAX_PT_MATCHES * 24)            /* [256][R_CM] compact measurements of the line matches */
+#define W_TOTAL (WL_B + LF_MAX_MATCHES * R_CM)
 
 __device__ __forceinline__ void h_pmeas(const double *ws, int i, lf_point_meas *pmm) {
   const double *m = ws + WP_M + 24 * (size_t)i;
@@ -56,16 +55,23 @@ __device__ __forceinline__ void h_pmeas(const double *ws, int i, lf_point_meas *
 }
 
 // getTransformFromHybridMatchesG2O with point and line edges; sequential twin: oracle_refine_hybrid.
+// Point landmarks: one thread each, their small blocks in the pair's HBM workspace.  Line landmarks: the resident passes of
+// k_pose (r_blocks / r_eliminate / r_backsub / r_errchi, lf_pose_res.h: six lanes per match, W | bl and both landmark sets in
+// LDS, V and Vi rows in registers).  Every ordered sum runs over the points first, then the lines -- the order in which the
+// reference adds vertices and edges: the accumulator lanes of the line passes START from the points' partial sums.
 __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, const int *lset, int nl, float *tf, int iterations) {
-  LmShared &M = S.lm;
-  const PoseCtx &lc = pc.lc;
+  ResShared &M = S.rs;
+  const double *cm = pc.cm;
   const int tid = threadIdx.x, ntot = np + nl;
   const double wgt = pc.P.g2o_line_error_weight, hd = pc.P.g2o_BA_kernel_delta;
   const int hub = pc.P.g2o_BA_use_kernel;
   double *ws = pc.ws;
+  ResRegs R;
   lf_se3 X, Xn;
   double lambda = 0, ni = 2, currentChi = 0;
+  int cur = 0;                                 // M.L[cur], M.X[cur]: the lines' current state (the trial step takes the other set)
   lf_tf_to_older_pose(tf, &X);
+  if (tid == 0) M.X[0] = X;
   for (int h = 0; h < HP_SLOT; h++) {
     int i = tid + PT_N * h;
     if (i < np) {
@@ -78,12 +84,11 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
     }
   }
   if (tid < nl) {
-    const lf_line_record *q = &pc.query[pc.mq[lset[tid]]];
-    for (int k = 0; k < 3; k++) { lc.wsL[6 * tid + k] = q->A[k]; lc.wsL[6 * tid + 3 + k] = q->B[k]; }
+    const double *c = cm + (size_t)lset[tid] * R_CM;       // nA | nB: the landmark starts at the newer camera's measurement
+    for (int k = 0; k < 6; k++) M.L[0][6 * tid + k] = c[k];
   }
   if (tid < 8) { M.red[0][ntot + tid] = 0.0; M.red[1][ntot + tid] = 0.0; }   // zero padding of the ordered sums
   __syncthreads();
-  int slot = 0;                                // error record of the line matches at the current (X, L)
   if (ntot > 0 && iterations > 0) {
     for (int h = 0; h < HP_SLOT; h++) {
       int i = tid + PT_N * h;
@@ -93,7 +98,7 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
         M.red[0][i] = lf_ptmatch_chi2(&X, p, &pmm, hd, hub);
       }
     }
-    p_errchi(lc, lset, nl, X, lc.wsL, slot, wgt, hd, hub, M.red[0] + np);
+    r_errchi(cm, lset, nl, &M.X[0], M.L[0], wgt, hd, hub, M.red[0] + np);
     __syncthreads();
     currentChi = p_sum_published(M.red[0], ntot, 0.0);
   }
@@ -101,7 +106,8 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
     double rho = 0, tempChi;
     int qmax = 0;
     double mxl = 0;
-    p_perturbed_poses(M, X);
+    PT(0);
+    r_perturbed_poses(M, &M.X[cur]);
     __syncthreads();
     for (int h = 0; h < HP_SLOT; h++) {        // point landmarks: one thread each
       int i = tid + PT_N * h;
@@ -118,14 +124,14 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
         for (int k = 0; k < 6; k++) o[66 + k] = Bk.bp[k];
       }
     }
-    p_blocks(M, lc, lset, nl, X, slot, &mxl);  // line landmarks: six lanes each
-    __syncthreads();
-    if (tid < 42) {   // Hpp | bp: accumulator thread a walks the landmarks in order, points first, then lines
-      double acc = p_walk<false>(ws + WP_B + 30 + tid, 72, np, 0.0);
-      M.hb[tid] = p_walk<false>(lc.wsB + 78 + tid, 120, nl, acc);
-    }
+    __syncthreads();                           // the point blocks are in the workspace
+    PT(1);
+    // Hpp | bp: accumulator lane a walks the landmarks in order, points first; the line passes continue from there
+    const double acc0 = (tid < 42) ? p_walk<false>(ws + WP_B + 30 + tid, 72, np, 0.0) : 0.0;
+    r_blocks(M, cm, lset, nl, &M.X[cur], M.L[cur], R, wgt, hd, hub, &mxl, acc0);
+    PT(2);
     if (it == 0) {
-      double mx = p_block_max(M, mxl);
+      double mx = r_block_max(M, mxl);         // (barrier inside: hb visible)
 #pragma unroll
       for (int i = 0; i < 6; i++) if (lf_fabs(M.hb[7 * i]) > mx) mx = lf_fabs(M.hb[7 * i]);
       lambda = 1e-5 * mx;
@@ -149,15 +155,11 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
           for (int k = 0; k < 6; k++) ws[WP_TU + (size_t)i * 42 + 36 + k] = u[k];
         }
       }
-      bad |= p_eliminate(M, lc, nl, lambda);
-      int ok2 = __syncthreads_or(bad) ? 0 : 1;
-      if (tid < 42) {
-        double acc = M.hb[tid];
-        if (tid < 36 && tid % 7 == 0) acc = acc + lambda;
-        acc = p_walk<true>(ws + WP_TU + tid, 42, np, acc);
-        M.sg[tid] = p_walk<true>(lc.wsTU + tid, 42, nl, acc);
-      }
-      __syncthreads();
+      __syncthreads();                         // the points' T | u rows are in the workspace: subtracted first, then the lines'
+      PT(3);
+      bad |= r_eliminate(M, nl, lambda, R, ws + WP_TU, np);
+      int ok2 = __syncthreads_or(bad) ? 0 : 1; // (barrier: M.sg visible)
+      PT(4);
       if (ok2) {
         double A[36];
 #pragma unroll
@@ -166,9 +168,11 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
         for (int i = 0; i < 6; i++) dp[i] = M.sg[36 + i];
         ok2 = lf_solve6_u(A, dp, 1);   // the pose system is the same in every thread: scalar pivot branches
       }
+      PT(5);
       tempChi = DBL_MAX;
       if (ok2) {
         lf_se3_oplus(&X, dp, &Xn);
+        if (tid == 0) M.X[cur ^ 1] = Xn;
 #pragma unroll
         for (int i = 0; i < 6; i++) scale += dp[i] * (lambda * dp[i] + M.hb[36 + i]);
         for (int h = 0; h < HP_SLOT; h++) {
@@ -187,13 +191,15 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
             M.red[1][i] = lf_ptmatch_chi2(&Xn, pn, &pmm, hd, hub);
           }
         }
-        p_backsub(lc, nl, dp, lambda, M.red[0] + np);
-        __syncthreads();                       // the new line landmarks are in wsLn
-        p_errchi(lc, lset, nl, Xn, lc.wsLn, slot ^ 1, wgt, hd, hub, M.red[1] + np);
+        PT(6);
+        r_backsub(M, nl, dp, lambda, M.L[cur], M.L[cur ^ 1], R, M.red[0] + np);
+        __syncthreads();                       // the trial line landmarks and the trial pose are complete
+        r_errchi(cm, lset, nl, &M.X[cur ^ 1], M.L[cur ^ 1], wgt, hd, hub, M.red[1] + np);
         __syncthreads();
-        scale = p_sum_published(M.red[0], ntot, scale);
-        tempChi = p_sum_published(M.red[1], ntot, 0.0);
+        tempChi = 0.0;
+        p_sum2_published(M.red[0], M.red[1], ntot, &scale, &tempChi);
       }
+      PT(7);
       rho = (currentChi - tempChi);
       scale += 1e-3;
       rho /= scale;
@@ -205,9 +211,8 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
         ni = 2;
         currentChi = tempChi;
         X = Xn;
-        slot ^= 1;
+        cur ^= 1;
         for (int k = tid; k < 3 * np; k += PT_N) ws[WP_L + k] = ws[WP_LN + k];
-        for (int k = tid; k < 6 * nl; k += PT_N) lc.wsL[k] = lc.wsLn[k];
       } else {
         lambda *= ni;
         ni *= 2;
@@ -218,13 +223,14 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
     if (qmax == 10 || rho == 0) break;
   }
   lf_older_pose_to_tf(&X, tf);
+  __syncthreads();                             // (the next refinement overwrites M.X / M.L)
 }
 
 // inlier scan of ALL point and line matches with tf (motion.cpp:680-699 / 783-812): lists ascending, sums in list
 // order (points, then lines); a non-inlier contributes 0.0, which changes neither sum
 __device__ void h_score(HShared &S, const HCtx &pc, int nPt, int nLn, const float *tf, double thr, int *pset, int *npin, int *lset,
                         int *nlin, float *sse_f_out, double *sse_d_out) {
-  LmShared &M = S.lm;
+  ResShared &M = S.rs;
   const int tid = threadIdx.x, w = tid >> 6, lane = p_lane(), ntot = nPt + nLn;
   bool inp[HP_SLOT], inl = false;
   u64 mp[HP_SLOT], ml;
@@ -330,7 +336,7 @@ __device__ bool h_model(const HCtx &pc, const unsigned short *smp, int it, int n
   return true;
 }
 
-__global__ void __launch_bounds__(PT_N, 2) k_pose_hybrid(PairConsts c, PairBuffers b) {
+__global__ void __launch_bounds__(PT_N) k_pose_hybrid(PairConsts c, PairBuffers b) {
   __shared__ HShared S;
   const int pr = blockIdx.x, tid = threadIdx.x, lane = p_lane();
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];
@@ -348,9 +354,7 @@ __global__ void __launch_bounds__(PT_N, 2) k_pose_hybrid(PairConsts c, PairBuffe
   pc.P = c.P;
   pc.pm = c.pm;
   pc.focal = c.focal;
-  pc.lc.train = pc.train; pc.lc.query = pc.query; pc.lc.mq = pc.mq; pc.lc.mt = pc.mt; pc.lc.P = c.P;
-  pc.lc.wsB = pc.ws + WL_B; pc.lc.wsVi = pc.ws + WL_VI; pc.lc.wsTU = pc.ws + WL_TU;
-  pc.lc.wsL = pc.ws + WL_L; pc.lc.wsLn = pc.ws + WL_LN; pc.lc.wsE = pc.ws + WL_E;
+  pc.cm = pc.ws + WL_B;
   const lf_params &P = c.P;
   int nLn = b.nmatches[pr], nPt = b.npm[pr];
   const int n_all = nLn, np_all = nPt;
@@ -359,6 +363,17 @@ __global__ void __launch_bounds__(PT_N, 2) k_pose_hybrid(PairConsts c, PairBuffe
   if (nPt > LF_MAX_PT_MATCHES) nPt = LF_MAX_PT_MATCHES;
   if (nPt > c.pt_match_cap) nPt = c.pt_match_cap;
   const int nTot = nPt + nLn;
+  {   // the measurements of the matched lines, 48 contiguous doubles per match (read by every refinement pass)
+    double *cmw = pc.ws + WL_B;
+    for (int e = tid; e < nLn * 2; e += PT_N) {
+      const int k = e >> 1, h = e & 1;
+      const lf_line_record *r = h ? &pc.train[pc.mt[k]] : &pc.query[pc.mq[k]];
+      double *o = cmw + (size_t)k * R_CM + 24 * h;
+      for (int j = 0; j < 3; j++) { o[j] = r->A[j]; o[3 + j] = r->B[j]; }
+      for (int j = 0; j < 9; j++) { o[6 + j] = r->DUa[j]; o[15 + j] = r->DUb[j]; }
+    }
+    __syncthreads();
+  }
   const int ovf = ((n_all > c.match_cap || n_all > LF_MAX_MATCHES) ? LF_OVF_MATCHES : 0) | ((np_all > nPt) ? LF_OVF_PT_MATCHES : 0) |
                   ((b.nlines[fq] > c.line_cap || b.nlines_t[ft] > b.line_cap_t) ? LF_OVF_LINES : 0);
   if (c.mode == LF_MODE_REFINE) {
@@ -379,6 +394,9 @@ __global__ void __launch_bounds__(PT_N, 2) k_pose_hybrid(PairConsts c, PairBuffe
     }
     return;
   }
+#ifdef LF_POSE_PROFILE
+  if (blockIdx.x == 7 && tid == 0) g_pprev = __builtin_amdgcn_s_memtime();
+#endif
   const long long id_t = (long long)b.frame_ids_t[ft], id_q = (long long)b.frame_ids[fq];
   const uint64_t stream = LF_STREAM_PAIR((uint64_t)id_q, (uint64_t)id_t);
   float tf_out[16];
@@ -431,12 +449,12 @@ __global__ void __launch_bounds__(PT_N, 2) k_pose_hybrid(PairConsts c, PairBuffe
       int oc = __shfl_xor(my_cnt, o, 64), oi = __shfl_xor(my_it, o, 64);
       if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
     }
-    if (lane == 0) { S.lm.wcnt[tid >> 6] = my_cnt; S.lm.wit[tid >> 6] = my_it; }
+    if (lane == 0) { S.rs.wcnt[tid >> 6] = my_cnt; S.rs.wit[tid >> 6] = my_it; }
     __syncthreads();
-    my_cnt = S.lm.wcnt[0]; my_it = S.lm.wit[0];
+    my_cnt = S.rs.wcnt[0]; my_it = S.rs.wit[0];
 #pragma unroll
     for (int w = 1; w < PW_N; w++) {
-      int oc = S.lm.wcnt[w], oi = S.lm.wit[w];
+      int oc = S.rs.wcnt[w], oi = S.rs.wit[w];
       if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
     }
     __syncthreads();
@@ -478,6 +496,14 @@ __global__ void __launch_bounds__(PT_N, 2) k_pose_hybrid(PairConsts c, PairBuffe
       }
     }
   }
+#ifdef LF_POSE_PROFILE
+  PT(8);
+  if (blockIdx.x == 7 && tid == 0) {
+    printf("k_pose_hybrid prof (kticks) np=%d nl=%d: other %.1f | point blocks %.1f walk + line blocks %.1f point elim %.1f line elim %.1f solve %.1f point backsub %.1f line backsub, chi2, sums %.1f | ransac, scoring %.1f\n",
+           nPt, nLn, g_pprof[0] / 1e3, g_pprof[1] / 1e3, g_pprof[2] / 1e3, g_pprof[3] / 1e3, g_pprof[4] / 1e3, g_pprof[5] / 1e3, g_pprof[6] / 1e3, g_pprof[7] / 1e3, g_pprof[8] / 1e3);
+    for (int i = 0; i < 16; i++) g_pprof[i] = 0;
+  }
+#endif
   if (tid == 0) {
     for (int i = 0; i < 16; i++) res->T[i] = tf_out[i];
     res->rmse = rmse_out;

@@ -22,6 +22,9 @@
 #define RP_ROWS (PG_N * RW_N)         // matches per pass of the workgroup
 #define RP_N ((LF_MAX_MATCHES + RP_ROWS - 1) / RP_ROWS)   // passes that cover LF_MAX_MATCHES
 #define R_ROW 42
+#ifndef R_RED_N
+#define R_RED_N (LF_MAX_MATCHES + 8)      // k_pose_hybrid: point landmarks in front of the line landmarks (it defines its own)
+#endif
 #ifndef RQ
 #define RQ 1                          // passes a lane runs TOGETHER in the elimination and the back-substitution: RQ independent
 #endif                                // 6x6 solves in one instruction stream hide each other's fp64 latency (one wavefront per SIMD)
@@ -31,7 +34,7 @@ static_assert(RP_N * RP_ROWS >= LF_MAX_MATCHES, "four passes cover the match lis
 struct ResShared {
   double wb[LF_MAX_MATCHES * R_ROW];        // W (row-major 6x6, rows = pose) | bl of the current linearisation
   double L[2][LF_MAX_MATCHES * 6];          // landmarks: current set and the trial step's
-  double red[2][LF_MAX_MATCHES + 8];        // per-match terms of the ordered sums (zero padded to a multiple of 8)
+  double red[2][R_RED_N];                   // per-landmark terms of the ordered sums (zero padded to a multiple of 8)
   double tile[RQ * RP_ROWS * R_ROW];        // one row per match of the RQ passes running together
   double hb[42], sg[42];                    // Hpp | bp of the linearisation; S | g of the current damping
   double wred[RW_N];
@@ -182,6 +185,7 @@ __device__ __forceinline__ void r_solve6q(double (&A)[Q][36], double (&B)[Q][6],
 // landmark itself; older camera: X^-1 L), the two robustified terms added in the order of the sequential code.
 __device__ __forceinline__ void r_errchi(const double *cm, const int *set, int n, const lf_se3 *X, const double *Lsrc,
                                          double wgt, double hd, int hub, double *red) {
+  if (n <= 0) return;                        // (k_pose_hybrid with point landmarks only: set[] holds nothing)
   const int tid = threadIdx.x, h = tid & 1;
   constexpr int RE_N = (LF_MAX_MATCHES + RT_N / 2 - 1) / (RT_N / 2);   // matches per thread pair: both evaluated in ONE instruction
   double r0[RE_N];                                                      // stream (the second is a repeat of match 0 when n <= 128)
@@ -240,11 +244,12 @@ __device__ __forceinline__ void r_edge_eval(const double *ms, const lf_se3 *Xe, 
   }
   lf_line_edge_error(ms + 6, ms + 15, ms, ms + 3, PA, PB, e);
 }
+// acc_init: what accumulator lane tid < 42 starts from (k_pose_hybrid: the point landmarks' Hpp | bp, added up first).
 __device__ void r_blocks(ResShared &S, const double *cm, const int *set, int n, const lf_se3 *X, const double *Lc,
-                         ResRegs &R, double wgt, double hd, int hub, double *mxl_io) {
+                         ResRegs &R, double wgt, double hd, int hub, double *mxl_io, double acc_init = 0.0) {
   const double delta = 1e-9, scalar = 1.0 / (2 * 1e-9);
   const int tid = threadIdx.x;
-  double mxl = *mxl_io, acc = 0.0;
+  double mxl = *mxl_io, acc = acc_init;
   for (int pass = 0; pass * RP_ROWS < n; pass++) {
     const ResTask t = r_task(pass, n);
     const int i = t.act ? t.i : 0, d = t.d;
@@ -345,11 +350,16 @@ R_EV_PRAGMA
 // lane d solves (V + lambda I) x = e_d (column d of Vi, kept in registers for the back-substitution), publishes
 // column d of W Vi, then row d of T = W Vi W^T and entry d of u = W Vi bl go to the tile row and are subtracted in
 // match order from Hpp + lambda I | bp -> S.sg.  Returns 1 if a match of this lane is singular.
-__device__ int r_eliminate(ResShared &S, int n, double lambda, ResRegs &R) {
+// ptu / np: T | u rows (42 doubles each) of np landmarks that come BEFORE the matches in the sums (k_pose_hybrid: the points).
+__device__ int r_eliminate(ResShared &S, int n, double lambda, ResRegs &R, const double *ptu = nullptr, int np = 0) {
   const int tid = threadIdx.x;
   int bad = 0;
   double acc = 0.0;
-  if (tid < 42) { acc = S.hb[tid]; if (tid < 36 && tid % 7 == 0) acc = acc + lambda; }
+  if (tid < 42) {
+    acc = S.hb[tid];
+    if (tid < 36 && tid % 7 == 0) acc = acc + lambda;
+    if (np > 0) acc = p_walk<true>(ptu + tid, 42, np, acc);
+  }
   for (int pass = 0; pass * RP_ROWS < n; pass += RQ) {
     ResTask t[RQ];
     double *row[RQ];
