@@ -21,9 +21,12 @@ static_assert(RT_N == PT_N, "the resident line passes and the point loops share 
 
 #define HP_SLOT (LF_MAX_PT_MATCHES / PT_N)   // point landmarks per thread
 
-struct HShared {
+struct HRansacShared {                                    // k_ransac_hybrid
   int idx[LF_MAX_PT_MATCHES + LF_MAX_MATCHES];
   unsigned short smp[LF_RANSAC_MAX_ITERS * 3];
+  int wcnt[16], wit[16];
+};
+struct HShared {
   int pset[LF_MAX_PT_MATCHES], lset[LF_MAX_MATCHES];     // current inlier lists
   int pcur[LF_MAX_PT_MATCHES], lcur[LF_MAX_MATCHES];     // scratch lists of the re-scoring loop
   int scnt[HP_SLOT + 1][PW_N];                           // inlier counts per (slot, wavefront) of h_score
@@ -47,7 +50,8 @@ struct HCtx {
 #define WP_LN (WP_L + LF_MAX_PT_MATCHES * 3)            /* [512][3]  */
 #define WP_M (WP_LN + LF_MAX_PT_MATCHES * 3)            /* [512][24] mn3 mo3 In9 Io9 */
 #define WL_B (WP_M + LF_MAX_PT_MATCHES * 24)            /* [256][R_CM] compact measurements of the line matches */
-#define W_TOTAL (WL_B + LF_MAX_MATCHES * R_CM)
+#define W_WIN (WL_B + LF_MAX_MATCHES * R_CM)            /* five ints: the winner of k_ransac_hybrid (iteration, score, sample) */
+#define W_TOTAL (W_WIN + 4)
 
 __device__ __forceinline__ void h_pmeas(const double *ws, int i, lf_point_meas *pmm) {
   const double *m = ws + WP_M + 24 * (size_t)i;
@@ -287,10 +291,10 @@ __device__ void h_score(HShared &S, const HCtx &pc, int nPt, int nLn, const floa
 }
 
 // minimal-sample model of RANSAC iteration `it` (uniform or per lane); returns validity
-__device__ bool h_model(const HCtx &pc, const unsigned short *smp, int it, int nPt, uint64_t stream, float *tf) {
+__device__ bool h_model(const HCtx &pc, const int *smp3, int it, int nPt, uint64_t stream, float *tf) {
   int spq[3], spt[3], slq[3], slt[3], nsp = 0, nsl = 0;
   for (int s = 0; s < 3; s++) {
-    int k = smp[3 * it + s];
+    int k = smp3[s];
     if (k < nPt) { spq[nsp] = pc.pq[k]; spt[nsp] = pc.pt[k]; nsp++; }
     else { slq[nsl] = pc.mq[k - nPt]; slt[nsl] = pc.mt[k - nPt]; nsl++; }
   }
@@ -336,12 +340,12 @@ __device__ bool h_model(const HCtx &pc, const unsigned short *smp, int it, int n
   return true;
 }
 
-__global__ void __launch_bounds__(PT_N) k_pose_hybrid(PairConsts c, PairBuffers b) {
-  __shared__ HShared S;
-  const int pr = blockIdx.x, tid = threadIdx.x, lane = p_lane();
+// what both kernels of the pair derive from the launch arguments: the context of the pair and the gates of
+// getTransform_PtsLines_ransac before the hypothesis loop (motion.cpp:621-633)
+struct HGate { int nLn, nPt, n_all, np_all, nTot, ovf, min_inlier, lw, maxIter; bool go; long long id_t, id_q; };
+__device__ __forceinline__ HGate h_setup(const PairConsts &c, const PairBuffers &b, int pr, HCtx *pcp) {
+  HCtx &pc = *pcp;
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];
-  lf_pair_result *res = b.results + pr;
-  HCtx pc;
   pc.train = b.recs_t + (size_t)ft * b.line_cap_t;
   pc.query = b.recs + (size_t)fq * c.line_cap;
   pc.tpts = b.pts_t + (size_t)ft * b.pt_cap_t * 4;
@@ -355,14 +359,106 @@ __global__ void __launch_bounds__(PT_N) k_pose_hybrid(PairConsts c, PairBuffers 
   pc.pm = c.pm;
   pc.focal = c.focal;
   pc.cm = pc.ws + WL_B;
+  HGate g;
   const lf_params &P = c.P;
-  int nLn = b.nmatches[pr], nPt = b.npm[pr];
-  const int n_all = nLn, np_all = nPt;
-  if (nLn > c.match_cap) nLn = c.match_cap;
-  if (nLn > LF_MAX_MATCHES) nLn = LF_MAX_MATCHES;
-  if (nPt > LF_MAX_PT_MATCHES) nPt = LF_MAX_PT_MATCHES;
-  if (nPt > c.pt_match_cap) nPt = c.pt_match_cap;
-  const int nTot = nPt + nLn;
+  g.nLn = b.nmatches[pr]; g.nPt = b.npm[pr];
+  g.n_all = g.nLn; g.np_all = g.nPt;
+  if (g.nLn > c.match_cap) g.nLn = c.match_cap;
+  if (g.nLn > LF_MAX_MATCHES) g.nLn = LF_MAX_MATCHES;
+  if (g.nPt > LF_MAX_PT_MATCHES) g.nPt = LF_MAX_PT_MATCHES;
+  if (g.nPt > c.pt_match_cap) g.nPt = c.pt_match_cap;
+  g.nTot = g.nPt + g.nLn;
+  g.ovf = ((g.n_all > c.match_cap || g.n_all > LF_MAX_MATCHES) ? LF_OVF_MATCHES : 0) | ((g.np_all > g.nPt) ? LF_OVF_PT_MATCHES : 0) |
+          ((b.nlines[fq] > c.line_cap || b.nlines_t[ft] > b.line_cap_t) ? LF_OVF_LINES : 0);
+  g.id_t = (long long)b.frame_ids_t[ft]; g.id_q = (long long)b.frame_ids[fq];
+  g.min_inlier = P.min_feature_matches; g.lw = P.line_match_number_weight; g.maxIter = P.ransac_iters_line_motion;
+  if (g.maxIter > LF_RANSAC_MAX_ITERS) g.maxIter = LF_RANSAC_MAX_ITERS;
+  g.go = !(g.nPt + g.nLn * g.lw < g.min_inlier);                                                              // motion.cpp:621-624
+  if (g.min_inlier > 0.7 * (g.nPt + g.nLn * g.lw)) g.min_inlier = (int)(0.7 * (g.nPt + g.nLn * g.lw));        // :626-628
+  { long long d = g.id_t - g.id_q; if (d < 0) d = -d; if (d > 50) g.min_inlier = P.min_matches_loopclose; }   // :631-633
+  if (g.nTot < 3) g.go = false;
+  return g;
+}
+
+// ------------------------------------------------------------------------------ k_ransac_hybrid
+// The hypothesis stage (motion.cpp:635-723) as its own launch, as k_ransac is for k_pose: one hypothesis per thread scored
+// against every point and line match, at several wavefronts per SIMD instead of inside the one-workgroup-per-CU refinement
+// kernel.  Leaves the winner (iteration, score, its three samples) in the pair's workspace.
+#ifndef HR_N
+#define HR_N 256
+#endif
+__global__ void __launch_bounds__(HR_N) k_ransac_hybrid(PairConsts c, PairBuffers b) {
+  __shared__ HRansacShared S;
+  const int pr = blockIdx.x, tid = threadIdx.x, lane = p_lane();
+  HCtx pc;
+  const HGate g = h_setup(c, b, pr, &pc);
+  int *win = (int *)(pc.ws + W_WIN);
+  if (c.mode == LF_MODE_REFINE) return;
+  if (!g.go) { if (tid == 0) { win[0] = -1; win[1] = 0; } return; }
+  const int nPt = g.nPt, nLn = g.nLn, nTot = g.nTot, maxIter = g.maxIter, lw = g.lw;
+  const double thr = c.P.max_mah_dist_for_inliers;
+  const uint64_t stream = LF_STREAM_PAIR((uint64_t)g.id_q, (uint64_t)g.id_t);
+  for (int i = tid; i < nTot; i += HR_N) S.idx[i] = i;
+  __syncthreads();
+  if (tid == 0) {   // sample sequence, serial (partial Fisher-Yates state carries over, :635-658)
+    uint64_t ctr = 0;
+    for (int it = 0; it < maxIter; it++) {
+      int bpos = 0, left = nTot;
+      for (int s = 0; s < 3; s++) {
+        int r = bpos + (int)(lf_rand31(c.P.rng_seed, stream, ctr++) % (uint32_t)left);
+        int t = S.idx[bpos]; S.idx[bpos] = S.idx[r]; S.idx[r] = t;
+        ++bpos; --left;
+      }
+      S.smp[3 * it] = (unsigned short)S.idx[0]; S.smp[3 * it + 1] = (unsigned short)S.idx[1]; S.smp[3 * it + 2] = (unsigned short)S.idx[2];
+    }
+  }
+  __syncthreads();
+  int my_cnt = -1, my_it = 1 << 30;
+  for (int it = tid; it < maxIter; it += HR_N) {   // one hypothesis per thread
+    float tf[16];
+    const int s3[3] = {S.smp[3 * it], S.smp[3 * it + 1], S.smp[3 * it + 2]};
+    if (!h_model(pc, s3, it, nPt, stream, tf)) continue;
+    int ncp = 0, ncl = 0;
+    for (int i = 0; i < nPt; ++i) {
+      double m = lf_error_function2(pc.qpts + 4 * (size_t)pc.pq[i], pc.tpts + 4 * (size_t)pc.pt[i], tf, &pc.pm);
+      ncp += (m < thr * thr);
+    }
+    for (int i = 0; i < nLn; ++i) {
+      double add;
+      const lf_line_record *q = &pc.query[pc.mq[i]], *tr = &pc.train[pc.mt[i]];
+      ncl += lf_line_inlier(tf, q->A, q->B, tr->A, tr->B, tr->DUa, tr->DUb, thr, &add);
+    }
+    int score = ncp + lw * ncl;
+    if (score > my_cnt) { my_cnt = score; my_it = it; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {   // arg-max: score desc, iteration asc -- wavefront, then the wavefronts
+    int oc = __shfl_xor(my_cnt, o, 64), oi = __shfl_xor(my_it, o, 64);
+    if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
+  }
+  if (lane == 0) { S.wcnt[tid >> 6] = my_cnt; S.wit[tid >> 6] = my_it; }
+  __syncthreads();
+  if (tid == 0) {
+    my_cnt = S.wcnt[0]; my_it = S.wit[0];
+    for (int w = 1; w < HR_N / 64; w++) {
+      int oc = S.wcnt[w], oi = S.wit[w];
+      if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
+    }
+    const int best = my_cnt > 0 ? my_it : -1;
+    win[0] = best; win[1] = my_cnt;
+    for (int s = 0; s < 3; s++) win[2 + s] = best >= 0 ? (int)S.smp[3 * best + s] : 0;
+  }
+}
+
+__global__ void __launch_bounds__(PT_N) k_pose_hybrid(PairConsts c, PairBuffers b) {
+  __shared__ HShared S;
+  const int pr = blockIdx.x, tid = threadIdx.x;
+  lf_pair_result *res = b.results + pr;
+  HCtx pc;
+  const HGate g = h_setup(c, b, pr, &pc);
+  const lf_params &P = c.P;
+  const int nLn = g.nLn, nPt = g.nPt, n_all = g.n_all, np_all = g.np_all, ovf = g.ovf;
+  const int fq = b.pair_q[pr], ft = b.pair_t[pr];
   {   // the measurements of the matched lines, 48 contiguous doubles per match (read by every refinement pass)
     double *cmw = pc.ws + WL_B;
     for (int e = tid; e < nLn * 2; e += PT_N) {
@@ -374,8 +470,6 @@ __global__ void __launch_bounds__(PT_N) k_pose_hybrid(PairConsts c, PairBuffers 
     }
     __syncthreads();
   }
-  const int ovf = ((n_all > c.match_cap || n_all > LF_MAX_MATCHES) ? LF_OVF_MATCHES : 0) | ((np_all > nPt) ? LF_OVF_PT_MATCHES : 0) |
-                  ((b.nlines[fq] > c.line_cap || b.nlines_t[ft] > b.line_cap_t) ? LF_OVF_LINES : 0);
   if (c.mode == LF_MODE_REFINE) {
     // getTransformFromHybridMatchesG2O on its own (lf_refine_pair): every match given is an edge, the start value is
     // the transform the host stored in the result slot
@@ -397,72 +491,23 @@ __global__ void __launch_bounds__(PT_N) k_pose_hybrid(PairConsts c, PairBuffers 
 #ifdef LF_POSE_PROFILE
   if (blockIdx.x == 7 && tid == 0) g_pprev = __builtin_amdgcn_s_memtime();
 #endif
-  const long long id_t = (long long)b.frame_ids_t[ft], id_q = (long long)b.frame_ids[fq];
+  const long long id_t = g.id_t, id_q = g.id_q;
   const uint64_t stream = LF_STREAM_PAIR((uint64_t)id_q, (uint64_t)id_t);
   float tf_out[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) tf_out[i] = (i % 5 == 0) ? 1.0f : 0.0f;
   float rmse_out = 1e9f;
   int valid = 0, n_pinl = 0, n_linl = 0, best_iter = -1, rounds = 0;
-  int min_inlier = P.min_feature_matches, lw = P.line_match_number_weight, maxIter = P.ransac_iters_line_motion;
-  if (maxIter > LF_RANSAC_MAX_ITERS) maxIter = LF_RANSAC_MAX_ITERS;
+  const int min_inlier = g.min_inlier, lw = g.lw;
   const double thr = P.max_mah_dist_for_inliers;
-  bool go = !(nPt + nLn * lw < min_inlier);                                                  // motion.cpp:621-624
-  if (min_inlier > 0.7 * (nPt + nLn * lw)) min_inlier = (int)(0.7 * (nPt + nLn * lw));       // :626-628
-  { long long d = id_t - id_q; if (d < 0) d = -d; if (d > 50) min_inlier = P.min_matches_loopclose; }   // :631-633
-  if (nTot < 3) go = false;
-  if (go) {
-    for (int i = tid; i < nTot; i += PT_N) S.idx[i] = i;
-    __syncthreads();
-    if (tid == 0) {   // sample sequence, serial (partial Fisher-Yates state carries over, :635-658)
-      uint64_t ctr = 0;
-      for (int it = 0; it < maxIter; it++) {
-        int bpos = 0, left = nTot;
-        for (int s = 0; s < 3; s++) {
-          int r = bpos + (int)(lf_rand31(P.rng_seed, stream, ctr++) % (uint32_t)left);
-          int t = S.idx[bpos]; S.idx[bpos] = S.idx[r]; S.idx[r] = t;
-          ++bpos; --left;
-        }
-        S.smp[3 * it] = (unsigned short)S.idx[0]; S.smp[3 * it + 1] = (unsigned short)S.idx[1]; S.smp[3 * it + 2] = (unsigned short)S.idx[2];
-      }
-    }
-    __syncthreads();
-    int my_cnt = -1, my_it = 1 << 30;
-    for (int it = tid; it < maxIter; it += PT_N) {   // one hypothesis per thread
-      float tf[16];
-      if (!h_model(pc, S.smp, it, nPt, stream, tf)) continue;
-      int ncp = 0, ncl = 0;
-      for (int i = 0; i < nPt; ++i) {
-        double m = lf_error_function2(pc.qpts + 4 * (size_t)pc.pq[i], pc.tpts + 4 * (size_t)pc.pt[i], tf, &pc.pm);
-        ncp += (m < thr * thr);
-      }
-      for (int i = 0; i < nLn; ++i) {
-        double add;
-        const lf_line_record *q = &pc.query[pc.mq[i]], *tr = &pc.train[pc.mt[i]];
-        ncl += lf_line_inlier(tf, q->A, q->B, tr->A, tr->B, tr->DUa, tr->DUb, thr, &add);
-      }
-      int score = ncp + lw * ncl;
-      if (score > my_cnt) { my_cnt = score; my_it = it; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {   // arg-max: score desc, iteration asc -- wavefront, then the four wavefronts
-      int oc = __shfl_xor(my_cnt, o, 64), oi = __shfl_xor(my_it, o, 64);
-      if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
-    }
-    if (lane == 0) { S.rs.wcnt[tid >> 6] = my_cnt; S.rs.wit[tid >> 6] = my_it; }
-    __syncthreads();
-    my_cnt = S.rs.wcnt[0]; my_it = S.rs.wit[0];
-#pragma unroll
-    for (int w = 1; w < PW_N; w++) {
-      int oc = S.rs.wcnt[w], oi = S.rs.wit[w];
-      if (oc > my_cnt || (oc == my_cnt && oi < my_it)) { my_cnt = oc; my_it = oi; }
-    }
-    __syncthreads();
-    best_iter = (my_cnt > 0) ? my_it : -1;
+  if (g.go) {
+    const int *win = (const int *)(pc.ws + W_WIN);       // the winner of k_ransac_hybrid
+    best_iter = win[0];
+    const int s3[3] = {win[2], win[3], win[4]};
     if (best_iter >= 0) {
       float tf_best[16], sse_best = 0;
       double sse_unused;
-      h_model(pc, S.smp, best_iter, nPt, stream, tf_best);
+      h_model(pc, s3, best_iter, nPt, stream, tf_best);
       int nbp, nbl;
       h_score(S, pc, nPt, nLn, tf_best, thr, S.pset, &nbp, S.lset, &nbl, &sse_best, &sse_unused);
       if (nbp + nbl >= 3) {                                                                  // :725-728
@@ -525,5 +570,6 @@ __global__ void __launch_bounds__(PT_N) k_pose_hybrid(PairConsts c, PairBuffers 
 
 size_t lf_pair_hybrid_ws_doubles() { return (size_t)W_TOTAL; }
 void lf_pair_hybrid_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t st) {
+  if (c.mode != LF_MODE_REFINE) hipLaunchKernelGGL(k_ransac_hybrid, dim3(n_pairs), dim3(HR_N), 0, st, c, b);
   hipLaunchKernelGGL(k_pose_hybrid, dim3(n_pairs), dim3(PT_N), 0, st, c, b);
 }
