@@ -502,7 +502,13 @@ LF_API int lf_allgather_keyframes(lf_ctx *ctx, const int32_t *kf_slots, int n_kf
 /* MatchingResult Node::matchNodePair(const Node* older_node) (src/node.h:107) for two nodes whose
  * `lines` live in host memory: uploads both line maps into slots 0/1 of the context, runs
  * lineMatching + RANSAC + LM, returns the flat MatchingResult.  Matches / inliers of the pair are
- * then available as pair 0 (lf_pair_get_matches / lf_pair_get_inliers).  Needs max_batch >= 2. */
+ * then available as pair 0 (lf_pair_get_matches / lf_pair_get_inliers).  Needs max_batch >= 2.
+ * Every host-resident entry point (lf_match_node_pair*, lf_line_matching_node_pair, lf_solve_node_pair, lf_feature_match_node_pair,
+ * lf_mle_lines, lf_refine_pair) OVERWRITES frame slots 0 and 1 of the context: afterwards lf_frame_get_lines(0 / 1) returns the
+ * uploaded maps, while the segment / label getters of those slots still describe the last detect batch -- keep a context for
+ * node pairs apart from one whose batch results are still needed.
+ * The row stride of a gathered map (lf_allgather_keyframes) is line_cap + 1, its capacity line_cap: a key frame whose owner
+ * had more lines than that arrives cut, and every pair against it carries LF_OVF_LINES. */
 LF_API int lf_match_node_pair(lf_ctx *ctx, const lf_line_record *newer, int n_newer, uint64_t id_newer,
                               const lf_line_record *older, int n_older, uint64_t id_older,
                               lf_pair_result *out);

@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(RT_N) LF_POSE_ATTR k_pose(PairConsts c, PairBu
     float r2 = rmse_out * rmse_out;                                   // float arithmetic as node.cpp:1533-1534
     res->information_scale = valid ? (double)((float)(0 + n_inl * lw) / r2) : 0.0;
     res->overflow = ((n_all > c.match_cap || n_all > LF_MAX_MATCHES) ? LF_OVF_MATCHES : 0) |
-                    ((b.nlines[fq] > c.line_cap || b.nlines_t[ft] > b.line_cap_t) ? LF_OVF_LINES : 0);
+                    ((b.nlines[fq] > c.line_cap || b.nlines_t[ft] > (b.line_cap_t < c.line_cap ? b.line_cap_t : c.line_cap)) ? LF_OVF_LINES : 0);
     res->reserved_ = 0;
   }
 }

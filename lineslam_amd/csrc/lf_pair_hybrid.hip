@@ -369,7 +369,7 @@ __device__ __forceinline__ HGate h_setup(const PairConsts &c, const PairBuffers 
   if (g.nPt > c.pt_match_cap) g.nPt = c.pt_match_cap;
   g.nTot = g.nPt + g.nLn;
   g.ovf = ((g.n_all > c.match_cap || g.n_all > LF_MAX_MATCHES) ? LF_OVF_MATCHES : 0) | ((g.np_all > g.nPt) ? LF_OVF_PT_MATCHES : 0) |
-          ((b.nlines[fq] > c.line_cap || b.nlines_t[ft] > b.line_cap_t) ? LF_OVF_LINES : 0);
+          ((b.nlines[fq] > c.line_cap || b.nlines_t[ft] > (b.line_cap_t < c.line_cap ? b.line_cap_t : c.line_cap)) ? LF_OVF_LINES : 0);
   g.id_t = (long long)b.frame_ids_t[ft]; g.id_q = (long long)b.frame_ids[fq];
   g.min_inlier = P.min_feature_matches; g.lw = P.line_match_number_weight; g.maxIter = P.ransac_iters_line_motion;
   if (g.maxIter > LF_RANSAC_MAX_ITERS) g.maxIter = LF_RANSAC_MAX_ITERS;

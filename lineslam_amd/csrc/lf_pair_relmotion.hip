@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(64) k_relmotion(PairConsts c, PairBuffers b) {
     res->refine_rounds = rounds;
     res->information_scale = 0.0;
     res->overflow = ((n_all > c.match_cap || n_all > LF_MAX_MATCHES) ? LF_OVF_MATCHES : 0) |
-                    ((b.nlines[b.pair_q[blockIdx.x]] > c.line_cap || b.nlines_t[b.pair_t[blockIdx.x]] > b.line_cap_t) ? LF_OVF_LINES : 0);
+                    ((b.nlines[b.pair_q[blockIdx.x]] > c.line_cap || b.nlines_t[b.pair_t[blockIdx.x]] > (b.line_cap_t < c.line_cap ? b.line_cap_t : c.line_cap)) ? LF_OVF_LINES : 0);
     res->reserved_ = 0;
     double *o = b.motion_d + (size_t)pr * LF_MOTION_STRIDE;
     for (int i = 0; i < 9; i++) o[i] = Ro[i];

@@ -65,3 +65,27 @@ def test_one_query_vs_256_distinct_keyframes_with_pose(keyframes):
                 assert np.array_equal(np.array(list(r.T), np.float32).reshape(4, 4), tf), k
                 nvalid += 1
     assert nvalid > 0
+
+
+def test_gathered_keyframe_with_one_line_too_many_is_flagged(keyframes):
+    """The gathered map has a row stride of line_cap + 1 (header row + records); a key frame whose owner detected line_cap + 1
+    lines arrives cut to line_cap: the pair against it must say LF_OVF_LINES, not pass as complete (the overflow test used to
+    compare the count with the stride)."""
+    import torch
+    from lineslam_amd import capi
+    ctx, P, recs, ext = keyframes
+    L = ctx.line_cap
+    stride = L + 1
+    # two slots laid out as lf_allgather_keyframes leaves them: [header | L record rows]; the record pointer skips the header
+    blob = torch.zeros((2, stride, capi.REC_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+    n = recs[3].shape[0]
+    host = np.zeros((L, capi.REC_DTYPE.itemsize), np.uint8)
+    host[:n] = np.frombuffer(recs[3].tobytes(), np.uint8).reshape(n, -1)
+    for s in range(2):
+        blob[s, 1:] = torch.from_numpy(host).cuda()
+    nl = torch.tensor([n, L + 1], dtype=torch.int32, device="cuda")          # slot 1: its owner had L + 1 lines
+    ids = torch.tensor([2003, 2004], dtype=torch.int64, device="cuda")
+    q = np.array([NK, NK], np.int32)
+    ctx.match_external_device(q, np.array([0, 1], np.int32), blob.data_ptr() + capi.REC_DTYPE.itemsize, nl.data_ptr(), ids.data_ptr(), 2, stride)
+    assert ctx.pair_result(0, allow_overflow=True).overflow == 0
+    assert ctx.pair_result(1, allow_overflow=True).overflow & capi.LF_OVF_LINES
