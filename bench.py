@@ -166,11 +166,69 @@ def cpu_baseline(gray, depth, P, n_frames):
             "variants": variants}
 
 
+def launch_plan(gpus, env, device_count):
+    """What `--gpus N` means for THIS process (the driver's contract: N ranks, one per GPU, of ONE node):
+      ("run", world)      this process is one of N ranks (N == 1, or torch.distributed.run / torchrun set WORLD_SIZE == N)
+      ("spawn", argv)     --gpus N > 1 without a launcher: re-execute under torch.distributed.run with N ranks on 127.0.0.1
+    Anything inconsistent is an error (SystemExit): a launcher whose WORLD_SIZE differs from --gpus, or fewer visible devices
+    than ranks -- `--gpus 8` never silently measures one rank."""
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    ws = env.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (gpus, ws))
+        if device_count is not None and device_count < int(env.get("LOCAL_RANK", "0")) + 1:
+            raise SystemExit("bench.py: local rank %s has no device (%d visible)" % (env.get("LOCAL_RANK", "0"), device_count))
+        return ("run", gpus)
+    if gpus == 1:
+        return ("run", 1)
+    if device_count is not None and device_count < gpus:
+        raise SystemExit("bench.py: --gpus %d needs %d devices on this node, %d visible" % (gpus, gpus, device_count))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return ("spawn", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+                      "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
+
+def launch_probe(world):
+    """LF_BENCH_LAUNCH_PROBE=1 (tests/test_bench_launch_cpu.py): the ranks the launch logic started meet on a gloo group and
+    rank 0 prints how many there are -- no device, no library; checks the --gpus N plumbing where no GPU exists."""
+    import torch
+    import torch.distributed as dist
+    n = world
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        n = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps({"probe": True, "n_gpus": n}))
+
+
 def main():
     a = parse()
+    probe = os.environ.get("LF_BENCH_LAUNCH_PROBE") == "1"
+    ndev = None
+    if not probe:
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+        ndev = torch.cuda.device_count()
+    what, arg = launch_plan(a.gpus, os.environ, ndev)
+    if what == "spawn":
+        import subprocess
+        raise SystemExit(subprocess.run(arg).returncode)
+    if probe:
+        return launch_probe(arg)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus
     # LF_BENCH_FORCE_EXCHANGE=1: run the multi-rank code path (process group, keyframe all-gather, loop-closure
     # matching against the gathered map) even with one rank -- the only way to exercise it on a 1-GPU box
     dist_on = world > 1 or os.environ.get("LF_BENCH_FORCE_EXCHANGE") == "1"
@@ -547,6 +605,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        assert out["n_gpus"] == a.gpus, "the line must describe the job --gpus asked for"
         print(json.dumps(out))
 
 
