@@ -159,6 +159,17 @@ def cpu_baseline(gray, depth, P, n_frames):
     dt = time.perf_counter() - t0
     variants["frames_parallel"] = {"value": n / dt, "cores": cores, "sample": "%d frames, %d threads over frames, %.1f s wall" % (n, cores, dt)}
     cpu_baseline.pairs = [(bool(p[0]), np.asarray(p[1], np.float64)) for p in poses_cpu]   # (valid, T newer->older)
+
+    def pair_sets(k, rr, fl):
+        mq, mt, md, _ = O.match_oracle(rr[k], rr[k - 1], True, flavour=fl)
+        ok, T, _, inl, _ = O.pose_oracle(rr[k - 1], rr[k], mq, mt, k - 1, k, P, (k << 32) ^ (k - 1) ^ 0x2000000000000000, flavour=fl)
+        return bool(ok), np.asarray(T, np.float64), mq, mt, np.sort(inl)
+    # (untimed) the same pairs once more with their match lists and inlier sets, in both arithmetic flavours: `ref` = host libm
+    # (the CPU reference port), `lf` = the device-side functions of csrc/lf_math.h on the host (what the kernels equal bit for bit)
+    with ThreadPoolExecutor(cores) as ex:
+        cpu_baseline.sets_ref = list(ex.map(lambda k: pair_sets(k, recs, "ref"), range(1, n)))
+        recs_lf = list(ex.map(lambda k: front(k, "lf"), range(n)))
+        cpu_baseline.sets_lf = list(ex.map(lambda k: pair_sets(k, recs_lf, "lf"), range(1, n)))
     ref = variants["reference_shaped"] or variants["frames_parallel"]
     return {"value": ref["value"], "unit": "frames/s", "cores": ref["cores"], "kind": "port",
             "sample": ("reference-shaped threading: " if variants["reference_shaped"] else "") + ref["sample"] +
@@ -208,6 +219,43 @@ def launch_probe(world):
         dist.destroy_process_group()
     if int(os.environ.get("RANK", "0")) == 0:
         print(json.dumps({"probe": True, "n_gpus": n}))
+
+
+ROT_BUDGET_RAD, TRANS_BUDGET_M = 1e-4, 1e-3     # BASELINE.json north_star: SE(3) pose within 1e-4 rad / 1e-3 m
+
+
+def pose_agreement(A, B):
+    """Two runs of the same pairs, each a list of (valid, T[4,4], match query idx, match train idx, sorted inlier idx):
+    per-pair rotation angle of Ra^T Rb and |ta - tb| over the pairs valid on both sides, the number over the north-star
+    budget, and whether those (and how many pairs in all) have different match lists / inlier sets."""
+    dr, dtr, over, over_same_sets, same_m, same_i, same_v, bytes_eq = [], [], 0, 0, 0, 0, 0, 0
+    worst_same = [0.0, 0.0]
+    for (va, Ta, qa, ta, ia), (vb, Tb, qb, tb, ib) in zip(A, B):
+        sm = np.array_equal(qa, qb) and np.array_equal(ta, tb)
+        si = sm and np.array_equal(ia, ib)
+        same_m += sm; same_i += si; same_v += (va == vb)
+        bytes_eq += bool(va == vb and np.array_equal(np.asarray(Ta, np.float32), np.asarray(Tb, np.float32)))
+        if not (va and vb):
+            continue
+        Ta, Tb = np.asarray(Ta, np.float64), np.asarray(Tb, np.float64)
+        M = Ta[:3, :3].T @ Tb[:3, :3]
+        sk = 0.5 * np.linalg.norm([M[2, 1] - M[1, 2], M[0, 2] - M[2, 0], M[1, 0] - M[0, 1]])
+        r, t = float(np.arctan2(sk, (np.trace(M) - 1) / 2)), float(np.linalg.norm(Ta[:3, 3] - Tb[:3, 3]))
+        dr.append(r); dtr.append(t)
+        if si:
+            worst_same = [max(worst_same[0], r), max(worst_same[1], t)]
+        if r > ROT_BUDGET_RAD or t > TRANS_BUDGET_M:
+            over += 1
+            over_same_sets += si
+    if not dr:
+        return None
+    return {"pairs": len(A), "pairs_valid_on_both": len(dr), "pairs_with_identical_validity": int(same_v),
+            "pairs_with_identical_match_list": int(same_m), "pairs_with_identical_match_list_and_inlier_set": int(same_i),
+            "pairs_with_identical_float_transform": int(bytes_eq),
+            "pairs_over_budget": int(over), "pairs_over_budget_with_identical_sets": int(over_same_sets),
+            "budget": {"rot_rad": ROT_BUDGET_RAD, "trans_m": TRANS_BUDGET_M},
+            "max_rot_rad": max(dr), "max_trans_m": max(dtr), "median_rot_rad": float(np.median(dr)), "median_trans_m": float(np.median(dtr)),
+            "max_rot_rad_identical_sets": worst_same[0], "max_trans_m_identical_sets": worst_same[1]}
 
 
 def main():
@@ -497,6 +545,14 @@ def main():
         # pair slots hold the loop-closure results of the last step: run the odometry pairs once more (untimed).
         if dist_on and not a.points and not strong:
             ctx.match_pairs_device(pq, pt)
+        if h2d is not None:
+            # the h2d leg ran last on this context, from 16-bit depth through the loader's float multiply (k_ingest_tum): those
+            # depth maps differ from the resident float32 ones in the last bit here and there, i.e. its results belong to OTHER
+            # inputs than the CPU leg's.  (Rounds 1-3 read them: the "7.6e-4 rad" of BENCH_r03 was this, not arithmetic.)
+            # One more untimed pass over the resident inputs -- the timed workload -- before anything is read back.
+            with torch.cuda.stream(streams[0]):
+                step_on(ctx)
+            torch.cuda.synchronize()
         res = res_strong if strong else [ctx.pair_result(i, allow_overflow=True) for i in range(F - 1)]
         valid = np.array([r.valid for r in res], bool)
         Ts = [np.array(list(r.T), np.float64).reshape(4, 4) for r in res]
@@ -587,18 +643,15 @@ def main():
             if cp:
                 out["quality"]["ate_rmse_m_vs_cpu_reference_port"] = ate.ate_rmse(est_g[:, :3, 3], est_c[:, :3, 3])
                 out["quality"]["pairs_with_identical_validity_vs_cpu"] = int(sum(bool(x) == b for x, (b, _) in zip(valid[:len(cp)], cp)))
-                # per pair (no chaining): the GPU pose against the CPU path's pose of the same pair -- north_star: 1e-4 rad / 1e-3 m
-                dr, dtr = [], []
-                for Tg, vg, (vc, Tc) in zip(Ts[:len(cp)], valid[:len(cp)], cp):
-                    if vg and vc:
-                        M = np.asarray(Tg, np.float64)[:3, :3].T @ np.asarray(Tc, np.float64)[:3, :3]
-                        sk = 0.5 * np.linalg.norm([M[2, 1] - M[1, 2], M[0, 2] - M[2, 0], M[1, 0] - M[0, 1]])
-                        dr.append(float(np.arctan2(sk, (np.trace(M) - 1) / 2)))
-                        dtr.append(float(np.linalg.norm(np.asarray(Tg, np.float64)[:3, 3] - np.asarray(Tc, np.float64)[:3, 3])))
-                if dr:
-                    out["quality"]["pair_pose_vs_cpu_reference_port"] = {"max_rot_rad": max(dr), "max_trans_m": max(dtr),
-                                                                        "median_rot_rad": float(np.median(dr)), "median_trans_m": float(np.median(dtr)),
-                                                                        "pairs": len(dr)}
+                # per pair (no chaining): the GPU pose against the CPU path's pose of the same pair -- north_star: 1e-4 rad / 1e-3 m,
+                # with the match-list / inlier-set breakdown (the gate holds "on identical match sets")
+                gpu_sets = [(bool(res[i].valid), Ts[i]) + tuple(ctx.pair_matches(i, allow_overflow=True)[:2]) +
+                            (np.sort(ctx.pair_inliers(i, allow_overflow=True)),) for i in range(len(cp))]
+                out["quality"]["pair_pose_vs_cpu_reference_port"] = pose_agreement(gpu_sets, cpu_baseline.sets_ref)
+                # the same comparison on the CPU alone: device arithmetic (lf_math.h, == the kernels bit for bit) vs host libm -- what
+                # of the difference is libm, and whether the GPU adds anything to it
+                out["quality"]["cpu_lf_flavour_vs_cpu_reference_port"] = pose_agreement(cpu_baseline.sets_lf, cpu_baseline.sets_ref)
+                out["quality"]["pair_pose_vs_cpu_lf_flavour"] = pose_agreement(gpu_sets, cpu_baseline.sets_lf)
     for c in ctxs:
         c.close()
     if dist_on:

@@ -135,13 +135,14 @@ static int dev_alloc(lf_ctx *c, T **p, size_t count, const char *what) {
     int r_ = dev_alloc(ctx, &(ptr), (size_t)(count), #ptr);    \
     if (r_ != LF_OK) return r_;                                \
   } while (0)
-static void guard_check(lf_ctx *c) {
+static void guard_check_one(const lf_ctx::Guard &g) {
   std::vector<unsigned char> h(256 + LF_GUARD_BYTES);
-  for (const auto &g : c->guards) {
-    if (hipMemcpy(h.data(), (const char *)g.p + g.bytes, h.size(), hipMemcpyDeviceToHost) != hipSuccess) continue;
-    for (size_t i = 0; i < h.size(); i++)
-      if (h[i] != 0xA5) { fprintf(stderr, "linefront guard: %s (%zu bytes) overwritten at +%zu past its end\n", g.what, g.bytes, i); break; }
-  }
+  if (hipMemcpy(h.data(), (const char *)g.p + g.bytes, h.size(), hipMemcpyDeviceToHost) != hipSuccess) return;
+  for (size_t i = 0; i < h.size(); i++)
+    if (h[i] != 0xA5) { fprintf(stderr, "linefront guard: %s (%zu bytes) overwritten at +%zu past its end\n", g.what, g.bytes, i); break; }
+}
+static void guard_check(lf_ctx *c) {
+  for (const auto &g : c->guards) guard_check_one(g);
 }
 
 static void pt_stream_join(lf_ctx *c);
@@ -887,9 +888,11 @@ int lf_match_pairs_hybrid_device_pm(lf_ctx *c, const int32_t *query_frames, cons
 // lf_ctx_point_join.  The next point-side call waits for the consumers of the previous one.
 static hipStream_t pt_stream_begin(lf_ctx *c) {
   if (!c->pts_async) return c->stream;
+  // EVERY point-side call starts after everything enqueued on the context's stream before it (the header's contract): a
+  // second call before the join may read what was put on c->stream since the first one (an upload, another entry point)
+  (void)hipEventRecord(c->ev_pts_in, c->stream);
+  (void)hipStreamWaitEvent(c->pstream, c->ev_pts_in, 0);
   if (!c->pts_pending) {
-    (void)hipEventRecord(c->ev_pts_in, c->stream);
-    (void)hipStreamWaitEvent(c->pstream, c->ev_pts_in, 0);
     if (c->pts_free_rec) (void)hipStreamWaitEvent(c->pstream, c->ev_pts_free, 0);
     c->pts_pending = true;
   }
@@ -1511,6 +1514,8 @@ static void free_tracked(lf_ctx *c, void *p) {
   if (!p) return;
   for (size_t i = 0; i < c->allocs.size(); i++)
     if (c->allocs[i] == p) { c->allocs.erase(c->allocs.begin() + (long)i); break; }
+  for (size_t i = 0; i < c->guards.size(); i++)      // LF_DEBUG_GUARD: the tail is checked now; lf_ctx_destroy must not read freed memory
+    if (c->guards[i].p == p) { guard_check_one(c->guards[i]); c->guards.erase(c->guards.begin() + (long)i); break; }
   (void)hipFree(p);
 }
 static int comm_buffers(lf_ctx *c, int world, int max_kf) {

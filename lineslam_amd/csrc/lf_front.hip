@@ -511,6 +511,11 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
 #define MLE_M(S) ((S).accs)
 #define MLE_D(S) ((S).accs + 48)
 #define MLE_CI(S) ((S).accs + 56)   // [2][9]: inverse covariances of the two end points (read by the two lanes that own those rows)
+// a group's LDS block is ROWS * MLE_ROW_DOUBLES + MLE_ACC_DOUBLES doubles; the accumulator area starts 8 doubles in (behind the
+// eight remainder slots of scr), so what it holds -- M 48, D 6 (+2 pad), CI 18 -- must fit MLE_ACC_DOUBLES - 8
+static_assert(8 + 56 + 18 <= MLE_ACC_DOUBLES, "scr remainder slots + M + D + CI must fit the group's accumulator area");
+static_assert(48 + 6 <= 56, "MLE_D (the plain diagonal) must end before MLE_CI");
+static_assert(MLE_ROW_DOUBLES == 3 + 9 + 6 + 1 + 1, "LDS row = pos 3, DU 9, Jacobian row 6, e 1, scr 1 (f_mstate_bind)");
 struct MState {   // views into the group's LDS block, sized for the kernel variant's row capacity
   double *pos;    // [rows][3]
   double *DU;     // [rows][9]
@@ -677,6 +682,10 @@ __device__ __forceinline__ double f_ordered_sumsq(const MState &S, const double 
     const int i = g.glane + G * h;
     if (i < n) S.scr[(i < blockn) ? i : ROWS + (i - blockn)] = v[h] * v[h];
   }
+  // the remainder slots behind the last remainder row are zeroed on every call (the sum must not depend on a previous call with
+  // another n, or on anyone else having used the area); rows blockn .. ROWS-1 of the block area are zero from f_levmar6's clear
+  // and are never written: n only selects which of them are overwritten by squares, and every index < blockn IS overwritten
+  if (g.glane < 8 && g.glane >= r) S.scr[ROWS + g.glane] = 0.0;
   g_order<G>();
   const int t0 = (c - (7 - r)) & 3;
   const double r0 = S.scr[ROWS + t0], r1 = S.scr[ROWS + t0 + 4];

@@ -6,8 +6,10 @@
  * functions use ONLY IEEE-754 +,-,*,/ and sqrt on doubles (no fma, no table
  * look-ups, no libm), so the same source compiled by gcc (-ffp-contract=off)
  * and by hipcc (--offload-arch=gfx950 -ffp-contract=off) returns bit-identical
- * results.  Accuracy is <= 2 ulp against glibc (tests/test_lf_math.py), which
- * is far below anything that can flip an LSD decision.
+ * results.  Accuracy, measured against the x87 long-double libm (tests/test_lf_math.py):
+ * exp / log / sin / cos < 0.9 ulp, atan2 < 1.4, log10 < 1.8 (glibc's own: 1.6), acos < 2.5;
+ * the *_cr variants are correctly rounded (0.500 ulp).  Far below anything that can flip an
+ * LSD decision except at the one place the *_cr variants exist for.
  *
  * Polynomial coefficients are the classical minimax sets published with
  * FreeBSD msun / fdlibm (Sun Microsystems, "freely granted" licence); the

@@ -152,12 +152,17 @@ __global__ void __launch_bounds__(MT_N) k_match(PairConsts c, PairBuffers b) {
           (m_ov(a, t) > lineOverlapThresh)) {
         const double *da = f1[i].des, *db = f2[j].des;
         double s = 0;
-        for (int kk = 0; kk < 72; kk += 8) {          // eight loads of each side in flight, the sum in index order
+        // cv::norm(des_i - des_j) as OpenCV 2.4 sums it (normL2Sqr_, modules/core/src/stat.cpp): four squares per trip,
+        // s += ((v0 v0 + v1 v1) + v2 v2) + v3 v3.  Eight loads of each side in flight.
+        for (int kk = 0; kk < 72; kk += 8) {
           double x[8], y[8];
 #pragma unroll
           for (int u = 0; u < 8; u++) { x[u] = da[kk + u]; y[u] = db[kk + u]; }
 #pragma unroll
-          for (int u = 0; u < 8; u++) { double d = x[u] - y[u]; s += d * d; }
+          for (int u = 0; u < 8; u += 4) {
+            const double d0 = x[u] - y[u], d1 = x[u + 1] - y[u + 1], d2 = x[u + 2] - y[u + 2], d3 = x[u + 3] - y[u + 3];
+            s += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+          }
         }
         const double v = lf_sqrt(s);
         if (v != v) { if (j == 0) S.rdead[i] = 1; if (i == 0) S.cdead[j] = 1; }
@@ -246,7 +251,11 @@ __global__ void __launch_bounds__(256) k_descdiff(PairConsts c, PairBuffers b, i
        0.25 * m_pt_line2d(bb->p, a->lineEq2d) + 0.25 * m_pt_line2d(bb->q, a->lineEq2d) < lineDistThresh) &&
       (m_overlap(a, bb) > lineOverlapThresh)) {
     double s = 0;
-    for (int kk = 0; kk < 72; kk++) { double d = a->des[kk] - bb->des[kk]; s += d * d; }
+    for (int kk = 0; kk < 72; kk += 4) {    // OpenCV's normL2Sqr_ order (four squares per trip)
+      const double d0 = a->des[kk] - bb->des[kk], d1 = a->des[kk + 1] - bb->des[kk + 1], d2 = a->des[kk + 2] - bb->des[kk + 2],
+                   d3 = a->des[kk + 3] - bb->des[kk + 3];
+      s += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
     v = lf_sqrt(s);
   }
   D[idx] = v;

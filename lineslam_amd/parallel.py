@@ -43,6 +43,10 @@ def strong_plan(n_frames, world, rank, block=64):
       bnd_t       [b]   slot of their predecessor in the gathered map (owner * K + index)
       K                 key frames per rank"""
     nblk = (n_frames + block - 1) // block
+    if nblk < world:
+        # a rank without a block would create an empty context and then sit out the step's all-gather: the others hang
+        raise ValueError("strong_plan: %d frames in blocks of %d give %d blocks for %d ranks -- every rank needs one (smaller block or fewer ranks)"
+                         % (n_frames, block, nblk, world))
     K = max(1, (nblk + world - 1) // world)
     frames = shard_frames(n_frames, world, rank, block)
     local = {int(g): j for j, g in enumerate(frames)}

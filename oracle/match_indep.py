@@ -10,13 +10,24 @@ materialised with numpy broadcasting, then the reference's row / column scans ru
   scans (node.cpp:1656-1690)  row minimum (first), < descDiffThresh, mutual (column minimum is that row), second-best of the row
                               and of the column (started at 100) times 0.7 above the minimum
 
-cv::norm of a 72-vector of doubles sums in OpenCV's own order; numpy's norm differs in the last bits.  tests compare the match
-indices exactly and the distances to 1e-12 (a flipped decision would need two candidates closer than that).  NaN entries:
+cv::norm of a 72-vector of doubles sums in OpenCV's own order (four squares per trip): cv_norm_l2 below restates it, so the
+distances are compared bit for bit.  NaN entries:
 passed over by every `<` / `>` of the scans; the one case where published OpenCV versions differ -- a NaN in the FIRST position
 of a scanned row or column -- does not occur in the fixtures and is not asserted."""
 import numpy as np
 
 PI_SHORT = 3.14159265
+
+
+def cv_norm_l2(v):
+    """cv::norm(NORM_L2) of the rows of v [n, 72] in OpenCV 2.4's summation order (normL2Sqr_, modules/core/src/stat.cpp):
+    four elements per trip, their squares added left to right and the group added to the running sum."""
+    q = (v * v).reshape(len(v), -1, 4)
+    g = ((q[:, :, 0] + q[:, :, 1]) + q[:, :, 2]) + q[:, :, 3]
+    s = np.zeros(len(v))
+    for k in range(g.shape[1]):
+        s = s + g[:, k]
+    return np.sqrt(s)
 
 
 def _pt_line(px, py, l):
@@ -58,7 +69,7 @@ def desc_diff(f1, f2, adjacent):
     D = np.full((len(f1), len(f2)), 100.0)
     live = g1 & g2 & g3
     ii, jj = np.nonzero(live)
-    D[ii, jj] = np.linalg.norm(f1["des"][ii] - f2["des"][jj], axis=1)
+    D[ii, jj] = cv_norm_l2(f1["des"][ii] - f2["des"][jj])
     return D
 
 

@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -173,3 +174,12 @@ def test_strong_plan_covers_every_pair_once():
                 assert slot[int(t)] == p["frames"][q] - 1
                 newer.append(int(p["frames"][q]))
         assert sorted(newer) == list(range(1, F))
+
+
+def test_strong_plan_refuses_a_rank_without_a_block():
+    """fewer blocks than ranks: a rank would own nothing, create an empty context and miss the collective (the others hang)"""
+    with pytest.raises(ValueError):
+        parallel.strong_plan(100, 4, 3, block=64)      # 2 blocks, 4 ranks
+    for r in range(4):                                  # bench.py's block choice always gives every rank a block
+        pl = parallel.strong_plan(100, 4, r, block=max(1, min(64, 100 // 4)))
+        assert len(pl["frames"]) > 0
