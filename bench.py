@@ -83,6 +83,10 @@ def parse():
                          "VideoDynamicAdaptedFeatureDetector (FAST threshold adapted from frame to frame, 600..900 key points)")
     ap.add_argument("--serial-points", action="store_true",
                     help="with --points: the point front end on the context's own stream instead of beside the line front end")
+    ap.add_argument("--config4", action="store_true",
+                    help="ONLY BASELINE configs[3] (1 query frame vs 256 key-frame line maps, one launch per step): prints its own line, "
+                         "metric loop-closure pairs/s; without the flag the default line carries the same measurement as its `config4` object")
+    ap.add_argument("--no-config4", action="store_true", help="leave the config4 leg out of the default line")
     ap.add_argument("--default-params", action="store_true",
                     help="ParameterServer defaults (lsd_angle_thres 22.5, min_matches 20) instead of the shipped "
                          "launch/lineslam.launch values (40, 10), which are what the reference actually runs with")
@@ -221,6 +225,63 @@ def launch_probe(world):
         print(json.dumps({"probe": True, "n_gpus": n}))
 
 
+def config4_leg(steps=50, warmup=5, keyframes=256, device=0):
+    """BASELINE.json configs[3], timed in this process: batched loop closure -- ONE query frame against `keyframes` DISTINCT
+    key-frame line maps (synthetic trajectory seed 6, launch-file parameters, the map laid out as the RCCL all-gather delivers
+    it) in ONE launch per step.  Two timings: all-pairs line matching alone (lf_line_matching_device = Node::lineMatching x 256,
+    k_match) and with the pose solve of every pair (lf_match_external_device).  Roofline of k_match: SURVEY.md 8(d)'s algorithmic
+    bytes of the matching (per key frame L (72 + 11) 8 B of descriptors + 2D geometry + L 12 B of outputs, the query once;
+    L = the lines these frames really have) / the launch's HIP-event time."""
+    import torch
+    from lineslam_amd import capi, synth
+    NK = keyframes
+    g, d, _ = synth.sequence(NK + 1, seed=6)
+    P = capi.default_params(launch=True)
+    st = torch.cuda.Stream()              # the context launches on THIS stream, so the HIP events below see its kernels
+    ctx = capi.Context(640, 480, max_batch=NK + 1, params=P, device=device, stream=st.cuda_stream)
+    dg, dd = torch.from_numpy(g).cuda(), torch.from_numpy(d).cuda()
+    torch.cuda.synchronize()
+    ctx.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), NK + 1, synth.K_TUM, np.arange(NK + 1, dtype=np.uint64))
+    ctx.synchronize()
+    r_t, n_t, _ = ctx.device_records(torch)
+    ext = (r_t[:NK].contiguous(), n_t[:NK].contiguous(), (torch.arange(NK, device="cuda", dtype=torch.int64) + 1000).contiguous())
+    nl = n_t.cpu().numpy()
+    q, t = np.full(NK, NK, np.int32), np.arange(NK, dtype=np.int32)
+    e = (ext[0].data_ptr(), ext[1].data_ptr(), ext[2].data_ptr(), NK, ctx.line_cap)
+    algo = int(sum(int(n) * (72 + 11) * 8 + int(n) * 12 for n in nl[:NK]) + int(nl[NK]) * (72 + 11) * 8)
+    out = {"workload": "BASELINE configs[3]: 1 query vs %d DISTINCT key frames (synthetic trajectory, launch-file parameters), one launch per step" % NK,
+           "lines_per_keyframe": float(nl[:NK].mean()), "lines_query": int(nl[NK]), "steps": steps, "warmup": warmup,
+           "algorithmic_bytes_per_launch": algo}
+    for pose in (False, True):
+        def step():
+            if pose:
+                ctx.match_external_device(q, t, *e)
+            else:
+                ctx.line_matching_device(q, t, ext=e)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        t0 = time.perf_counter()
+        ev[0].record(st)
+        for _ in range(steps):
+            step()
+        ev[1].record(st)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kernel_ms = ev[0].elapsed_time(ev[1]) / steps
+        leg = {"value": NK * steps / dt, "unit": "pairs/s", "ms_per_step": dt / steps * 1e3, "launch_ms_hip_events": kernel_ms}
+        if not pose:
+            leg["roofline"] = {"bound": "hbm", "kernel": "k_match", "achieved": algo / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": algo / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "note": "one 512-thread block per pair, 256 blocks on 256 CUs: a single partial wave of blocks -- launch / latency "
+                                       "sized, bound by the gates' fp64 / LDS work on n1 n2 line pairs, not by these bytes"}
+            out["matches_total"] = int(sum(len(ctx.pair_matches(i)[0]) for i in range(NK)))
+        out["matching_and_pose" if pose else "matching_only"] = leg
+    ctx.close()
+    return out
+
+
 ROT_BUDGET_RAD, TRANS_BUDGET_M = 1e-4, 1e-3     # BASELINE.json north_star: SE(3) pose within 1e-4 rad / 1e-3 m
 
 
@@ -277,6 +338,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus
+    if a.config4:
+        if world != 1:
+            raise SystemExit("bench.py --config4 is a one-GPU measurement (configs[3])")
+        import torch
+        from lineslam_amd import build
+        torch.cuda.set_device(local)
+        build.build()
+        c4 = config4_leg(steps=max(a.steps, 10), warmup=max(a.warmup, 2), device=local)
+        m = c4["matching_only"]
+        print(json.dumps({"metric": "loop-closure pairs/sec: 1 query frame vs 256 key-frame line maps, all-pairs line matching (BASELINE configs[3])",
+                          "value": m["value"], "unit": "pairs/s", "n_gpus": 1, "steps": c4["steps"], "warmup": c4["warmup"], "ms_per_step": m["ms_per_step"],
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": c4["workload"], "lines_per_keyframe": c4["lines_per_keyframe"], "lines_query": c4["lines_query"],
+                                     "matches_total": c4["matches_total"]},
+                          "roofline": dict(m["roofline"], algorithmic_bytes_per_launch=c4["algorithmic_bytes_per_launch"], kernel_ms=m["launch_ms_hip_events"]),
+                          "with_pose": c4["matching_and_pose"]}))
+        return
     # LF_BENCH_FORCE_EXCHANGE=1: run the multi-rank code path (process group, keyframe all-gather, loop-closure
     # matching against the gathered map) even with one rank -- the only way to exercise it on a 1-GPU box
     dist_on = world > 1 or os.environ.get("LF_BENCH_FORCE_EXCHANGE") == "1"
@@ -654,6 +732,8 @@ def main():
                 out["quality"]["pair_pose_vs_cpu_lf_flavour"] = pose_agreement(gpu_sets, cpu_baseline.sets_lf)
     for c in ctxs:
         c.close()
+    if rank == 0 and world == 1 and not dist_on and not a.no_config4 and not a.points and a.detector == "lsd" and not strong:
+        out["config4"] = config4_leg(device=local)        # configs[3] on the driver's record: timed in this run, after the headline workload
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

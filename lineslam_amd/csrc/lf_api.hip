@@ -369,6 +369,7 @@ static int alloc_lsd(lf_ctx *c) {
   ALLOC(c, b.seeds, B * NM);
   ALLOC(c, b.nseeds, B);
   ALLOC(c, b.used, B * NM);
+  ALLOC(c, b.ndbits, B * (size_t)lc.M * (size_t)((lc.N + 31) / 32));
   ALLOC(c, b.reg, B * NM);
   ALLOC(c, b.tmp, B * NM);
   ALLOC(c, b.mw_tag, B * LF_MW_MAXW * NM);

@@ -60,6 +60,7 @@ struct LsdBuffers {
   uint32_t *seeds;       // [B][M*N]   pixel address y*N+x in reference list order
   int *nseeds;           // [B]
   uint8_t *used;         // [B][M*N]
+  uint32_t *ndbits;      // [B][M][ceil(N/32)] NOTDEF bitmap (bit x & 31 of word x >> 5 of row y), written by k_ll_angle
   uint32_t *reg;         // [B][M*N]   region pixel list, x | y<<16
   uint32_t *tmp;         // [B][M*N]   scratch for reduce_region_radius
   uint8_t *mw_tag;       // [B][W][M*N] private tentative marks of each sweep wavefront

@@ -169,6 +169,14 @@ __global__ void __launch_bounds__(256) k_ll_angle(LsdConsts c, LsdBuffers b) {
     b.modgrad[f * NM + adr] = norm;
     *(lf_d2 *)&b.cossin[2 * (f * NM + adr)] = (lf_d2){ca, sa};
   }
+  {
+    // NOTDEF bitmap of the frame, rows padded to whole 32-bit words (k_lsd_sweep_lu's initial `unavailable` mask): a wavefront
+    // covers two tile rows of 32 pixels -- the two halves of one ballot; pixels outside the image count as unavailable
+    const u64 ndm = __ballot(bin == LF_BIN_NONE);
+    const int wpr = (c.N + 31) >> 5;
+    if ((threadIdx.x & 31) == 0 && y < c.M)
+      b.ndbits[((size_t)f * c.M + y) * wpr + blockIdx.x] = (uint32_t)(ndm >> (threadIdx.x & 32));
+  }
   tile[ty][tx] = bin;
   __syncthreads();
   const int cx = threadIdx.x >> 3, ry = threadIdx.x & 7;     // 8 consecutive rows of one column per 8 threads
@@ -285,14 +293,22 @@ struct Rect {   // lsd.cpp:1075-1084, plus the precision level (p = p0 / 2^plev)
   double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p;
   int plev;
 };
-template <bool MW_>
+#define LF_TILE_W 8          // LU sweep: side of the (cos, sin) tile staged in LDS around a seed (64 pixels: one 16-byte DMA per lane)
+#define LF_TILE_AT 3         // the seed sits at (3, 3) of its tile: offsets -3 .. +4
+template <bool MW_, bool LU_ = false>
 struct FrameViewT {
   static constexpr bool kMW = MW_;
+  static constexpr bool kLU = LU_;                    // `used` lives in LDS as a bitmap, (cos, sin) tiles of the seeds are staged in LDS
+  static constexpr int kRing = LU_ ? 512 : 1024;      // most recent region pixels kept in LDS (the growth front reads them back)
   int N, M, lane;
   const double *angles, *modgrad, *lgam, *cossin;
   const double *nfa_tab;  // tabulated nfa() for small n (null: always evaluate)
   const LsdConsts *dc;
   uint8_t *used;          // committed `used` mask of the frame
+  uint32_t *ubits;        // LU: the frame's `unavailable` bitmap in LDS -- bit (x & 31) of word y * wpr + (x >> 5) is set when the pixel
+  int wpr;                //     is used OR its angle is NOTDEF (region_grow rejects both the same way, lsd.cpp:1639-1641, 807)
+  const lf_d2 *tile;      // LU: (cos, sin) of the LF_TILE_W x LF_TILE_W pixels from (tx0, ty0), staged in LDS by lu_stage_tile
+  int tx0, ty0;
   uint8_t *tag;           // multi-wave sweep: this wavefront's PRIVATE marks (null: mark `used` directly)
   uint32_t *reg, *tmp;    // region list / scratch, `cap` entries each
   int cap;
@@ -309,17 +325,29 @@ struct FrameViewT {
 // `used` as the growing region sees it: committed marks plus its own tentative marks
 typedef FrameViewT<false> FrameView;      // sequential sweep: marks go straight to `used`
 typedef FrameViewT<true> FrameViewMW;     // multi-wave sweep: private tentative marks
-template <class FV> __device__ __forceinline__ bool fv_is_used(const FV &f, int p) {
-  unsigned char u = f.used[p];
-  if constexpr (FV::kMW) u |= f.tag[p];
-  return u != 0;
+typedef FrameViewT<false, true> FrameViewLU;   // sequential sweep with `used` and the seeds' neighbourhoods in LDS
+template <class FV> __device__ __forceinline__ bool fv_is_used(const FV &f, int x, int y) {
+  if constexpr (FV::kLU) return ((f.ubits[y * f.wpr + (x >> 5)] >> (x & 31)) & 1u) != 0u;
+  else {
+    const int p = y * f.N + x;
+    unsigned char u = f.used[p];
+    if constexpr (FV::kMW) u |= f.tag[p];
+    return u != 0;
+  }
 }
-template <class FV> __device__ __forceinline__ void fv_mark(const FV &f, int p) { if constexpr (FV::kMW) f.tag[p] = 1; else f.used[p] = 1; }
-template <class FV> __device__ __forceinline__ void fv_unmark(const FV &f, int p) { if constexpr (FV::kMW) f.tag[p] = 0; else f.used[p] = 0; }
+template <class FV> __device__ __forceinline__ void fv_mark(const FV &f, int x, int y) {
+  if constexpr (FV::kLU) atomicOr(&f.ubits[y * f.wpr + (x >> 5)], 1u << (x & 31));   // (lanes of one wavefront may share a word)
+  else if constexpr (FV::kMW) f.tag[y * f.N + x] = 1;
+  else f.used[y * f.N + x] = 1;
+}
+template <class FV> __device__ __forceinline__ void fv_unmark(const FV &f, int x, int y) {
+  if constexpr (FV::kLU) atomicAnd(&f.ubits[y * f.wpr + (x >> 5)], ~(1u << (x & 31)));   // (region pixels are never NOTDEF: the bit was a mark)
+  else if constexpr (FV::kMW) f.tag[y * f.N + x] = 0;
+  else f.used[y * f.N + x] = 0;
+}
 
-// Entry i of the current region list (n entries): the LDS ring holds the most recent LF_RING entries at [i mod LF_RING],
-// i.e. the WHOLE list whenever n <= LF_RING -- nearly always -- so the passes over the list do not go to memory.
-#define LF_RING 1024   // most recent region pixels kept in LDS (the growth front reads them back)
+// Entry i of the current region list (n entries): the LDS ring holds the most recent FV::kRing entries at [i mod kRing],
+// i.e. the WHOLE list whenever n <= kRing -- nearly always -- so the passes over the list do not go to memory.
 template <class FV> __device__ __forceinline__ uint32_t fv_reg(const FV &f, int i, int n) {
   (void)n;
   return *f.ring_ok ? f.ring[i] : f.reg[i];
@@ -387,7 +415,8 @@ __device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec
   double sumdx = f.cossin[2 * seed], sumdy = f.cossin[2 * seed + 1];
   double S2 = sumdx * sumdx + sumdy * sumdy;
   bool angle_valid = true;     // reg_angle == atan2(sumdy, sumdx) of the current sums
-  if (lane == 0) { uint32_t pk = (uint32_t)sx | ((uint32_t)sy << 16); f.reg[0] = pk; ring[0] = pk; fv_mark(f, seed); }
+  constexpr int LF_RING = FV::kRing;
+  if (lane == 0) { uint32_t pk = (uint32_t)sx | ((uint32_t)sy << 16); f.reg[0] = pk; ring[0] = pk; fv_mark(f, sx, sy); }
   wave_mem_order();
   int size = 1, cur = 0;
   bool full = false;
@@ -404,7 +433,7 @@ __device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec
     int cx = (int)(pk & 0xffffu) + ox - 1, cy = (int)(pk >> 16) + (nb - ox * 3) - 1;
     bool inb = act && cx >= 0 && cy >= 0 && cx < N && cy < M;
     int ca = inb ? cy * N + cx : 0;
-    bool u = fv_is_used(f, ca);            // the gathers are issued together
+    bool u = fv_is_used(f, inb ? cx : 0, inb ? cy : 0);            // the gathers are issued together
     const lf_d2 csv = *(const lf_d2 *)&f.cossin[2 * ca];
     double cc = csv.x, ss = csv.y;
     bool cand = inb && !u && (cc <= 1.5);   // cos == 2 marks NOTDEF
@@ -479,7 +508,7 @@ __device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec
     if ((cmask >> lane) & 1ull) {
       int at = size0 + __popcll(cmask & lanemask_lt());
       uint32_t npk = (uint32_t)cx | ((uint32_t)cy << 16);
-      fv_mark(f, ca); f.reg[at] = npk; ring[at & (LF_RING - 1)] = npk;
+      fv_mark(f, cx, cy); f.reg[at] = npk; ring[at & (LF_RING - 1)] = npk;
     }
     wave_mem_order();
     cur += min(64, total - cur);
@@ -487,6 +516,149 @@ __device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec
   if (!angle_valid) reg_angle = lf_atan2(sumdy, sumdx);   // value after the last accepted pixel (lsd.cpp:1654)
   *reg_angle_io = reg_angle;
   if (lane == 0) *f.ring_ok = (size <= LF_RING) ? 1 : 0;   // (a list that shrinks later stays complete: fills are mirrored)
+  wave_mem_order();
+  return size;
+}
+
+// ---- region_grow with the frame's `used` mask and the seed's neighbourhood in LDS (FrameViewLU) -------------------------------
+// Same slot enumeration, same window decisions, same arithmetic in the same order as d_region_grow above; what changes is where
+// the operands come from:
+//   * `used` is a bitmap in LDS (24.5 KB for 512 x 384) that also carries NOTDEF -- region_grow rejects a used pixel
+//     (lsd.cpp:1639) and an undefined one (isaligned, :807) alike, and nothing else reads `used` -- so a window first reads its
+//     bits (one ds_read) and gathers (cos, sin) for the CANDIDATE lanes only;
+//   * (cos, sin) of the 8 x 8 pixels around the seed were staged in LDS by a DMA issued one region EARLIER (lu_stage_tile,
+//     global_load_lds: 64 lanes x 16 bytes, no registers): the small regions -- 95 % of all growths, 2.5 windows each -- decide
+//     entirely from LDS; a lane whose pixel lies outside the tile gathers it from memory as before;
+//   * the seed's own (cos, sin) comes from the tile, and its angle is only fetched in the one case that uses it (the exact
+//     fall-back before the first accepted pixel): the dependent load in front of every growth is gone.
+// `cossin` is immutable, so a staged tile can never be stale; `used` is read from the authoritative LDS bitmap at use time.
+__device__ __forceinline__ void lu_stage_tile(const double *cossin, lf_d2 *slot, int N, int M, int tx0, int ty0, int lane) {
+  const int x = tx0 + (lane & (LF_TILE_W - 1)), y = ty0 + (lane >> 3);
+  if (x >= 0 && y >= 0 && x < N && y < M)      // LDS destination = slot + lane * 16 (M0 base + lane * size): entry ly * 8 + lx
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(cossin + 2 * ((size_t)y * N + x)),
+                                     (__attribute__((address_space(3))) void *)slot, 16, 0, 0);
+}
+__device__ __forceinline__ void lu_wait_staged() {      // the wavefront's own DMAs have landed (nothing else orders a ds_read behind them)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <class FV>
+__device__ LF_NI_GROW int d_region_grow_lu(const FV &f, int sx, int sy, double prec, double cos_prec, double *reg_angle_io,
+                                           u64 *n_steps) {
+  static_assert(FV::kLU && !FV::kMW, "LDS-resident sweep only");
+  constexpr int RING = FV::kRing;
+  uint32_t *ring = f.ring;
+  const int N = f.N, M = f.M, lane = f.lane;
+  const int seed = sy * N + sx;
+  const bool fast = (prec > 1e-6 && prec < 1.5);
+  const double cp2 = cos_prec * cos_prec;
+  const int tx0 = f.tx0, ty0 = f.ty0;
+  double reg_angle = 0.0;
+  bool angle_valid = false, seed_angle = true;     // seed_angle: the region's angle is still angles[seed] (no pixel accepted yet)
+  double sumdx, sumdy;
+  {
+    const lf_d2 sv = f.tile[(sy - ty0) * LF_TILE_W + (sx - tx0)];     // the seed is always inside its own tile
+    sumdx = sv.x; sumdy = sv.y;
+  }
+  double S2 = sumdx * sumdx + sumdy * sumdy;
+  if (lane == 0) { uint32_t pk = (uint32_t)sx | ((uint32_t)sy << 16); f.reg[0] = pk; ring[0] = pk; fv_mark(f, sx, sy); }
+  wave_mem_order();
+  int size = 1, cur = 0;
+  for (;;) {
+    const int total = size * 9;
+    if (cur >= total) break;
+    LF_STAT((*n_steps)++);
+    int slot = cur + lane;
+    bool act = slot < total;
+    int pi = slot / 9, nb = slot - pi * 9;
+    uint32_t pk = (uint32_t)sx | ((uint32_t)sy << 16);
+    if (act && cur > 0) pk = (pi + RING >= size) ? ring[pi & (RING - 1)] : f.reg[pi];   // (first window, cur == 0: the seed's own neighbours)
+    int ox = nb / 3;
+    int cx = (int)(pk & 0xffffu) + ox - 1, cy = (int)(pk >> 16) + (nb - ox * 3) - 1;
+    bool inb = act && cx >= 0 && cy >= 0 && cx < N && cy < M;
+    int ca = inb ? cy * N + cx : 0;
+    bool cand = inb && !fv_is_used(f, inb ? cx : 0, inb ? cy : 0);
+    double cc = 2.0, ss = 0.0;
+    if (cand) {
+      const unsigned lx = (unsigned)(cx - tx0), ly = (unsigned)(cy - ty0);
+      lf_d2 csv;
+      if (lx < (unsigned)LF_TILE_W && ly < (unsigned)LF_TILE_W) csv = f.tile[ly * LF_TILE_W + lx];
+      else csv = *(const lf_d2 *)&f.cossin[2 * ca];
+      cc = csv.x; ss = csv.y;
+    }
+    cand = cand && (cc <= 1.5);             // (cos == 2 marks NOTDEF: already folded into the bitmap, kept as a guard)
+#ifdef LF_SWEEP_PROFILE
+    u64 tp0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    { int probe = __builtin_amdgcn_readfirstlane((int)cand + (int)(cc > 0.0)); asm volatile("" :: "s"(probe)); }
+    u64 tp1 = __builtin_amdgcn_s_memtime();
+#endif
+    const int size0 = size;
+    u64 cmask = 0;
+    int lastL = -1;
+    bool need_exact = !fast;
+    if (fast) {
+      u64 pendm = __ballot(cand);
+      double thr_hi = cp2 * S2 + 1e-12 * S2, thr_lo = cp2 * S2 - 1e-12 * S2;
+      for (;;) {
+        double dot = sumdx * cc + sumdy * ss;
+        double lhs = dot * dot;
+        const u64 posm = __builtin_amdgcn_ballot_w64(dot > 0.0) & pendm;
+        u64 ym = __builtin_amdgcn_ballot_w64(lhs > thr_hi) & posm;
+        u64 mm = __builtin_amdgcn_ballot_w64(!(lhs < thr_lo)) & posm;
+        if (mm != ym) { need_exact = true; break; }
+        if (ym == 0) break;
+        int L = __builtin_ctzll(ym);
+        double cL = rl64(cc, L), sL = rl64(ss, L);
+        pendm &= ~((2ull << L) - 1ull) & ~__builtin_amdgcn_ballot_w64(ca == rl32(ca, L));
+        cmask |= 1ull << L;
+        size++;
+        sumdx += cL;
+        sumdy += sL;
+        asm volatile("" : "+v"(sumdx), "+v"(sumdy));
+        S2 = sumdx * sumdx + sumdy * sumdy;
+        thr_hi = cp2 * S2 + 1e-12 * S2;
+        thr_lo = cp2 * S2 - 1e-12 * S2;
+        angle_valid = false; seed_angle = false;
+        lastL = L;
+      }
+      cand = cand && ((pendm >> lane) & 1ull);
+    }
+    if (need_exact) {   // the reference's own arithmetic for the rest of the window
+      double a_exact = cand ? f.angles[ca] : LF_NOTDEF;
+      for (;;) {
+        if (!angle_valid) { reg_angle = seed_angle ? f.angles[seed] : lf_atan2(sumdy, sumdx); angle_valid = true; }
+        bool ok = cand && lane > lastL && d_isaligned(a_exact, reg_angle, prec);
+        u64 mask = __ballot(ok);
+        if (mask == 0) break;
+        int L = __builtin_ctzll(mask);
+        double cL = rl64(cc, L), sL = rl64(ss, L);
+        if (ca == rl32(ca, L)) cand = false;
+        cmask |= 1ull << L;
+        size++;
+        sumdx += cL;
+        sumdy += sL;
+        S2 = sumdx * sumdx + sumdy * sumdy;
+        angle_valid = false; seed_angle = false;
+        lastL = L;
+      }
+    }
+#ifdef LF_SWEEP_PROFILE
+    { u64 tp2 = __builtin_amdgcn_s_memtime(); f.gprof[0]++; f.gprof[1] += tp1 - tp0; f.gprof[2] += tp2 - tp1; f.gprof[3] += (u64)__popcll(cmask); }
+#endif
+    if ((cmask >> lane) & 1ull) {
+      int at = size0 + __popcll(cmask & lanemask_lt());
+      uint32_t npk = (uint32_t)cx | ((uint32_t)cy << 16);
+      fv_mark(f, cx, cy); f.reg[at] = npk; ring[at & (RING - 1)] = npk;
+    }
+    wave_mem_order();
+    cur += min(64, total - cur);
+  }
+  // value after the last accepted pixel (lsd.cpp:1654); a region of the seed alone keeps the seed's stored angle -- its callers
+  // drop such a region (size < min_reg_size / size < 2) unless min_reg_size <= 1, so that load is left to them (*reg_angle_io
+  // is then -1e300: d_region_angle_of_seed)
+  if (!angle_valid) reg_angle = seed_angle ? -1e300 : lf_atan2(sumdy, sumdx);
+  *reg_angle_io = reg_angle;
+  if (lane == 0) *f.ring_ok = (size <= RING) ? 1 : 0;
   wave_mem_order();
   return size;
 }
@@ -922,7 +1094,7 @@ __device__ bool d_reduce_region_radius(const FV &f, int *reg_size, double reg_an
       uint32_t pk = v ? fv_reg(f, i, size) : 0u;
       int rx = (int)(pk & 0xffffu), ry = (int)(pk >> 16);
       bool far = v && (d_dist(xc, yc, (double)rx, (double)ry) > rad);
-      if (far) fv_unmark(f, ry * N + rx);
+      if (far) fv_unmark(f, rx, ry);
       bool hole = far && i < nkeep;
       bool fill = v && !far && i >= nkeep;
       u64 mh = __ballot(hole), mf = __ballot(fill);
@@ -966,7 +1138,7 @@ __device__ bool d_refine(const FV &f, int *reg_size, double reg_angle, double pr
     bool v = i < size;
     uint32_t pk = v ? fv_reg(f, i, size) : 0u;
     int rx = (int)(pk & 0xffffu), ry = (int)(pk >> 16);
-    if (v) fv_unmark(f, ry * N + rx);
+    if (v) fv_unmark(f, rx, ry);
     if constexpr (FV::kMW) { if (v && f.ever) { if (i < f.ever_cap) f.ever[i] = pk; } }   // first growth, kept for validation
     bool q = v && d_dist(xc, yc, (double)rx, (double)ry) < rec->width;
     double ang_d = q ? d_angle_diff_signed(f.angles[ry * N + rx], ang_c) : 0.0;
@@ -984,7 +1156,8 @@ __device__ bool d_refine(const FV &f, int *reg_size, double reg_angle, double pr
   double mean_angle = sum / (double)n;
   double tau = 2.0 * lf_sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
   if constexpr (FV::kMW) { if (f.ever) { if (size > f.ever_cap) { *f.overflow = 1; } *f.n_ever = size < f.ever_cap ? size : f.ever_cap; } }
-  size = d_region_grow(f, sx, sy, tau, lf_cos(tau), &reg_angle, n_steps);
+  if constexpr (FV::kLU) size = d_region_grow_lu(f, sx, sy, tau, lf_cos(tau), &reg_angle, n_steps);   // (a region of < 2 pixels is dropped below: its angle is never read)
+  else size = d_region_grow(f, sx, sy, tau, lf_cos(tau), &reg_angle, n_steps);
   *reg_size = size;
   if constexpr (FV::kMW) {
   if (*f.overflow) return false;
@@ -1010,30 +1183,13 @@ __device__ bool d_refine(const FV &f, int *reg_size, double reg_angle, double pr
 #ifndef LF_SWEEP_WAVES
 #define LF_SWEEP_WAVES 3
 #endif
-__global__ void __launch_bounds__(64, LF_SWEEP_WAVES) k_lsd_sweep(LsdConsts c, const LsdConsts *dc, LsdBuffers b) {
-  __builtin_amdgcn_s_setprio(LF_SWEEP_PRIO);
-  const int fidx = blockIdx.x, lane = lane_id();
+#define LF_LU_WORDS 6144    // LDS bitmap of k_lsd_sweep_lu in 32-bit words: 512 x 384 pixels (640 x 480 input); larger scaled
+                            // images take k_lsd_sweep (global `used`)
+// The seed loop for one frame; FV = FrameView (k_lsd_sweep) or FrameViewLU (k_lsd_sweep_lu: tiles = its two LDS tile slots).
+template <class FV>
+__device__ __forceinline__ void d_sweep_frame(FV &f, const LsdConsts &c, const LsdBuffers &b, int fidx, lf_d2 (*tiles)[64]) {
+  const int lane = f.lane;
   const size_t NM = (size_t)c.N * c.M;
-  FrameView f;
-  f.N = c.N; f.M = c.M; f.lane = lane;
-  f.angles = b.angles + fidx * NM;
-  f.modgrad = b.modgrad + fidx * NM;
-  f.cossin = b.cossin + 2 * fidx * NM;
-  f.lgam = b.lgam;
-  f.nfa_tab = b.nfa_tab;
-  f.dc = dc;
-  __shared__ uint32_t ring1[LF_RING];
-  __shared__ double sums1[64 * 4];
-  __shared__ int ring_ok1;
-  f.sums = sums1;
-  f.ring_ok = &ring_ok1;
-  f.used = b.used + fidx * NM;
-  f.tag = nullptr;
-  f.reg = b.reg + fidx * NM;
-  f.tmp = b.tmp + fidx * NM;
-  f.cap = (int)NM;
-  f.ring = ring1;
-  f.ever = nullptr; f.ever_cap = 0; f.n_ever = nullptr; f.overflow = nullptr;
   uint16_t *labels = b.labels + fidx * NM;
   const uint32_t *seeds = b.seeds + fidx * NM;
   double *segs = b.segs + (size_t)fidx * c.seg_cap * LF_SEG_STRIDE;
@@ -1055,7 +1211,9 @@ __global__ void __launch_bounds__(64, LF_SWEEP_WAVES) k_lsd_sweep(LsdConsts c, c
   // every region (a region may have swallowed later seeds of the window)
   int wbase = -64, wlast = 63;
   uint32_t addr = 0u;
+  int sxw = 0, syw = 0;        // this lane's seed of the window
   bool v = false;
+  int tkey0 = -1, tkey1 = -1;  // LU: seed index (position in the list) whose tile is staged / being staged in slot 0 / 1
   while (s < nseeds) {
     PROF(6);
     if (wlast >= 63) {            // next window
@@ -1065,21 +1223,40 @@ __global__ void __launch_bounds__(64, LF_SWEEP_WAVES) k_lsd_sweep(LsdConsts c, c
       int idx = s + lane;
       v = idx < nseeds;
       addr = v ? seeds[idx] : 0u;
+      syw = (int)addr / c.N; sxw = (int)addr - syw * c.N;
     }
-    bool isfree = v && lane > wlast && f.used[addr] == 0;      // angles != NOTDEF holds for every listed pixel
+    bool isfree = v && lane > wlast && !fv_is_used(f, sxw, syw);      // angles != NOTDEF holds for every listed pixel
     u64 m = __ballot(isfree);
     if (m == 0) { wlast = 63; continue; }
     int L = __builtin_ctzll(m);
-    int sa = rl32((int)addr, L);
     wlast = L;
-    int sx = sa % c.N, sy = sa / c.N;
+    int sx = rl32(sxw, L), sy = rl32(syw, L);
+    if constexpr (FV::kLU) {
+      // the seed's 8 x 8 (cos, sin) tile: staged while the PREVIOUS region was processed (slot keyed by the seed's list
+      // position); otherwise -- first seed of a window, or the predicted seed was swallowed by that region -- staged now
+      const int sidx = wbase + L;
+      int cs = (tkey1 == sidx) ? 1 : 0;
+      if (tkey0 != sidx && tkey1 != sidx) { lu_stage_tile(f.cossin, tiles[0], c.N, c.M, sx - LF_TILE_AT, sy - LF_TILE_AT, lane); tkey0 = sidx; }
+      lu_wait_staged();
+      // stage the tile of the next free seed of the window behind this region's work (cossin is immutable: never stale)
+      const u64 m2 = m & (m - 1);
+      if (m2) {
+        const int L2 = __builtin_ctzll(m2), nidx = wbase + L2;
+        lu_stage_tile(f.cossin, tiles[cs ^ 1], c.N, c.M, rl32(sxw, L2) - LF_TILE_AT, rl32(syw, L2) - LF_TILE_AT, lane);
+        if (cs) tkey0 = nidx; else tkey1 = nidx;
+      }
+      f.tile = tiles[cs]; f.tx0 = sx - LF_TILE_AT; f.ty0 = sy - LF_TILE_AT;
+    }
     double reg_angle;
     LF_STAT(++n_grow);
     PROF(0);
-    int reg_size = d_region_grow(f, sx, sy, c.prec, c.cos_prec, &reg_angle, &n_steps);
+    int reg_size;
+    if constexpr (FV::kLU) reg_size = d_region_grow_lu(f, sx, sy, c.prec, c.cos_prec, &reg_angle, &n_steps);
+    else reg_size = d_region_grow(f, sx, sy, c.prec, c.cos_prec, &reg_angle, &n_steps);
     PROF(1);
     LF_STAT(n_regpx += (u64)reg_size);
     if (reg_size < c.min_reg_size) continue;
+    if constexpr (FV::kLU) { if (reg_angle == -1e300) reg_angle = f.angles[sy * c.N + sx]; }   // a region of the seed alone that is kept (min_reg_size <= 1)
     Rect rec;
     d_region2rect(f, reg_size, reg_angle, c.prec, c.p, 0, &rec);
     PROF(2);
@@ -1104,7 +1281,7 @@ __global__ void __launch_bounds__(64, LF_SWEEP_WAVES) k_lsd_sweep(LsdConsts c, c
     for (int base = 0; base < reg_size; base += 64) {
       int i = base + lane;
       if (i < reg_size) {
-        uint32_t pk = f.reg[i];
+        uint32_t pk = fv_reg(f, i, reg_size);
         labels[(int)(pk >> 16) * c.N + (int)(pk & 0xffffu)] = (uint16_t)ls_count;
       }
     }
@@ -1125,6 +1302,56 @@ __global__ void __launch_bounds__(64, LF_SWEEP_WAVES) k_lsd_sweep(LsdConsts c, c
   }
 }
 #undef PROF
+template <class FV>
+__device__ __forceinline__ void d_bind_frame(FV &f, const LsdConsts &c, const LsdConsts *dc, const LsdBuffers &b, int fidx) {
+  const size_t NM = (size_t)c.N * c.M;
+  f.N = c.N; f.M = c.M; f.lane = lane_id();
+  f.angles = b.angles + fidx * NM;
+  f.modgrad = b.modgrad + fidx * NM;
+  f.cossin = b.cossin + 2 * fidx * NM;
+  f.lgam = b.lgam;
+  f.nfa_tab = b.nfa_tab;
+  f.dc = dc;
+  f.used = b.used + fidx * NM;
+  f.ubits = nullptr; f.wpr = 0; f.tile = nullptr; f.tx0 = 0; f.ty0 = 0;
+  f.tag = nullptr;
+  f.reg = b.reg + fidx * NM;
+  f.tmp = b.tmp + fidx * NM;
+  f.cap = (int)NM;
+  f.ever = nullptr; f.ever_cap = 0; f.n_ever = nullptr; f.overflow = nullptr;
+}
+__global__ void __launch_bounds__(64, LF_SWEEP_WAVES) k_lsd_sweep(LsdConsts c, const LsdConsts *dc, LsdBuffers b) {
+  __builtin_amdgcn_s_setprio(LF_SWEEP_PRIO);
+  __shared__ uint32_t ring1[FrameView::kRing];
+  __shared__ double sums1[64 * 4];
+  __shared__ int ring_ok1;
+  FrameView f;
+  d_bind_frame(f, c, dc, b, blockIdx.x);
+  f.sums = sums1; f.ring_ok = &ring_ok1; f.ring = ring1;
+  d_sweep_frame(f, c, b, blockIdx.x, nullptr);
+}
+// The same sweep with the frame's `used` mask (+ NOTDEF) as a bitmap in LDS and the seeds' (cos, sin) neighbourhoods staged in
+// LDS one region ahead (d_region_grow_lu): 30.0 KB of LDS per frame, five frames per CU.
+__global__ void __launch_bounds__(64, LF_SWEEP_WAVES) k_lsd_sweep_lu(LsdConsts c, const LsdConsts *dc, LsdBuffers b) {
+  __builtin_amdgcn_s_setprio(LF_SWEEP_PRIO);
+  __shared__ __attribute__((aligned(16))) uint32_t ubits1[LF_LU_WORDS];
+  __shared__ __attribute__((aligned(16))) lf_d2 tiles1[2][64];
+  __shared__ uint32_t ring1[FrameViewLU::kRing];
+  __shared__ double sums1[64 * 4];
+  __shared__ int ring_ok1;
+  FrameViewLU f;
+  const int fidx = blockIdx.x;
+  d_bind_frame(f, c, dc, b, fidx);
+  f.sums = sums1; f.ring_ok = &ring_ok1; f.ring = ring1;
+  f.ubits = ubits1; f.wpr = (c.N + 31) >> 5;
+  f.used = nullptr;
+  // the bitmap starts as the frame's NOTDEF mask (written by k_ll_angle; pad bits of a row are set)
+  const int nw = c.M * f.wpr;
+  const uint32_t *nd = b.ndbits + (size_t)fidx * nw;
+  for (int i = f.lane; i < nw; i += 64) ubits1[i] = nd[i];
+  wave_mem_order();
+  d_sweep_frame(f, c, b, fidx, tiles1);
+}
 
 
 // ----------------------------------------------------------------------------------------------
@@ -1170,7 +1397,7 @@ __device__ __noinline__ void mw_process(const FV &f, const LsdConsts &c, int sx,
 template <int W>
 __global__ void __launch_bounds__(W * 64) k_lsd_sweep_mw(LsdConsts c, const LsdConsts *dc, LsdBuffers b) {
   __shared__ SweepCtl ctl;
-  __shared__ uint32_t rings[W][LF_RING];
+  __shared__ uint32_t rings[W][FrameViewMW::kRing];
   __shared__ double sums_w[W][64 * 4];
   __shared__ int ring_ok_w[W];
   __shared__ int s_never[W], s_over[W];
@@ -1333,7 +1560,8 @@ void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int B, hipStream_t s
   hipLaunchKernelGGL(k_seed_hist, dim3(nch, B), blk, lds, st, c, b);
   hipLaunchKernelGGL(k_seed_scan, dim3(B), dim3(1024), 0, st, c, b);
   hipLaunchKernelGGL(k_seed_scatter, dim3(nch, B), dim3(64), lds, st, c, b);
-  (void)hipMemsetAsync(b.used, 0, NM * (size_t)B, st);
+  const bool lu = c.sweep_waves <= 1 && c.M * ((c.N + 31) >> 5) <= LF_LU_WORDS;      // the one-wavefront sweep with `used` in LDS
+  if (!lu) (void)hipMemsetAsync(b.used, 0, NM * (size_t)B, st);
   (void)hipMemsetAsync(b.labels, 0, NM * (size_t)B * sizeof(uint16_t), st);
   if (b.ev_sweep0) (void)hipEventRecord(b.ev_sweep0, st);
   if (c.sweep_waves > 1) {
@@ -1343,7 +1571,8 @@ void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int B, hipStream_t s
     else hipLaunchKernelGGL(k_lsd_sweep_mw<2>, dim3(B), dim3(2 * 64), 0, st, c, b.dconsts, b);
   } else {
 #ifndef LF_EXP_SKIP_SWEEP   // (throughput experiments only)
-    hipLaunchKernelGGL(k_lsd_sweep, dim3(B), dim3(64), 0, st, c, b.dconsts, b);
+    if (lu) hipLaunchKernelGGL(k_lsd_sweep_lu, dim3(B), dim3(64), 0, st, c, b.dconsts, b);
+    else hipLaunchKernelGGL(k_lsd_sweep, dim3(B), dim3(64), 0, st, c, b.dconsts, b);
 #endif
   }
   if (b.ev_sweep1) (void)hipEventRecord(b.ev_sweep1, st);

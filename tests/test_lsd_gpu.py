@@ -120,3 +120,54 @@ def test_lsd_large_image(built_lib):
     assert np.array_equal(segs, so)
     assert np.array_equal(labels.astype(np.int32), lo)
     ctx.close()
+
+
+def _one_wave_cases(fixtures_lsd):
+    rng = np.random.default_rng(41)
+    cases = [(fixtures_lsd[name], ang) for name, ang in CASES]
+    cases.append((np.full((480, 640), 128, np.uint8), 22.5))                            # no seeds at all
+    cases.append((rng.integers(0, 256, (480, 640), dtype=np.uint8), 40.0))               # noise: every seed a tiny region
+    for w, h in ((64, 48), (33, 17), (130, 9), (16, 16), (100, 75)):                     # scaled widths 51, 26, 104, 12, 80: rows of the
+        img = np.zeros((h, w), np.uint8)                                                 # bitmap are padded to whole words
+        img[:, w // 2:] = 200
+        img[h // 3:h // 3 + max(2, h // 4), : w // 3] = 120
+        cases.append((np.clip(img.astype(np.int32) + rng.integers(-6, 7, img.shape), 0, 255).astype(np.uint8), 22.5))
+    return cases
+
+
+def test_one_wavefront_sweeps_vs_oracle(built_lib, fixtures_lsd, monkeypatch):
+    """The kernels behind large batches, forced on small ones (LF_SWEEP_WAVES=1): k_lsd_sweep_lu -- `used` + NOTDEF as a bitmap
+    in LDS, the seeds' (cos, sin) tiles staged in LDS by DMA one region ahead -- for scaled images of up to 512 x 384, and
+    k_lsd_sweep (global `used`) above that.  Segments and region labels bit-equal to the oracle, on the reference's own test
+    images, on flat / noise frames, on images smaller than a tile, and on a 1280 x 720 frame."""
+    from lineslam_amd import capi, synth
+    monkeypatch.setenv("LF_SWEEP_WAVES", "1")
+    cases = _one_wave_cases(fixtures_lsd)
+    big, _, _ = synth.sequence(1, seed=9, w=1280, h=720)
+    cases.append((big[0], 22.5))                                                         # 1024 x 576 scaled: not the LDS variant
+    for img, ang in cases:
+        p = capi.default_params(); p.lsd_angle_th = ang
+        h, w = img.shape
+        ctx = capi.Context(w, h, max_batch=1, params=p)
+        segs, labels = ctx.lsd(img)
+        so, lo = O.lsd_oracle(img, ang, flavour="lf")
+        assert segs.shape == so.shape and np.array_equal(segs, so), (img.shape, ang)
+        assert np.array_equal(labels.astype(np.int32), lo), (img.shape, ang)
+        ctx.close()
+
+
+def test_one_wavefront_sweep_on_a_batch(built_lib, monkeypatch):
+    """k_lsd_sweep_lu on 24 different frames of one launch (every frame its own LDS bitmap and tile slots), launch-file angle"""
+    import torch
+    from lineslam_amd import capi, synth
+    monkeypatch.setenv("LF_SWEEP_WAVES", "1")
+    g, _, _ = synth.sequence(24, seed=21)
+    P = capi.default_params(launch=True)
+    ctx = capi.Context(640, 480, max_batch=24, params=P)
+    d = torch.from_numpy(g).cuda()
+    ctx.lsd_batch_device(d.data_ptr(), 24)
+    for k in range(24):
+        so, lo = O.lsd_oracle(g[k], P.lsd_angle_th, P.lsd_density_th, flavour="lf")
+        assert np.array_equal(ctx.lsd_segments(k), so), k
+        assert np.array_equal(ctx.lsd_labels(k).astype(np.int32), lo), k
+    ctx.close()
