@@ -287,6 +287,12 @@ static int build_lsd_consts(lf_ctx *c) {
     lc.sweep_waves = e ? atoi(e) : 0;
     if (lc.sweep_waves < 0) lc.sweep_waves = 0;
     if (lc.sweep_waves > LF_MW_MAXW) lc.sweep_waves = LF_MW_MAXW;
+    // LF_SWEEP_LU=1: the one-wavefront sweep keeps `used` (+ NOTDEF) as a bitmap in LDS and stages the seeds' (cos, sin) tiles in
+    // LDS by DMA (k_lsd_sweep_lu, 30 KB of LDS per frame).  Bit-identical; measured: a pass alone 105.5 ->
+    // 98.9 ms, but five frames fill a CU's LDS, so the passes of a pipelined run no longer share CUs with each other or with
+    // k_mle: four passes in flight 119 -> 153 ms.  Off by default.
+    const char *lu = getenv("LF_SWEEP_LU");
+    lc.sweep_lu = lu ? atoi(lu) : 0;
   }
   return LF_OK;
 }

@@ -636,6 +636,9 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
   }
   // ---- lines
   int nlines = 0;
+#ifdef LF_ED_EXP_WALK_ONLY      // (timing experiments only: tools/exp/ed_phase.sh)
+  b.nsegs[f] = nsegments; return;
+#endif
   for (int s = 0; s < nsegments && !overflow; s++) {
     nlines = e_split_segment(F, segpix + F.segtab[2 * s], F.segtab[2 * s + 1], s, c.min_len, nlines);
     if (nlines < 0) { overflow = true; nlines = 0; }
@@ -665,6 +668,9 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
     nlines = lastLineIndex + 1;
   }
   int nout = 0;
+#ifdef LF_ED_EXP_NO_VALIDATE
+  b.nsegs[f] = nlines; return;
+#endif
   for (int i = 0; i < nlines && !overflow; i++) {   // ValidateLineSegments
     const EdLine *ls = &F.lines[i];
     int valid;

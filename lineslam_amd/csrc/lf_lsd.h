@@ -37,6 +37,7 @@ struct LsdConsts {
   double log10p[LF_MAX_PLEVEL];  // log10(p / 2^k)
   int seg_cap;         // rows available per frame in the segment output
   int sweep_waves;     // wavefronts per frame in the seed sweep (1 = sequential kernel)
+  int sweep_lu;        // one-wavefront sweep: 1 = k_lsd_sweep_lu (`used` bitmap + seed tiles in LDS, 30 KB per frame), 0 = k_lsd_sweep
 };
 
 // Per-batch device pointers (frame f uses offset f * per-frame size).

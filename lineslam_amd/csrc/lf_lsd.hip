@@ -348,9 +348,14 @@ template <class FV> __device__ __forceinline__ void fv_unmark(const FV &f, int x
 
 // Entry i of the current region list (n entries): the LDS ring holds the most recent FV::kRing entries at [i mod kRing],
 // i.e. the WHOLE list whenever n <= kRing -- nearly always -- so the passes over the list do not go to memory.
+// (explicit address spaces: with generic pointers hipcc folds "ring or memory" into ONE flat_load of a selected address, which pays
+// the memory path's latency for what is nearly always an LDS read)
+typedef __attribute__((address_space(3))) uint32_t lf_lds_u32;
+typedef __attribute__((address_space(1))) uint32_t lf_glb_u32;
 template <class FV> __device__ __forceinline__ uint32_t fv_reg(const FV &f, int i, int n) {
   (void)n;
-  return *f.ring_ok ? f.ring[i] : f.reg[i];
+  if (*f.ring_ok) return ((const lf_lds_u32 *)f.ring)[i];      // (wave-uniform branch)
+  return ((const lf_glb_u32 *)f.reg)[i];
 }
 
 // lsd.cpp:147-165
@@ -534,9 +539,17 @@ __device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec
 // `cossin` is immutable, so a staged tile can never be stale; `used` is read from the authoritative LDS bitmap at use time.
 __device__ __forceinline__ void lu_stage_tile(const double *cossin, lf_d2 *slot, int N, int M, int tx0, int ty0, int lane) {
   const int x = tx0 + (lane & (LF_TILE_W - 1)), y = ty0 + (lane >> 3);
-  if (x >= 0 && y >= 0 && x < N && y < M)      // LDS destination = slot + lane * 16 (M0 base + lane * size): entry ly * 8 + lx
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(cossin + 2 * ((size_t)y * N + x)),
-                                     (__attribute__((address_space(3))) void *)slot, 16, 0, 0);
+  if (x >= 0 && y >= 0 && x < N && y < M) {
+    // global_load_lds_dwordx4: LDS destination = M0 (the slot's byte offset in LDS) + lane * 16, i.e. entry ly * 8 + lx of the
+    // slot.  Issued as inline assembly ON PURPOSE: with the builtin, hipcc orders every later LDS access and every fence of
+    // the wavefront behind the DMA (s_waitcnt vmcnt(0) in front of each ds_read / ds_or), which makes the staging synchronous;
+    // here the ONE consumer waits itself (lu_wait_staged) and nothing else touches the slot while the DMA is in flight.
+    // An instruction the compiler does not count only makes its own vmcnt(N) waits more conservative (memory operations of a
+    // wavefront complete in order), never too short.
+    const double *g = cossin + 2 * ((size_t)y * N + x);
+    const unsigned lds_off = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)slot);   // low half of the flat address of a __shared__ object = its LDS offset (wave-uniform)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_off) : "memory", "m0");
+  }
 }
 __device__ __forceinline__ void lu_wait_staged() {      // the wavefront's own DMAs have landed (nothing else orders a ds_read behind them)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -560,7 +573,10 @@ __device__ LF_NI_GROW int d_region_grow_lu(const FV &f, int sx, int sy, double p
     sumdx = sv.x; sumdy = sv.y;
   }
   double S2 = sumdx * sumdx + sumdy * sumdy;
-  if (lane == 0) { uint32_t pk = (uint32_t)sx | ((uint32_t)sy << 16); f.reg[0] = pk; ring[0] = pk; fv_mark(f, sx, sy); }
+  // The region's pixel list lives in the LDS ring; the frame's global list f.reg is written only from the window in which the
+  // region outgrows the ring (first the ring's content, then every new pixel) -- a region of <= kRing pixels, i.e. nearly
+  // every one, never stores to memory while it grows (fv_reg / the label pass read the ring while *f.ring_ok).
+  if (lane == 0) { ring[0] = (uint32_t)sx | ((uint32_t)sy << 16); fv_mark(f, sx, sy); }
   wave_mem_order();
   int size = 1, cur = 0;
   for (;;) {
@@ -570,21 +586,21 @@ __device__ LF_NI_GROW int d_region_grow_lu(const FV &f, int sx, int sy, double p
     int slot = cur + lane;
     bool act = slot < total;
     int pi = slot / 9, nb = slot - pi * 9;
-    uint32_t pk = (uint32_t)sx | ((uint32_t)sy << 16);
-    if (act && cur > 0) pk = (pi + RING >= size) ? ring[pi & (RING - 1)] : f.reg[pi];   // (first window, cur == 0: the seed's own neighbours)
+    uint32_t pk = ((const lf_lds_u32 *)ring)[pi & (RING - 1)];      // (inactive lanes read some slot of the ring: harmless)
+    if (size > RING) { if (act && pi + RING < size) pk = ((const lf_glb_u32 *)f.reg)[pi]; }   // wave-uniform guard: older entries of a big region
     int ox = nb / 3;
     int cx = (int)(pk & 0xffffu) + ox - 1, cy = (int)(pk >> 16) + (nb - ox * 3) - 1;
     bool inb = act && cx >= 0 && cy >= 0 && cx < N && cy < M;
     int ca = inb ? cy * N + cx : 0;
+    // the bitmap word and the tile entry are read together (both addresses depend on (cx, cy) only); a candidate outside the
+    // tile gathers its (cos, sin) from memory
+    const unsigned lx = (unsigned)(cx - tx0), ly = (unsigned)(cy - ty0);
+    const bool intile = inb && lx < (unsigned)LF_TILE_W && ly < (unsigned)LF_TILE_W;
+    lf_d2 csv = f.tile[intile ? ly * LF_TILE_W + lx : 0];
     bool cand = inb && !fv_is_used(f, inb ? cx : 0, inb ? cy : 0);
-    double cc = 2.0, ss = 0.0;
-    if (cand) {
-      const unsigned lx = (unsigned)(cx - tx0), ly = (unsigned)(cy - ty0);
-      lf_d2 csv;
-      if (lx < (unsigned)LF_TILE_W && ly < (unsigned)LF_TILE_W) csv = f.tile[ly * LF_TILE_W + lx];
-      else csv = *(const lf_d2 *)&f.cossin[2 * ca];
-      cc = csv.x; ss = csv.y;
-    }
+    const bool far = cand && !intile;
+    if (__builtin_amdgcn_ballot_w64(far) != 0ull) { if (far) csv = *(const lf_d2 *)&f.cossin[2 * ca]; }
+    double cc = cand ? csv.x : 2.0, ss = csv.y;
     cand = cand && (cc <= 1.5);             // (cos == 2 marks NOTDEF: already folded into the bitmap, kept as a guard)
 #ifdef LF_SWEEP_PROFILE
     u64 tp0 = __builtin_amdgcn_s_memtime();
@@ -645,10 +661,15 @@ __device__ LF_NI_GROW int d_region_grow_lu(const FV &f, int sx, int sy, double p
 #ifdef LF_SWEEP_PROFILE
     { u64 tp2 = __builtin_amdgcn_s_memtime(); f.gprof[0]++; f.gprof[1] += tp1 - tp0; f.gprof[2] += tp2 - tp1; f.gprof[3] += (u64)__popcll(cmask); }
 #endif
+    if (size > RING && size0 <= RING) {       // the region outgrows the ring in this window: the list so far goes to memory first
+      for (int i = lane; i < size0; i += 64) f.reg[i] = ring[i];
+      wave_mem_order();
+    }
     if ((cmask >> lane) & 1ull) {
       int at = size0 + __popcll(cmask & lanemask_lt());
       uint32_t npk = (uint32_t)cx | ((uint32_t)cy << 16);
-      fv_mark(f, cx, cy); f.reg[at] = npk; ring[at & (RING - 1)] = npk;
+      fv_mark(f, cx, cy); ring[at & (RING - 1)] = npk;
+      if (size > RING) f.reg[at] = npk;
     }
     wave_mem_order();
     cur += min(64, total - cur);
@@ -1107,7 +1128,11 @@ __device__ bool d_reduce_region_radius(const FV &f, int *reg_size, double reg_an
     // hole j (ascending position) <- fillers from the end: filler k (ascending) sits at tmp[NM-1-k]
     for (int base = 0; base < nh; base += 64) {
       int j = base + lane;
-      if (j < nh) { uint32_t at = f.tmp[j], fl = f.tmp[NM - nf + j]; f.reg[at] = fl; if (*f.ring_ok) f.ring[at] = fl; }
+      if (j < nh) {
+        uint32_t at = f.tmp[j], fl = f.tmp[NM - nf + j];
+        if (FV::kLU ? !*f.ring_ok : true) f.reg[at] = fl;      // (LU: the memory list exists only for regions beyond the ring)
+        if (*f.ring_ok) f.ring[at] = fl;
+      }
     }
     wave_mem_order();
     size = nkeep;
@@ -1213,7 +1238,12 @@ __device__ __forceinline__ void d_sweep_frame(FV &f, const LsdConsts &c, const L
   uint32_t addr = 0u;
   int sxw = 0, syw = 0;        // this lane's seed of the window
   bool v = false;
-  int tkey0 = -1, tkey1 = -1;  // LU: seed index (position in the list) whose tile is staged / being staged in slot 0 / 1
+  // LU: the two tile slots -- origin of the staged 8 x 8 pixels, DMA possibly still in flight, slot of the last region
+  int tox0 = -4096, toy0 = -4096, tox1 = -4096, toy1 = -4096, tcur = 0;
+  bool tpend0 = false, tpend1 = false;
+  // a slot serves a seed whose 3 x 3 neighbourhood lies inside it (tiles are immutable snapshots: any landed slot stays valid;
+  // consecutive seeds of the list are mostly neighbours in the image, so the slot of the last region usually serves the next)
+#define LU_COVERS(ox, oy, x, y) ((unsigned)((x) - (ox) - 1) < (unsigned)(LF_TILE_W - 2) && (unsigned)((y) - (oy) - 1) < (unsigned)(LF_TILE_W - 2))
   while (s < nseeds) {
     PROF(6);
     if (wlast >= 63) {            // next window
@@ -1232,20 +1262,29 @@ __device__ __forceinline__ void d_sweep_frame(FV &f, const LsdConsts &c, const L
     wlast = L;
     int sx = rl32(sxw, L), sy = rl32(syw, L);
     if constexpr (FV::kLU) {
-      // the seed's 8 x 8 (cos, sin) tile: staged while the PREVIOUS region was processed (slot keyed by the seed's list
-      // position); otherwise -- first seed of a window, or the predicted seed was swallowed by that region -- staged now
-      const int sidx = wbase + L;
-      int cs = (tkey1 == sidx) ? 1 : 0;
-      if (tkey0 != sidx && tkey1 != sidx) { lu_stage_tile(f.cossin, tiles[0], c.N, c.M, sx - LF_TILE_AT, sy - LF_TILE_AT, lane); tkey0 = sidx; }
-      lu_wait_staged();
-      // stage the tile of the next free seed of the window behind this region's work (cossin is immutable: never stale)
+      // the seed's (cos, sin) tile: the slot of the last region if it covers the seed, else the other slot if it does (staged
+      // while that region was processed), else staged now around the seed
+      const bool c0 = LU_COVERS(tox0, toy0, sx, sy), c1 = LU_COVERS(tox1, toy1, sx, sy);
+      int cs;
+      if (tcur ? c1 : c0) cs = tcur;
+      else if (tcur ? c0 : c1) cs = tcur ^ 1;
+      else {
+        cs = tcur ^ 1;
+        lu_stage_tile(f.cossin, tiles[cs], c.N, c.M, sx - LF_TILE_AT, sy - LF_TILE_AT, lane);
+        if (cs) { tox1 = sx - LF_TILE_AT; toy1 = sy - LF_TILE_AT; tpend1 = true; } else { tox0 = sx - LF_TILE_AT; toy0 = sy - LF_TILE_AT; tpend0 = true; }
+      }
+      if (cs ? tpend1 : tpend0) { lu_wait_staged(); tpend0 = false; tpend1 = false; }
+      tcur = cs;
+      // stage the tile of the next free seed of the window behind this region's work, unless a slot already serves it
       const u64 m2 = m & (m - 1);
       if (m2) {
-        const int L2 = __builtin_ctzll(m2), nidx = wbase + L2;
-        lu_stage_tile(f.cossin, tiles[cs ^ 1], c.N, c.M, rl32(sxw, L2) - LF_TILE_AT, rl32(syw, L2) - LF_TILE_AT, lane);
-        if (cs) tkey0 = nidx; else tkey1 = nidx;
+        const int L2 = __builtin_ctzll(m2), nx = rl32(sxw, L2), ny = rl32(syw, L2);
+        if (!LU_COVERS(tox0, toy0, nx, ny) && !LU_COVERS(tox1, toy1, nx, ny)) {
+          lu_stage_tile(f.cossin, tiles[cs ^ 1], c.N, c.M, nx - LF_TILE_AT, ny - LF_TILE_AT, lane);
+          if (cs) { tox0 = nx - LF_TILE_AT; toy0 = ny - LF_TILE_AT; tpend0 = true; } else { tox1 = nx - LF_TILE_AT; toy1 = ny - LF_TILE_AT; tpend1 = true; }
+        }
       }
-      f.tile = tiles[cs]; f.tx0 = sx - LF_TILE_AT; f.ty0 = sy - LF_TILE_AT;
+      f.tile = tiles[cs]; f.tx0 = cs ? tox1 : tox0; f.ty0 = cs ? toy1 : toy0;
     }
     double reg_angle;
     LF_STAT(++n_grow);
@@ -1302,6 +1341,7 @@ __device__ __forceinline__ void d_sweep_frame(FV &f, const LsdConsts &c, const L
   }
 }
 #undef PROF
+#undef LU_COVERS
 template <class FV>
 __device__ __forceinline__ void d_bind_frame(FV &f, const LsdConsts &c, const LsdConsts *dc, const LsdBuffers &b, int fidx) {
   const size_t NM = (size_t)c.N * c.M;
@@ -1560,7 +1600,7 @@ void lf_lsd_launch(const LsdConsts &c, const LsdBuffers &b, int B, hipStream_t s
   hipLaunchKernelGGL(k_seed_hist, dim3(nch, B), blk, lds, st, c, b);
   hipLaunchKernelGGL(k_seed_scan, dim3(B), dim3(1024), 0, st, c, b);
   hipLaunchKernelGGL(k_seed_scatter, dim3(nch, B), dim3(64), lds, st, c, b);
-  const bool lu = c.sweep_waves <= 1 && c.M * ((c.N + 31) >> 5) <= LF_LU_WORDS;      // the one-wavefront sweep with `used` in LDS
+  const bool lu = c.sweep_lu && c.sweep_waves <= 1 && c.M * ((c.N + 31) >> 5) <= LF_LU_WORDS;      // the one-wavefront sweep with `used` in LDS
   if (!lu) (void)hipMemsetAsync(b.used, 0, NM * (size_t)B, st);
   (void)hipMemsetAsync(b.labels, 0, NM * (size_t)B * sizeof(uint16_t), st);
   if (b.ev_sweep0) (void)hipEventRecord(b.ev_sweep0, st);
