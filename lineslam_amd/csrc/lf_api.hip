@@ -394,7 +394,7 @@ static int alloc_lsd(lf_ctx *c) {
   memset(&fb, 0, sizeof fb);
   fc.W = c->W; fc.H = c->H;
   fc.cand_cap = lc.seg_cap; fc.line_cap = c->caps.line_cap; fc.seg_cap = lc.seg_cap;   // every LSD segment is examined
-  fc.pts_slots = fc.line_cap;
+  fc.pts_slots = 2 * fc.line_cap < fc.cand_cap ? 2 * fc.line_cap : fc.cand_cap;     // one per long segment (k_cand_slots), twice the lines a frame may keep
   ALLOC(c, fb.gxy, B * (size_t)c->W * c->H * 2);
   ALLOC(c, c->d_frame_ids, B);
   ALLOC(c, fb.cand_flag, B * fc.cand_cap);
@@ -1849,7 +1849,8 @@ static int ed_prepare(lf_ctx *c) {
   ALLOC(c, b.hist, B * LF_ED_BINS); ALLOC(c, b.anchors, B * (size_t)e.anchor_cap); ALLOC(c, b.nanch, B);
   ALLOC(c, b.walk, B * HW); ALLOC(c, b.stack, B * (size_t)LF_ED_STACK_CAP * 2); ALLOC(c, b.chains, B * (size_t)(LF_ED_CHAIN_CAP + 1));
   ALLOC(c, b.chain_nos, B * WH8); ALLOC(c, b.segpix, B * HW); ALLOC(c, b.segtab, B * (size_t)e.segtab_cap * 2);
-  ALLOC(c, b.lines, B * (size_t)LF_ED_LINE_CAP); ALLOC(c, b.rect, B * WH8);
+  ALLOC(c, b.lines, B * (size_t)LF_ED_LINE_CAP);
+  ALLOC(c, b.nsegtab, B); ALLOC(c, b.seg_nl, B * (size_t)e.segtab_cap * 3); ALLOC(c, b.nslots, B); ALLOC(c, b.lvalid, B * (size_t)LF_ED_LINE_CAP);
   ALLOC(c, d_kmin, kmin.size()); ALLOC(c, d_lut, lut.size());
   HIPCHK(c, hipMemcpyAsync(d_kmin, kmin.data(), kmin.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_lut, lut.data(), lut.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));

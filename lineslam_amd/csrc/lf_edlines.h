@@ -36,8 +36,11 @@ struct EdBuffers {
   int *chain_nos;               // [B][(W + H) * 8]
   unsigned *segpix;             // [B][H*W] pixels of the edge segments, one after the other
   int *segtab;                  // [B][segtab_cap][2] first pixel, number of pixels
-  EdLine *lines;                // [B][LF_ED_LINE_CAP]
-  int *rect;                    // [B][(W + H) * 8] x | y of the rectangle enumeration
+  EdLine *lines;                // [B][LF_ED_LINE_CAP] line slots in list order (len = -1: joined into an earlier line)
+  int *nsegtab;                 // [B] edge segments of the frame (-1: the walk exceeded a capacity)
+  int *seg_nl;                  // [B][segtab_cap][3] lines of the segment before the joining, its first line slot, (spare)
+  int *nslots;                  // [B] line slots in use (-1: over capacity)
+  uint8_t *lvalid;              // [B][LF_ED_LINE_CAP] ValidateLineSegments per slot
   const int *kmin;              // [nmax] minimal number of aligned pixels for a meaningful line of n pixels (host table)
   const double *atan_lut;       // [1025] atan(i / 1024) (host table, as the binary builds it with libm)
   double *segs;                 // [B][seg_cap][5]  rows x1 y1 x2 y2 0 (the layout of the LSD output: the 3D stage reads both)

@@ -11,9 +11,13 @@
 //                  pass that ranks the anchors of every 64-pixel batch inside their bin (strongest first, raster order in
 //                  one gradient value)
 //   k_ed_link      ONE LANE PER FRAME, frames in flight are the parallel axis: the anchor walk with its explicit stack and
-//                  chain tree, the longest path as the edge segment, the leftover branches, then SplitSegment2Lines,
-//                  JoinCollinearLines and ValidateLineSegments -- a dependent chain per frame by nature (every step reads
-//                  what the previous one marked); fp64 sums in the oracle's order.
+//                  chain tree, the longest path as the edge segment, the leftover branches -- a dependent chain per frame by
+//                  nature (every step reads what the previous one marked)
+//   k_ed_split_count / k_ed_scan_segments / k_ed_split_join   SplitSegment2Lines + JoinCollinearLines with ONE LANE PER EDGE
+//                  SEGMENT (segments are independent; the line list is their concatenation): count, ordered offsets, then the
+//                  lines at their slots and the joining inside the segment; fp64 sums in the oracle's order
+//   k_ed_validate  ValidateLineSegments with ONE LANE PER LINE (the rectangle pixels are counted as they are enumerated)
+//   k_ed_emit      the valid lines in list order -> segment rows (one wavefront per frame)
 #include "lf_edlines.h"
 #include "lf_math.h"
 #include <float.h>
@@ -332,7 +336,9 @@ __device__ int e_aligned(const EdFrame &F, int r, int c, double lineAngle) {
   const double pixelAngle = e_my_atan2(F, (double)gx, (double)-gy), diff = lf_fabs(lineAngle - pixelAngle);
   return diff <= prec || diff >= ED_PI - prec;
 }
-__device__ int e_enumerate_rect_points(double sx, double sy, double ex, double ey, int *ptsx, int *ptsy, int cap) {
+struct EdRectCount;
+__device__ __forceinline__ void e_rect_point(EdRectCount *rc, int x, int y);
+__device__ int e_enumerate_rect_points(double sx, double sy, double ex, double ey, EdRectCount *rc, int cap) {
   double vxTmp[4], vyTmp[4], vx[4], vy[4];
   const double x1 = sx, y1 = sy, x2 = ex, y2 = ey, width = 2;
   double dx = x2 - x1, dy = y2 - y1, ys, ye;
@@ -393,27 +399,31 @@ __device__ int e_enumerate_rect_points(double sx, double sy, double ex, double e
       y = (int)__builtin_ceil(ys);
     }
     if (x > vx[2]) break;
-    ptsx[noPoints] = x; ptsy[noPoints] = y; noPoints++;
+    e_rect_point(rc, x, y); noPoints++;
   }
   return noPoints;
 }
+// ValidateLineSegments' rectangle test: the pixels of EnumerateRectPoints are consumed as they are produced (the binary fills
+// two arrays first and counts afterwards: same pixels, same order, no per-line scratch -- one lane validates one line)
+struct EdRectCount { const EdFrame *F; double lineAngle; int count, aligned; };
 __device__ int e_validate_rect(const EdFrame &F, const EdLine *ls) {
-  const double lineAngle = e_line_angle(ls);
-  const int cap = (F.W + F.H) * 4;
-  int *rx = F.rect, *ry = F.rect + cap;
-  const int noPoints = e_enumerate_rect_points(ls->sx, ls->sy, ls->ex, ls->ey, rx, ry, cap);
-  int count = 0, aligned = 0;
-  for (int i = 0; i < noPoints; i++) {
-    const int r = ry[i], c = rx[i];
-    if (r <= 0 || r >= F.H - 1 || c <= 0 || c >= F.W - 1) continue;
-    count++;
-    if (e_aligned(F, r, c, lineAngle)) aligned++;
-  }
-  return e_check_nfa(F, count, aligned);
+  EdRectCount rc;
+  rc.F = &F; rc.lineAngle = e_line_angle(ls); rc.count = 0; rc.aligned = 0;
+  e_enumerate_rect_points(ls->sx, ls->sy, ls->ex, ls->ey, &rc, (F.W + F.H) * 4);
+  return e_check_nfa(F, rc.count, rc.aligned);
 }
 
-// SplitSegment2Lines on the pixels p[0 .. noPixels) of segment segmentNo; appends to F.lines.  Returns the new line count, -1 on overflow.
-__device__ int e_split_segment(const EdFrame &F, const unsigned *p, int noPixels, int segmentNo, int min_line_len, int nlines) {
+__device__ __forceinline__ void e_rect_point(EdRectCount *rc, int x, int y) {
+  const EdFrame &F = *rc->F;
+  if (y <= 0 || y >= F.H - 1 || x <= 0 || x >= F.W - 1) return;
+  rc->count++;
+  if (e_aligned(F, y, x, rc->lineAngle)) rc->aligned++;
+}
+
+// SplitSegment2Lines on the pixels p[0 .. noPixels) of segment segmentNo; line k of the segment goes to out[k] (out == nullptr:
+// count only).  Returns the number of lines of the segment.
+__device__ int e_split_segment(const unsigned *p, int noPixels, int segmentNo, int min_line_len, EdLine *out) {
+  int nlines = 0;
   int firstPixelIndex = 0;
   while (noPixels >= min_line_len) {
     int valid = 0, lastInvert = 0, index, len;
@@ -451,8 +461,8 @@ __device__ int e_split_segment(const EdFrame &F, const unsigned *p, int noPixels
         e_closest_point(e_sx(p, i1), e_sy(p, i1), lastA, lastB, lastInvert, &l.ex, &l.ey);
         l.a = lastA; l.b = lastB; l.invert = lastInvert; l.pad_ = 0; l.pad2_ = 0; l.segmentNo = segmentNo;
         l.firstPixelIndex = firstPixelIndex + noSkippedPixels; l.len = i1 - noSkippedPixels + 1;
-        if (nlines >= LF_ED_LINE_CAP) return -1;
-        F.lines[nlines++] = l;
+        if (out) out[nlines] = l;
+        nlines++;
         len = i1 + 1;
         break;
       }
@@ -466,16 +476,20 @@ __device__ int e_split_segment(const EdFrame &F, const unsigned *p, int noPixels
 __device__ __forceinline__ bool e_near(unsigned a, unsigned b) { return e_iabs(e_pr(a) - e_pr(b)) <= 1 && e_iabs(e_pc(a) - e_pc(b)) <= 1; }
 
 __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
-  const int f = blockIdx.x;
-  if ((threadIdx.x & 63u) != 0) return;          // a dependent chain per frame: one lane walks, frames in flight fill the chip
+  // A dependent chain per frame; frames in flight fill the chip.  ALL 64 lanes run the walk with identical (uniform) state --
+  // same loads, same decisions, the same value stored to the same address by every lane (one write per instruction) -- so that
+  // the inner loop can fetch the 3 x 3 neighbourhoods of E, G and D around the walker with ONE load per step (lane l < 27
+  // loads cell l % 9 of map l / 9; the decisions read them with readlane) instead of four dependent round trips.
+  const int f = blockIdx.x, lane = (int)(threadIdx.x & 63u);
   const int W = c.W, H = c.H;
+  const int fk = lane / 9, fq = lane - 9 * fk, fdy = fq / 3 - 1, fdx = fq - 3 * (fq / 3) - 1;
   const size_t NP = (size_t)W * H;
   EdFrame F;
   F.G = b.G + f * NP; F.D = b.D + f * NP; F.E = b.E + f * NP; F.W = W; F.H = H;
   F.img = b.gray + (size_t)f * b.gray_frame_stride; F.img_stride = b.gray_row_stride;
   F.walk = b.walk + f * NP; F.stack = b.stack + (size_t)f * LF_ED_STACK_CAP * 2; F.segpix = b.segpix + f * NP;
   F.ch = b.chains + (size_t)f * (LF_ED_CHAIN_CAP + 1); F.chain_nos = b.chain_nos + (size_t)f * (W + H) * 8;
-  F.segtab = b.segtab + (size_t)f * c.segtab_cap * 2; F.rect = b.rect + (size_t)f * (W + H) * 8;
+  F.segtab = b.segtab + (size_t)f * c.segtab_cap * 2; F.rect = nullptr;
   F.lines = b.lines + (size_t)f * LF_ED_LINE_CAP;
   F.kmin = b.kmin; F.atan_lut = b.atan_lut; F.lut_size = c.lut_size; F.nmax = c.nmax;
   const int16_t *G = F.G; const uint8_t *D = F.D; uint8_t *E = F.E;
@@ -515,34 +529,53 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
       chains[noChains].dir = dir; chains[noChains].parent = parent; chains[noChains].child0 = chains[noChains].child1 = -1;
       chains[noChains].pix = len;
       pixels[len] = e_mk(r, cc); len++; chainLen++;
-      while (D[(size_t)r * W + cc] == (horizontal ? ED_HORIZONTAL : ED_VERTICAL)) {
-        E[(size_t)r * W + cc] = ED_EDGE;
-        if (horizontal) {
-          if (E[(size_t)(r - 1) * W + cc] == ED_ANCHOR) E[(size_t)(r - 1) * W + cc] = 0;
-          if (E[(size_t)(r + 1) * W + cc] == ED_ANCHOR) E[(size_t)(r + 1) * W + cc] = 0;
-          if (E[(size_t)r * W + cc + step] >= ED_ANCHOR) { cc += step; }
-          else if (E[(size_t)(r + step) * W + cc + step] >= ED_ANCHOR) { r += step; cc += step; }
-          else if (E[(size_t)(r - step) * W + cc + step] >= ED_ANCHOR) { r -= step; cc += step; }
-          else {
-            const int Ag = G[(size_t)(r - 1) * W + cc + step], Bg = G[(size_t)r * W + cc + step], Cg = G[(size_t)(r + 1) * W + cc + step];
-            if (Ag > Bg) { if (Ag > Cg) r--; else r++; }
-            else if (Cg > Bg) r++;
-            cc += step;
-          }
-        } else {
-          if (E[(size_t)r * W + cc - 1] == ED_ANCHOR) E[(size_t)r * W + cc - 1] = 0;
-          if (E[(size_t)r * W + cc + 1] == ED_ANCHOR) E[(size_t)r * W + cc + 1] = 0;
-          if (E[(size_t)(r + step) * W + cc] >= ED_ANCHOR) { r += step; }
-          else if (E[(size_t)(r + step) * W + cc + step] >= ED_ANCHOR) { r += step; cc += step; }
-          else if (E[(size_t)(r + step) * W + cc - step] >= ED_ANCHOR) { r += step; cc -= step; }
-          else {
-            const int Ag = G[(size_t)(r + step) * W + cc - 1], Bg = G[(size_t)(r + step) * W + cc], Cg = G[(size_t)(r + step) * W + cc + 1];
-            if (Ag > Bg) { if (Ag > Cg) cc--; else cc++; }
-            else if (Cg > Bg) cc++;
-            r += step;
+      for (;;) {
+        // E (cells 0..8), G (9..17), D (18..26) of the 3 x 3 pixels around (r, cc): cell (dy + 1) * 3 + (dx + 1)
+        int nv = 0;
+        {
+          const int rr = r + fdy, c2 = cc + fdx;
+          if (lane < 27 && rr >= 0 && rr < H && c2 >= 0 && c2 < W) {
+            const size_t at = (size_t)rr * W + c2;
+            nv = fk == 0 ? (int)E[at] : (fk == 1 ? (int)G[at] : (int)D[at]);
           }
         }
-        if (E[(size_t)r * W + cc] == ED_EDGE || G[(size_t)r * W + cc] < ED_GRAD_THRESH) {
+#define NB_E(dy, dx) __builtin_amdgcn_readlane(nv, ((dy) + 1) * 3 + (dx) + 1)
+#define NB_G(dy, dx) __builtin_amdgcn_readlane(nv, 9 + ((dy) + 1) * 3 + (dx) + 1)
+        if (__builtin_amdgcn_readlane(nv, 18 + 4) != (horizontal ? ED_HORIZONTAL : ED_VERTICAL)) break;
+        E[(size_t)r * W + cc] = ED_EDGE;
+        int nr = r, nc = cc;
+        if (horizontal) {
+          if (NB_E(-1, 0) == ED_ANCHOR) E[(size_t)(r - 1) * W + cc] = 0;
+          if (NB_E(1, 0) == ED_ANCHOR) E[(size_t)(r + 1) * W + cc] = 0;
+          if (NB_E(0, step) >= ED_ANCHOR) { nc += step; }
+          else if (NB_E(step, step) >= ED_ANCHOR) { nr += step; nc += step; }
+          else if (NB_E(-step, step) >= ED_ANCHOR) { nr -= step; nc += step; }
+          else {
+            const int Ag = NB_G(-1, step), Bg = NB_G(0, step), Cg = NB_G(1, step);
+            if (Ag > Bg) { if (Ag > Cg) nr--; else nr++; }
+            else if (Cg > Bg) nr++;
+            nc += step;
+          }
+        } else {
+          if (NB_E(0, -1) == ED_ANCHOR) E[(size_t)r * W + cc - 1] = 0;
+          if (NB_E(0, 1) == ED_ANCHOR) E[(size_t)r * W + cc + 1] = 0;
+          if (NB_E(step, 0) >= ED_ANCHOR) { nr += step; }
+          else if (NB_E(step, step) >= ED_ANCHOR) { nr += step; nc += step; }
+          else if (NB_E(step, -step) >= ED_ANCHOR) { nr += step; nc -= step; }
+          else {
+            const int Ag = NB_G(step, -1), Bg = NB_G(step, 0), Cg = NB_G(step, 1);
+            if (Ag > Bg) { if (Ag > Cg) nc--; else nc++; }
+            else if (Cg > Bg) nc++;
+            nr += step;
+          }
+        }
+        // the pixel walked to is one of the nine (its E and G were fetched before this step's stores, none of which touches it:
+        // they go to the walker's own pixel and its two side neighbours, the move goes one column / row ahead)
+        const int enew = NB_E(nr - r, nc - cc), gnew = NB_G(nr - r, nc - cc);
+        r = nr; cc = nc;
+#undef NB_E
+#undef NB_G
+        if (enew == ED_EDGE || gnew < ED_GRAD_THRESH) {
           if (chainLen > 0) {
             chains[noChains].len = chainLen;
             if (child0) chains[parent].child0 = noChains; else chains[parent].child1 = noChains;
@@ -571,7 +604,7 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
     }
     if (overflow) break;
     if (len - duplicatePixelCount < ED_MIN_PATH) {
-      for (int q = 0; q < len; q++) E[(size_t)e_pr(pixels[q]) * W + e_pc(pixels[q])] = 0;
+      for (int q = lane; q < len; q += 64) E[(size_t)e_pr(pixels[q]) * W + e_pc(pixels[q])] = 0;
       continue;
     }
     if ((size_t)nsegpix + (size_t)len + 2 >= NP) { overflow = true; break; }
@@ -589,7 +622,7 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
           int index = n - 2;
           while (index >= 0) { if (e_near(fp, seg[index])) { n--; index--; } else break; }
           if (chains[cn].len > 1 && n > 0) { fp = cp[chains[cn].len - 2]; if (e_near(fp, seg[n - 1])) chains[cn].len--; }
-          for (int l = chains[cn].len - 1; l >= 0; l--) seg[n++] = cp[l];
+          { const int cl = chains[cn].len; for (int l = lane; l < cl; l += 64) seg[n + l] = cp[cl - 1 - l]; if (cl > 0) n += cl; }   // (64 pixels per trip: the lanes share the copy)
           chains[cn].len = 0;
         }
       }
@@ -604,7 +637,7 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
           int index = n - 2, startIndex = 0;
           while (index >= 0) { if (e_near(cp[0], seg[index])) { n--; index--; } else break; }
           if (chains[cn].len > 1 && n > 0) { if (e_near(cp[1], seg[n - 1])) startIndex = 1; }
-          for (int l = startIndex; l < chains[cn].len; l++) seg[n++] = cp[l];
+          { const int cl = chains[cn].len - startIndex; for (int l = lane; l < cl; l += 64) seg[n + l] = cp[startIndex + l]; if (cl > 0) n += cl; }
           chains[cn].len = 0;
         }
       }
@@ -625,7 +658,7 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
           int index = n - 2, startIndex = 0;
           while (index >= 0) { if (e_near(cp[0], seg[index])) { n--; index--; } else break; }
           if (chains[cn].len > 1 && n > 0) { if (e_near(cp[1], seg[n - 1])) startIndex = 1; }
-          for (int l = startIndex; l < chains[cn].len; l++) seg[n++] = cp[l];
+          { const int cl = chains[cn].len - startIndex; for (int l = lane; l < cl; l += 64) seg[n + l] = cp[startIndex + l]; if (cl > 0) n += cl; }
           chains[cn].len = 0;
         }
         if (nsegments >= c.segtab_cap) { overflow = true; break; }
@@ -634,73 +667,124 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
       }
     }
   }
-  // ---- lines
-  int nlines = 0;
-#ifdef LF_ED_EXP_WALK_ONLY      // (timing experiments only: tools/exp/ed_phase.sh)
-  b.nsegs[f] = nsegments; return;
-#endif
-  for (int s = 0; s < nsegments && !overflow; s++) {
-    nlines = e_split_segment(F, segpix + F.segtab[2 * s], F.segtab[2 * s + 1], s, c.min_len, nlines);
-    if (nlines < 0) { overflow = true; nlines = 0; }
+  // ---- the edge segments are complete: the line stage runs on them with one lane per segment / per line (kernels below)
+  b.nsegtab[f] = overflow ? -1 : nsegments;
+}
+
+__device__ __forceinline__ void e_bind_lines(EdFrame &F, const EdConsts &c, const EdBuffers &b, int f) {
+  const size_t NP = (size_t)c.W * c.H;
+  F.G = nullptr; F.D = nullptr; F.E = nullptr; F.W = c.W; F.H = c.H;
+  F.img = b.gray + (size_t)f * b.gray_frame_stride; F.img_stride = b.gray_row_stride;
+  F.walk = nullptr; F.stack = nullptr; F.segpix = b.segpix + f * NP; F.ch = nullptr; F.chain_nos = nullptr;
+  F.segtab = b.segtab + (size_t)f * c.segtab_cap * 2; F.rect = nullptr;
+  F.lines = b.lines + (size_t)f * LF_ED_LINE_CAP;
+  F.kmin = b.kmin; F.atan_lut = b.atan_lut; F.lut_size = c.lut_size; F.nmax = c.nmax;
+}
+// SplitSegment2Lines, first pass: ONE LANE PER EDGE SEGMENT counts the lines its segment splits into (the segments are
+// independent of each other; the binary's line list is their concatenation in segment order)
+__global__ void __launch_bounds__(64) k_ed_split_count(EdConsts c, EdBuffers b) {
+  const int f = blockIdx.y, s = blockIdx.x * 64 + (int)threadIdx.x;
+  const int nseg = b.nsegtab[f];
+  if (s >= nseg) return;
+  const int *segtab = b.segtab + (size_t)f * c.segtab_cap * 2;
+  const unsigned *segpix = b.segpix + (size_t)f * c.W * c.H;
+  b.seg_nl[((size_t)f * c.segtab_cap + s) * 3] = e_split_segment(segpix + segtab[2 * s], segtab[2 * s + 1], s, c.min_len, nullptr);
+}
+// ordered offsets: one wavefront per frame scans the per-segment counts (which = 0: lines before the joining -> seg_nl[.][1] =
+// first slot of the segment, nslots[f] = all of them, frame over capacity beyond LF_ED_LINE_CAP as the sequential list)
+__global__ void __launch_bounds__(64) k_ed_scan_segments(EdConsts c, EdBuffers b) {
+  const int f = blockIdx.x, lane = (int)threadIdx.x;
+  const int nseg = b.nsegtab[f];
+  int *nl = b.seg_nl + (size_t)f * c.segtab_cap * 3;
+  int run = 0;
+  for (int s0 = 0; s0 < nseg; s0 += 64) {
+    const int s = s0 + lane;
+    int v = s < nseg ? nl[3 * s] : 0, inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (s < nseg) nl[3 * s + 1] = run + inc - v;
+    run += __shfl(inc, 63, 64);
   }
-  if (!overflow) {   // JoinCollinearLines
-    EdLine *L = F.lines;
-    int lastLineIndex = -1, i = 0;
-    while (i < nlines) {
-      const int segmentNo = L[i].segmentNo;
-      int count = 1;
-      lastLineIndex++;
-      if (lastLineIndex != i) L[lastLineIndex] = L[i];
-      const int firstLineIndex = lastLineIndex;
-      for (int j = i + 1; j < nlines; j++) {
-        if (L[j].segmentNo != segmentNo) break;
-        if (!e_try_to_join(&L[lastLineIndex], &L[j], ED_MAX_DIST, ED_MAX_ERROR)) {
-          lastLineIndex++;
-          if (lastLineIndex != j) L[lastLineIndex] = L[j];
-        }
-        count++;
+  if (lane == 0) b.nslots[f] = nseg < 0 ? -1 : (run > LF_ED_LINE_CAP ? -1 : run);
+}
+// second pass: the lines of the segment at their slots, then JoinCollinearLines inside the segment (it only ever joins lines
+// of one segment: consecutive ones, then the last to the first).  Slots the joining frees are marked dead (len = -1).
+__global__ void __launch_bounds__(64) k_ed_split_join(EdConsts c, EdBuffers b) {
+  const int f = blockIdx.y, s = blockIdx.x * 64 + (int)threadIdx.x;
+  const int nseg = b.nsegtab[f];
+  if (s >= nseg || b.nslots[f] < 0) return;
+  const int *segtab = b.segtab + (size_t)f * c.segtab_cap * 2;
+  const unsigned *segpix = b.segpix + (size_t)f * c.W * c.H;
+  const int *nl = b.seg_nl + ((size_t)f * c.segtab_cap + s) * 3;
+  EdLine *L = b.lines + (size_t)f * LF_ED_LINE_CAP + nl[1];
+  const int nlines = e_split_segment(segpix + segtab[2 * s], segtab[2 * s + 1], s, c.min_len, L);
+  int last = -1;
+  if (nlines > 0) {
+    last = 0;
+    for (int j = 1; j < nlines; j++) {
+      if (!e_try_to_join(&L[last], &L[j], ED_MAX_DIST, ED_MAX_ERROR)) {
+        last++;
+        if (last != j) L[last] = L[j];
       }
-      if (firstLineIndex != lastLineIndex) {
-        if (e_try_to_join(&L[firstLineIndex], &L[lastLineIndex], ED_MAX_DIST, ED_MAX_ERROR)) lastLineIndex--;
-      }
-      i += count;
     }
-    nlines = lastLineIndex + 1;
+    if (last != 0) { if (e_try_to_join(&L[0], &L[last], ED_MAX_DIST, ED_MAX_ERROR)) last--; }
   }
-  int nout = 0;
-#ifdef LF_ED_EXP_NO_VALIDATE
-  b.nsegs[f] = nlines; return;
-#endif
-  for (int i = 0; i < nlines && !overflow; i++) {   // ValidateLineSegments
-    const EdLine *ls = &F.lines[i];
-    int valid;
-    if (ls->len >= 80) valid = 1;
-    else if (ls->len <= 25) valid = e_validate_rect(F, ls);
-    else {
-      const double lineAngle = e_line_angle(ls);
-      const unsigned *px = segpix + F.segtab[2 * ls->segmentNo] + ls->firstPixelIndex;
-      int aligned = 0, count = 0;
-      for (int q = 0; q < ls->len; q++) {
-        const int r = e_pr(px[q]), cc = e_pc(px[q]);
-        if (r <= 0 || r >= H - 1 || cc <= 0 || cc >= W - 1) continue;
-        count++;
-        if (e_aligned(F, r, cc, lineAngle)) aligned++;
-      }
-      valid = e_check_nfa(F, count, aligned);
-      if (!valid) valid = e_validate_rect(F, ls);
+  for (int j = last + 1; j < nlines; j++) L[j].len = -1;
+}
+// ValidateLineSegments: ONE LANE PER LINE SLOT
+__global__ void __launch_bounds__(64) k_ed_validate(EdConsts c, EdBuffers b) {
+  const int f = blockIdx.y, i = blockIdx.x * 64 + (int)threadIdx.x;
+  const int nslots = b.nslots[f];
+  if (i >= nslots) return;
+  EdFrame F;
+  e_bind_lines(F, c, b, f);
+  const EdLine *ls = &F.lines[i];
+  int valid = 0;
+  if (ls->len >= 80) valid = 1;
+  else if (ls->len < 0) valid = 0;                       // joined into an earlier line of its segment
+  else if (ls->len <= 25) valid = e_validate_rect(F, ls);
+  else {
+    const double lineAngle = e_line_angle(ls);
+    const unsigned *px = F.segpix + F.segtab[2 * ls->segmentNo] + ls->firstPixelIndex;
+    int aligned = 0, count = 0;
+    for (int q = 0; q < ls->len; q++) {
+      const int r = e_pr(px[q]), cc = e_pc(px[q]);
+      if (r <= 0 || r >= c.H - 1 || cc <= 0 || cc >= c.W - 1) continue;
+      count++;
+      if (e_aligned(F, r, cc, lineAngle)) aligned++;
     }
-    if (valid) {
-      if (nout < c.seg_cap) { double *o = segs + 5 * (size_t)nout; o[0] = ls->sx; o[1] = ls->sy; o[2] = ls->ex; o[3] = ls->ey; o[4] = 0.0; }
-      nout++;
-    }
+    valid = e_check_nfa(F, count, aligned);
+    if (!valid) valid = e_validate_rect(F, ls);
   }
-  if (overflow) {
+  b.lvalid[(size_t)f * LF_ED_LINE_CAP + i] = (uint8_t)valid;
+}
+// the valid lines in list order -> segment rows: one wavefront per frame
+__global__ void __launch_bounds__(64) k_ed_emit(EdConsts c, EdBuffers b) {
+  const int f = blockIdx.x, lane = (int)threadIdx.x;
+  const int nslots = b.nslots[f];
+  double *segs = b.segs + (size_t)f * c.seg_cap * 5;
+  if (nslots < 0) {
     // an internal capacity was exceeded: the frame is reported as over capacity (nsegs > seg_cap: the getters return
-    // LF_ERR_CAPACITY), and the rows that were not written become zero-length segments -- the 3D stage treats all seg_cap
-    // rows of an over-capacity frame as present, and its length filter drops these instead of reading stale rows
-    for (int i = (nout < c.seg_cap ? nout : c.seg_cap); i < c.seg_cap; i++) { double *o = segs + 5 * (size_t)i; o[0] = o[1] = o[2] = o[3] = o[4] = 0.0; }
+    // LF_ERR_CAPACITY), and its rows become zero-length segments -- the 3D stage treats all seg_cap rows of an over-capacity
+    // frame as present, and its length filter drops these instead of reading stale rows
+    for (int i = lane; i < c.seg_cap * 5; i += 64) segs[i] = 0.0;
+    if (lane == 0) b.nsegs[f] = c.seg_cap + 1;
+    return;
   }
-  b.nsegs[f] = overflow ? c.seg_cap + 1 : nout;
+  const EdLine *L = b.lines + (size_t)f * LF_ED_LINE_CAP;
+  const uint8_t *lv = b.lvalid + (size_t)f * LF_ED_LINE_CAP;
+  int nout = 0;
+  for (int i0 = 0; i0 < nslots; i0 += 64) {
+    const int i = i0 + lane;
+    const bool v = i < nslots && lv[i] != 0;
+    const unsigned long long m = __ballot(v);
+    if (v) {
+      const int at = nout + __popcll(m & ((1ull << lane) - 1ull));
+      if (at < c.seg_cap) { double *o = segs + 5 * (size_t)at; o[0] = L[i].sx; o[1] = L[i].sy; o[2] = L[i].ex; o[3] = L[i].ey; o[4] = 0.0; }
+    }
+    nout += __popcll(m);
+  }
+  if (lane == 0) b.nsegs[f] = nout;
 }
 
 void lf_edlines_launch(const EdConsts &c, const EdBuffers &b, int B, hipStream_t st) {
@@ -710,4 +794,10 @@ void lf_edlines_launch(const EdConsts &c, const EdBuffers &b, int B, hipStream_t
   hipLaunchKernelGGL(k_ed_anchor, dim3((c.W * c.H + 255) / 256, B), dim3(256), 0, st, c, b);
   hipLaunchKernelGGL(k_ed_sort, dim3(B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_ed_link, dim3(B), dim3(64), 0, st, c, b);
+  const int sblocks = (c.segtab_cap + 63) / 64;
+  hipLaunchKernelGGL(k_ed_split_count, dim3(sblocks, B), dim3(64), 0, st, c, b);
+  hipLaunchKernelGGL(k_ed_scan_segments, dim3(B), dim3(64), 0, st, c, b);
+  hipLaunchKernelGGL(k_ed_split_join, dim3(sblocks, B), dim3(64), 0, st, c, b);
+  hipLaunchKernelGGL(k_ed_validate, dim3(LF_ED_LINE_CAP / 64, B), dim3(64), 0, st, c, b);
+  hipLaunchKernelGGL(k_ed_emit, dim3(B), dim3(64), 0, st, c, b);
 }

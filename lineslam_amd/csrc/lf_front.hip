@@ -286,6 +286,31 @@ __device__ __forceinline__ void f_jac_line(const double *pos, const double *M, c
   }
 }
 
+// Support-point slots of the frame's candidates: segment s gets the slot of its rank among the segments that pass the length
+// filter (lineslam.cpp:218) -- every one of them may become a 3D line -- or -1 beyond pts_slots (= 2 line_cap; k_records reports
+// the frame as over capacity if a kept line is left without one).  One wavefront per frame; deterministic, unlike a counter
+// bumped in completion order.
+__global__ void __launch_bounds__(64) k_cand_slots(FrontConsts c, FrontBuffers b) {
+  const int f = blockIdx.x, lane = f_lane();
+  int nseg = b.nsegs[f];
+  if (nseg > c.seg_cap) nseg = c.seg_cap;
+  if (nseg > c.cand_cap) nseg = c.cand_cap;
+  int base = 0;
+  for (int s0 = 0; s0 < c.cand_cap; s0 += 64) {
+    const int s = s0 + lane;
+    bool lng = false;
+    if (s < nseg) {
+      const double *sg = b.segs + ((size_t)f * c.seg_cap + s) * 5;
+      const double pa = sg[0], pb = sg[1], qc = sg[2], qd = sg[3];
+      lng = lf_sqrt((pa - qc) * (pa - qc) + (pb - qd) * (pb - qd)) > c.P.line_segment_len_thresh;
+    }
+    const u64 m = __ballot(lng);
+    const int rank = base + __popcll(m & f_lt());
+    if (s < c.cand_cap) b.cand_slot[(size_t)f * c.cand_cap + s] = (lng && rank < c.pts_slots) ? rank : -1;
+    base += __popcll(m);
+  }
+}
+
 __global__ void __launch_bounds__(64) k_line3d(FrontConsts c, FrontBuffers b) {
   __shared__ L3State S;
   const int cand = blockIdx.x, f = blockIdx.y, lane = f_lane();
@@ -431,13 +456,10 @@ __global__ void __launch_bounds__(64) k_line3d(FrontConsts c, FrontBuffers b) {
   bool have = (nbest / numSmp > P.ratio_of_collinear_pts) &&
               (lf_sqrt((LA[0] - LB[0]) * (LA[0] - LB[0]) + (LA[1] - LB[1]) * (LA[1] - LB[1]) + (LA[2] - LB[2]) * (LA[2] - LB[2])) > P.line3d_length_thresh);
   if (!have) { if (lane == 0) *flag = 1; return; }                                          // lineslam.cpp:302-307
-  // ---- hand the supporting points (line.pts, in list order) to the MLE kernel
+  // ---- hand the supporting points (line.pts, in list order) to the MLE kernel: the slot was fixed by k_cand_slots (rank of the
+  // segment among the frame's long segments -- independent of the order in which the wavefronts of this kernel finish)
   {
-    int slot = 0;
-    if (lane == 0) slot = atomicAdd(&b.pts_cnt[f], 1);
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    if (slot >= c.pts_slots) slot = -1;              // more 3D lines than slots: the frame overflows line_cap as well
-    if (lane == 0) b.cand_slot[(size_t)f * c.cand_cap + cand] = slot;
+    const int slot = b.cand_slot[(size_t)f * c.cand_cap + cand];
     if (slot >= 0) {
       double *pts = b.pts + ((size_t)f * c.pts_slots + slot) * (LF_MAX_SAMPLES * 3);
       bool in0 = (best0 >> lane) & 1ull, in1 = (best1 >> lane) & 1ull;
@@ -462,11 +484,13 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
   lf_line_record *recs = b.recs + (size_t)f * c.line_cap;
   int *list0 = b.mle_list + (size_t)f * 3 * c.line_cap, *list1 = list0 + c.line_cap, *list2 = list1 + c.line_cap;
   int base = 0, n0 = 0, n1 = 0, n2 = 0;
+  bool noslot = false;
   for (int s0 = 0; s0 < nseg; s0 += 64) {
     int s = s0 + lane;
     bool have = s < nseg && flag[s] == 2;
     u64 m = __ballot(have);
     int lid = base + __popcll(m & f_lt());
+    if (__ballot(have && lid < c.line_cap && b.cand_slot[(size_t)f * c.cand_cap + s] < 0) != 0ull) noslot = true;
     {   // MLE work lists by number of RANSAC support points: <= 16, 17..32, more
       bool kept = have && lid < c.line_cap;
       int nsup = kept ? (int)b.cand_out[((size_t)f * c.cand_cap + s) * LF_CAND_STRIDE + 26] : 0;
@@ -497,7 +521,12 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
     }
     base += __popcll(m);
   }
-  if (lane == 0) { b.nlines[f] = base; b.mle_cnt[3 * f] = n0; b.mle_cnt[3 * f + 1] = n1; b.mle_cnt[3 * f + 2] = n2; }
+  if (lane == 0) {
+    // (a kept line without a support-point slot -- more than pts_slots long segments in front of it -- has no refined end
+    // points: the frame is reported as over capacity, like one with more than line_cap lines)
+    b.nlines[f] = (noslot && base <= c.line_cap) ? c.line_cap + 1 : base;
+    b.mle_cnt[3 * f] = n0; b.mle_cnt[3 * f + 1] = n1; b.mle_cnt[3 * f + 2] = n2;
+  }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1285,7 +1314,7 @@ static void launch_mle_kernels(const FrontConsts &c, const FrontBuffers &b, int 
 }
 void lf_front_launch_mle(const FrontConsts &c, const FrontBuffers &b, int B, hipStream_t st) { launch_mle_kernels(c, b, B, st); }
 void lf_front_launch(const FrontConsts &c, const FrontBuffers &b, int B, hipStream_t st) {
-  (void)hipMemsetAsync(b.pts_cnt, 0, sizeof(int) * (size_t)B, st);
+  hipLaunchKernelGGL(k_cand_slots, dim3(B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_sobel5, dim3((c.W + 255) / 256, (c.H + SOBEL_ROWS - 1) / SOBEL_ROWS, B), dim3(256), 0, st, c, b);
   hipLaunchKernelGGL(k_line3d, dim3(c.cand_cap, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_records, dim3(B), dim3(64), 0, st, c, b);
