@@ -268,6 +268,7 @@ static int build_lsd_consts(lf_ctx *c) {
   lc.p = p.lsd_angle_th / 180.0;                            // lsd.cpp:1964
   lc.rho = p.lsd_quant / sin(lc.prec);                      // lsd.cpp:1965
   lc.cos_prec = cos(lc.prec);
+  lc.k_hi = lc.cos_prec * lc.cos_prec + 1e-12; lc.k_lo = lc.cos_prec * lc.cos_prec - 1e-12;
   lc.logNT = 5.0 * (log10((double)lc.N) + log10((double)lc.M)) / 2.0;   // lsd.cpp:1983
   lc.min_reg_size = (int)(-lc.logNT / log10(lc.p));         // lsd.cpp:1984
   lc.density_th = p.lsd_density_th;

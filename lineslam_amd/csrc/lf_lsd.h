@@ -27,6 +27,7 @@ struct LsdConsts {
   double prec;         // pi * ang_th / 180              (lsd.cpp:1963)
   double p;            // ang_th / 180                   (lsd.cpp:1964)
   double cos_prec;     // cos(prec), host libm: alignment pre-filter of region_grow
+  double k_hi, k_lo;   // cos^2(prec) +- 1e-12: the band of that pre-filter (scalar operands of the decision loop)
   double logNT;        // 5 (log10 N + log10 M) / 2      (lsd.cpp:1983)
   int min_reg_size;    // (int)(-logNT / log10 p)        (lsd.cpp:1984)
   double density_th;   // sysPara.lsd_density_th

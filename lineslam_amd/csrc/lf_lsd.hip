@@ -402,20 +402,19 @@ __device__ __forceinline__ double d_angle_diff(double a, double b) {          //
 //   | atan2(sumdy, sumdx) - a | (wrapped, lsd.cpp:799-832) < prec.
 // For 0 < prec < pi/2 that is  cos(angle between (sumdx,sumdy) and (cos a, sin a)) > cos(prec), i.e.
 //   dot > 0  and  dot^2 > cos^2(prec) |S|^2     with dot = sumdx cos a + sumdy sin a.
-// Both sides are evaluated in fp64 with relative error ~1e-15; whenever they are closer than 1e-12
-// (relative) the lane is AMBIGUOUS and the step falls back to the exact reference arithmetic (atan2 +
+// Both sides are evaluated in fp64 with relative error ~1e-15; whenever dot |dot| lies between (cos^2 prec - 1e-12) |S|^2
+// and (cos^2 prec + 1e-12) |S|^2 the lane is AMBIGUOUS and the step falls back to the exact reference arithmetic (atan2 +
 // isaligned), so every decision equals the reference's.  cos a / sin a come from k_ll_angle (the same
 // lf_sincos values the reference's sums use, lsd.cpp:1652-1653).  prec outside (1e-6, 1.5) -- possible for
 // the tolerance tau of refine() -- always takes the exact path (the wrap quirk of isaligned for angle
 // differences in (pi, 3pi/2] matters once prec > pi/2).
 template <class FV>
-__device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec, double cos_prec, double *reg_angle_io,
+__device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec, double k_hi, double k_lo, double *reg_angle_io,
                              u64 *n_steps) {
   uint32_t *ring = f.ring;
   const int N = f.N, M = f.M, lane = f.lane;
   const int seed = sy * N + sx;
   const bool fast = (prec > 1e-6 && prec < 1.5);
-  const double cp2 = cos_prec * cos_prec;
   double reg_angle = f.angles[seed];
   double sumdx = f.cossin[2 * seed], sumdy = f.cossin[2 * seed + 1];
   double S2 = sumdx * sumdx + sumdy * sumdy;
@@ -460,13 +459,14 @@ __device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec
     if (fast) {
       // candidate lanes still to be decided, as a scalar mask; every lane keeps its own (cc, ss, ca)
       u64 pendm = __ballot(cand);
-      double thr_hi = cp2 * S2 + 1e-12 * S2, thr_lo = cp2 * S2 - 1e-12 * S2;
+      // band of the pre-filter: (cos^2 prec -+ 1e-12) |S|^2; the signed square dot |dot| carries "dot > 0" with it (both band
+      // edges are positive for prec < 1.5), so one product and two compares decide a lane
+      double thr_hi = k_hi * S2, thr_lo = k_lo * S2;
       for (;;) {
         double dot = sumdx * cc + sumdy * ss;
-        double lhs = dot * dot;
-        const u64 posm = __builtin_amdgcn_ballot_w64(dot > 0.0) & pendm;
-        u64 ym = __builtin_amdgcn_ballot_w64(lhs > thr_hi) & posm;      // aligned for certain
-        u64 mm = __builtin_amdgcn_ballot_w64(!(lhs < thr_lo)) & posm;   // aligned or inside the 1e-12 band
+        double lhs = dot * __builtin_fabs(dot);
+        u64 ym = __builtin_amdgcn_ballot_w64(lhs > thr_hi) & pendm;      // aligned for certain
+        u64 mm = __builtin_amdgcn_ballot_w64(!(lhs < thr_lo)) & pendm;   // aligned or inside the 1e-12 band
         if (mm != ym) { need_exact = true; break; }              // ambiguous lane: exact arithmetic below
         if (ym == 0) break;
         if constexpr (FV::kMW) { if (size >= f.cap) { *f.overflow = 1; full = true; break; } }   // speculative list full: caller re-runs at the frontier
@@ -480,8 +480,8 @@ __device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec
         sumdy += sL;
         asm volatile("" : "+v"(sumdx), "+v"(sumdy));   // keep the running sums in vector registers (no SGPR round trip)
         S2 = sumdx * sumdx + sumdy * sumdy;
-        thr_hi = cp2 * S2 + 1e-12 * S2;
-        thr_lo = cp2 * S2 - 1e-12 * S2;
+        thr_hi = k_hi * S2;
+        thr_lo = k_lo * S2;
         angle_valid = false;
         lastL = L;
       }
@@ -555,7 +555,7 @@ __device__ __forceinline__ void lu_wait_staged() {      // the wavefront's own D
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 template <class FV>
-__device__ LF_NI_GROW int d_region_grow_lu(const FV &f, int sx, int sy, double prec, double cos_prec, double *reg_angle_io,
+__device__ LF_NI_GROW int d_region_grow_lu(const FV &f, int sx, int sy, double prec, double k_hi, double k_lo, double *reg_angle_io,
                                            u64 *n_steps) {
   static_assert(FV::kLU && !FV::kMW, "LDS-resident sweep only");
   constexpr int RING = FV::kRing;
@@ -563,7 +563,6 @@ __device__ LF_NI_GROW int d_region_grow_lu(const FV &f, int sx, int sy, double p
   const int N = f.N, M = f.M, lane = f.lane;
   const int seed = sy * N + sx;
   const bool fast = (prec > 1e-6 && prec < 1.5);
-  const double cp2 = cos_prec * cos_prec;
   const int tx0 = f.tx0, ty0 = f.ty0;
   double reg_angle = 0.0;
   bool angle_valid = false, seed_angle = true;     // seed_angle: the region's angle is still angles[seed] (no pixel accepted yet)
@@ -614,13 +613,12 @@ __device__ LF_NI_GROW int d_region_grow_lu(const FV &f, int sx, int sy, double p
     bool need_exact = !fast;
     if (fast) {
       u64 pendm = __ballot(cand);
-      double thr_hi = cp2 * S2 + 1e-12 * S2, thr_lo = cp2 * S2 - 1e-12 * S2;
+      double thr_hi = k_hi * S2, thr_lo = k_lo * S2;
       for (;;) {
         double dot = sumdx * cc + sumdy * ss;
-        double lhs = dot * dot;
-        const u64 posm = __builtin_amdgcn_ballot_w64(dot > 0.0) & pendm;
-        u64 ym = __builtin_amdgcn_ballot_w64(lhs > thr_hi) & posm;
-        u64 mm = __builtin_amdgcn_ballot_w64(!(lhs < thr_lo)) & posm;
+        double lhs = dot * __builtin_fabs(dot);
+        u64 ym = __builtin_amdgcn_ballot_w64(lhs > thr_hi) & pendm;
+        u64 mm = __builtin_amdgcn_ballot_w64(!(lhs < thr_lo)) & pendm;
         if (mm != ym) { need_exact = true; break; }
         if (ym == 0) break;
         int L = __builtin_ctzll(ym);
@@ -632,8 +630,8 @@ __device__ LF_NI_GROW int d_region_grow_lu(const FV &f, int sx, int sy, double p
         sumdy += sL;
         asm volatile("" : "+v"(sumdx), "+v"(sumdy));
         S2 = sumdx * sumdx + sumdy * sumdy;
-        thr_hi = cp2 * S2 + 1e-12 * S2;
-        thr_lo = cp2 * S2 - 1e-12 * S2;
+        thr_hi = k_hi * S2;
+        thr_lo = k_lo * S2;
         angle_valid = false; seed_angle = false;
         lastL = L;
       }
@@ -1181,8 +1179,9 @@ __device__ bool d_refine(const FV &f, int *reg_size, double reg_angle, double pr
   double mean_angle = sum / (double)n;
   double tau = 2.0 * lf_sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
   if constexpr (FV::kMW) { if (f.ever) { if (size > f.ever_cap) { *f.overflow = 1; } *f.n_ever = size < f.ever_cap ? size : f.ever_cap; } }
-  if constexpr (FV::kLU) size = d_region_grow_lu(f, sx, sy, tau, lf_cos(tau), &reg_angle, n_steps);   // (a region of < 2 pixels is dropped below: its angle is never read)
-  else size = d_region_grow(f, sx, sy, tau, lf_cos(tau), &reg_angle, n_steps);
+  const double ct = lf_cos(tau), ct2 = ct * ct;      // band of the alignment pre-filter for this tolerance: cos^2 tau -+ 1e-12
+  if constexpr (FV::kLU) size = d_region_grow_lu(f, sx, sy, tau, ct2 + 1e-12, ct2 - 1e-12, &reg_angle, n_steps);   // (a region of < 2 pixels is dropped below: its angle is never read)
+  else size = d_region_grow(f, sx, sy, tau, ct2 + 1e-12, ct2 - 1e-12, &reg_angle, n_steps);
   *reg_size = size;
   if constexpr (FV::kMW) {
   if (*f.overflow) return false;
@@ -1253,14 +1252,18 @@ __device__ __forceinline__ void d_sweep_frame(FV &f, const LsdConsts &c, const L
       int idx = s + lane;
       v = idx < nseeds;
       addr = v ? seeds[idx] : 0u;
-      syw = (int)addr / c.N; sxw = (int)addr - syw * c.N;
+      if constexpr (FV::kLU) { syw = (int)addr / c.N; sxw = (int)addr - syw * c.N; }   // (the bitmap is addressed by (x, y))
     }
-    bool isfree = v && lane > wlast && !fv_is_used(f, sxw, syw);      // angles != NOTDEF holds for every listed pixel
+    bool isfree;                                                       // angles != NOTDEF holds for every listed pixel
+    if constexpr (FV::kLU) isfree = v && lane > wlast && !fv_is_used(f, sxw, syw);
+    else isfree = v && lane > wlast && f.used[addr] == 0;
     u64 m = __ballot(isfree);
     if (m == 0) { wlast = 63; continue; }
     int L = __builtin_ctzll(m);
     wlast = L;
-    int sx = rl32(sxw, L), sy = rl32(syw, L);
+    int sx, sy;
+    if constexpr (FV::kLU) { sx = rl32(sxw, L); sy = rl32(syw, L); }
+    else { const int sa = rl32((int)addr, L); sx = sa % c.N; sy = sa / c.N; }
     if constexpr (FV::kLU) {
       // the seed's (cos, sin) tile: the slot of the last region if it covers the seed, else the other slot if it does (staged
       // while that region was processed), else staged now around the seed
@@ -1290,8 +1293,8 @@ __device__ __forceinline__ void d_sweep_frame(FV &f, const LsdConsts &c, const L
     LF_STAT(++n_grow);
     PROF(0);
     int reg_size;
-    if constexpr (FV::kLU) reg_size = d_region_grow_lu(f, sx, sy, c.prec, c.cos_prec, &reg_angle, &n_steps);
-    else reg_size = d_region_grow(f, sx, sy, c.prec, c.cos_prec, &reg_angle, &n_steps);
+    if constexpr (FV::kLU) reg_size = d_region_grow_lu(f, sx, sy, c.prec, c.k_hi, c.k_lo, &reg_angle, &n_steps);
+    else reg_size = d_region_grow(f, sx, sy, c.prec, c.k_hi, c.k_lo, &reg_angle, &n_steps);
     PROF(1);
     LF_STAT(n_regpx += (u64)reg_size);
     if (reg_size < c.min_reg_size) continue;
@@ -1418,7 +1421,7 @@ __device__ __noinline__ void mw_process(const FV &f, const LsdConsts &c, int sx,
                            u64 *n_steps, u64 *n_nfa, u64 *n_px) {
   double reg_angle;
   out->accepted = 0;
-  int reg_size = d_region_grow(f, sx, sy, c.prec, c.cos_prec, &reg_angle, n_steps);
+  int reg_size = d_region_grow(f, sx, sy, c.prec, c.k_hi, c.k_lo, &reg_angle, n_steps);
   out->reg_size = reg_size;
   if (f.overflow && *f.overflow) return;
   if (reg_size < c.min_reg_size) return;
