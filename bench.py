@@ -174,6 +174,25 @@ def cpu_baseline(gray, depth, P, n_frames):
         cpu_baseline.sets_ref = list(ex.map(lambda k: pair_sets(k, recs, "ref"), range(1, n)))
         recs_lf = list(ex.map(lambda k: front(k, "lf"), range(n)))
         cpu_baseline.sets_lf = list(ex.map(lambda k: pair_sets(k, recs_lf, "lf"), range(1, n)))
+    # the one stage whose REFERENCE CODE runs here: the reference's own lsd.c (oracle/_ref/liblsd_ref.so, built from /root/reference
+    # by oracle/Makefile, prebuilt on the GPU box), single thread, on the same frames -- next to the port's LSD stage
+    lsd_ref = None
+    try:
+        if O.ref_lsd_lib() is not None:
+            m3 = min(n, 8)
+            t0 = time.perf_counter()
+            for k in range(m3):
+                O.lsd_reference(gray[k], P.lsd_angle_th, P.lsd_density_th)
+            t_ref = (time.perf_counter() - t0) / m3
+            t0 = time.perf_counter()
+            for k in range(m3):
+                O.lsd_oracle(gray[k], P.lsd_angle_th, P.lsd_density_th, flavour="ref")
+            t_port = (time.perf_counter() - t0) / m3
+            lsd_ref = {"kind": "reference", "stage": "LSD only (callLsd -> LineSegmentDetection)", "ms_per_frame_reference_code": t_ref * 1e3,
+                       "ms_per_frame_port": t_port * 1e3, "cores": 1, "sample": "%d frames, the reference's lsd.c compiled as is vs oracle/lsd_oracle.c" % m3}
+    except Exception:
+        lsd_ref = None
+    variants["lsd_stage_reference_code"] = lsd_ref
     ref = variants["reference_shaped"] or variants["frames_parallel"]
     return {"value": ref["value"], "unit": "frames/s", "cores": ref["cores"], "kind": "port",
             "sample": ("reference-shaped threading: " if variants["reference_shaped"] else "") + ref["sample"] +

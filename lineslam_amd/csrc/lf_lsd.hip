@@ -354,6 +354,7 @@ typedef __attribute__((address_space(3))) uint32_t lf_lds_u32;
 typedef __attribute__((address_space(1))) uint32_t lf_glb_u32;
 template <class FV> __device__ __forceinline__ uint32_t fv_reg(const FV &f, int i, int n) {
   (void)n;
+  if constexpr (!FV::kLU) return *f.ring_ok ? f.ring[i] : f.reg[i];   // (k_lsd_sweep: the branchy form below costs it 34 more spilled registers)
   if (*f.ring_ok) return ((const lf_lds_u32 *)f.ring)[i];      // (wave-uniform branch)
   return ((const lf_glb_u32 *)f.reg)[i];
 }

@@ -60,3 +60,27 @@ def test_gpus_2_without_devices_exits_non_zero():
     r = _run(["--gpus", "2"], {})
     assert r.returncode != 0
     assert '"n_gpus"' not in r.stdout
+
+
+def test_pose_agreement_counts_budget_and_sets():
+    """the quality leg's pair-by-pair comparison: budget 1e-4 rad / 1e-3 m, broken down by identical match list / inlier set"""
+    import numpy as np
+    I = np.eye(4)
+
+    def rz(a, t=0.0):
+        T = np.eye(4); c, s = np.cos(a), np.sin(a)
+        T[:2, :2] = [[c, -s], [s, c]]; T[0, 3] = t
+        return T
+    q, t, inl = np.arange(5), np.arange(5), np.arange(4)
+    A = [(True, I, q, t, inl), (True, I, q, t, inl), (True, I, q, t, inl), (False, I, q, t, inl), (True, I, q, t, inl)]
+    B = [(True, rz(5e-5), q, t, inl),                 # inside the budget, same sets
+         (True, rz(3e-4), q, t, inl),                 # rotation over budget, SAME sets
+         (True, rz(0.0, 2e-3), q, t[::-1].copy(), inl),   # translation over budget, different match list
+         (False, I, q, t, inl),                       # invalid on both: not compared
+         (True, I, q, t, np.arange(3))]               # same match list, different inlier set, identical pose
+    r = bench.pose_agreement(A, B)
+    assert r["pairs"] == 5 and r["pairs_valid_on_both"] == 4 and r["pairs_with_identical_validity"] == 5
+    assert r["pairs_with_identical_match_list"] == 4 and r["pairs_with_identical_match_list_and_inlier_set"] == 3
+    assert r["pairs_over_budget"] == 2 and r["pairs_over_budget_with_identical_sets"] == 1
+    assert abs(r["max_rot_rad"] - 3e-4) < 1e-9 and abs(r["max_trans_m"] - 2e-3) < 1e-12
+    assert abs(r["max_rot_rad_identical_sets"] - 3e-4) < 1e-9
