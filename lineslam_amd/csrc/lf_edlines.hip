@@ -117,19 +117,32 @@ __global__ void __launch_bounds__(64) k_ed_sort(EdConsts c, EdBuffers b) {
   __shared__ int base[LF_ED_BINS];
   const int f = blockIdx.x, lane = threadIdx.x, W = c.W, H = c.H;
   const int *hist = b.hist + (size_t)f * LF_ED_BINS;
-  if (lane == 0) {
+  {   // base[g] = anchors with a larger gradient: exclusive suffix sums of the histogram, 64 bins per trip from the top
     int run = 0;
-    for (int g = LF_ED_BINS - 1; g >= 0; g--) { base[g] = run; run += hist[g]; }
-    b.nanch[f] = run;
+    for (int g0 = LF_ED_BINS - 64; g0 >= 0; g0 -= 64) {
+      const int g = g0 + 63 - lane;                 // lane 0 takes the largest value of the group
+      const int v = hist[g];
+      int inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+      base[g] = run + inc - v;
+      run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) b.nanch[f] = run;
   }
   __syncthreads();
   const uint8_t *E = b.E + (size_t)f * W * H;
   const int16_t *G = b.G + (size_t)f * W * H;
   unsigned *out = b.anchors + (size_t)f * c.anchor_cap;
+  // the map reads of the NEXT batch are issued before the current one is ranked (the ranking is one dependent chain of LDS
+  // counters; the reads need not wait for it)
+  int en = lane < W * H ? (int)E[lane] : 0, gn = lane < W * H ? (int)G[lane] : -1;
   for (int i0 = 0; i0 < W * H; i0 += 64) {
     const int i = i0 + lane;
-    const bool a = i < W * H && E[i] == ED_ANCHOR;
-    const int g = a ? (int)G[i] : -1;
+    const int ec = en, gc = gn;
+    { const int in = i + 64; en = in < W * H ? (int)E[in] : 0; gn = in < W * H ? (int)G[in] : -1; }
+    const bool a = ec == ED_ANCHOR;
+    const int g = a ? gc : -1;
     unsigned long long todo = __ballot(a);
     while (todo) {                                   // one gradient value of the batch at a time, its lanes ranked in lane order
       const int src = __builtin_ctzll(todo);
@@ -478,11 +491,10 @@ __device__ __forceinline__ bool e_near(unsigned a, unsigned b) { return e_iabs(e
 __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
   // A dependent chain per frame; frames in flight fill the chip.  ALL 64 lanes run the walk with identical (uniform) state --
   // same loads, same decisions, the same value stored to the same address by every lane (one write per instruction) -- so that
-  // the inner loop can fetch the 3 x 3 neighbourhoods of E, G and D around the walker with ONE load per step (lane l < 27
-  // loads cell l % 9 of map l / 9; the decisions read them with readlane) instead of four dependent round trips.
+  // the inner loop can fetch a 7 x 9 window of E, G and D ahead of the walker with ONE load per map (a cell per lane; the
+  // decisions read them with readlane) and walk up to eight pixels on it, instead of four dependent round trips per pixel.
   const int f = blockIdx.x, lane = (int)(threadIdx.x & 63u);
   const int W = c.W, H = c.H;
-  const int fk = lane / 9, fq = lane - 9 * fk, fdy = fq / 3 - 1, fdx = fq - 3 * (fq / 3) - 1;
   const size_t NP = (size_t)W * H;
   EdFrame F;
   F.G = b.G + f * NP; F.D = b.D + f * NP; F.E = b.E + f * NP; F.W = W; F.H = H;
@@ -504,8 +516,15 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
   if (overflow) noAnchors = c.anchor_cap;
   int nsegments = 0, nsegpix = 0;
   // ---- join the anchors, the one with the greatest gradient first
-  for (int k = 0; k < noAnchors && !overflow; k++) {
-    const int idx = (int)A[k], i = idx / W, j = idx - i * W;
+  // (the anchors are taken 64 at a time: one parallel look at the edge map drops those a walk has already consumed -- most of
+  // them -- without a dependent load each; an anchor that is still alive then is looked at again when its turn comes)
+  for (int k0 = 0; k0 < noAnchors && !overflow; k0 += 64) {
+   const int myidx = (k0 + lane < noAnchors) ? (int)A[k0 + lane] : -1;
+   unsigned long long am = __ballot(myidx >= 0 && E[myidx < 0 ? 0 : myidx] == ED_ANCHOR);
+   while (am != 0ull && !overflow) {
+    const int aL = __builtin_ctzll(am);
+    am &= am - 1ull;
+    const int idx = __builtin_amdgcn_readlane(myidx, aL), i = idx / W, j = idx - i * W;
     int noChains = 1, len = 0, duplicatePixelCount = 0, top = -1;
     if (E[idx] != ED_ANCHOR) continue;
     chains[0].len = 0; chains[0].parent = -1; chains[0].dir = 0; chains[0].child0 = chains[0].child1 = -1; chains[0].pix = 0;
@@ -529,63 +548,62 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
       chains[noChains].dir = dir; chains[noChains].parent = parent; chains[noChains].child0 = chains[noChains].child1 = -1;
       chains[noChains].pix = len;
       pixels[len] = e_mk(r, cc); len++; chainLen++;
-      for (;;) {
-        // E (cells 0..8), G (9..17), D (18..26) of the 3 x 3 pixels around (r, cc): cell (dy + 1) * 3 + (dx + 1)
-        int nv = 0;
-        {
-          const int rr = r + fdy, c2 = cc + fdx;
-          if (lane < 27 && rr >= 0 && rr < H && c2 >= 0 && c2 < W) {
-            const size_t at = (size_t)rr * W + c2;
-            nv = fk == 0 ? (int)E[at] : (fk == 1 ? (int)G[at] : (int)D[at]);
+      {
+        // The walk in (across, along) coordinates: along = the column of a horizontal walk / the row of a vertical one, advancing
+        // by `step` per pixel; across = the other coordinate.  A WINDOW of 7 (across, -3 .. +3) x 9 (along, 0 .. 8 steps ahead)
+        // pixels of E, G and D is fetched with one load per map (lane (xo + 3) * 9 + k holds cell (xo, k)) and serves the steps
+        // until the walker is within two steps of its far edge or more than two pixels off its axis -- up to eight pixels per
+        // memory round trip.  The walker's own stores go to its pixel and the two pixels beside it (same along position): every
+        // cell a later step consults lies further along, so the fetched values stay current.
+        int x = horizontal ? r : cc, a = horizontal ? cc : r;
+        int x0 = x, a0 = a, wk = 99, vE = 0, vG = 0, vD = 0;
+        const int fxo = lane / 9 - 3, fk = lane - 9 * (lane / 9);
+#define WCELL(v, xo, dk) __builtin_amdgcn_readlane(v, (x - x0 + (xo) + 3) * 9 + wk + (dk))
+        for (;;) {
+          if (wk > 7 || x - x0 > 2 || x0 - x > 2) {          // (re)fetch the window, the walker at (0, 0)
+            x0 = x; a0 = a; wk = 0;
+            const int px = x0 + fxo, pa = a0 + fk * step;
+            const int rr = horizontal ? px : pa, c2 = horizontal ? pa : px;
+            vE = 0; vG = 0; vD = 0;
+            if (lane < 63 && rr >= 0 && rr < H && c2 >= 0 && c2 < W) {
+              const size_t at = (size_t)rr * W + c2;
+              vE = (int)E[at]; vG = (int)G[at]; vD = (int)D[at];
+            }
           }
-        }
-#define NB_E(dy, dx) __builtin_amdgcn_readlane(nv, ((dy) + 1) * 3 + (dx) + 1)
-#define NB_G(dy, dx) __builtin_amdgcn_readlane(nv, 9 + ((dy) + 1) * 3 + (dx) + 1)
-        if (__builtin_amdgcn_readlane(nv, 18 + 4) != (horizontal ? ED_HORIZONTAL : ED_VERTICAL)) break;
-        E[(size_t)r * W + cc] = ED_EDGE;
-        int nr = r, nc = cc;
-        if (horizontal) {
-          if (NB_E(-1, 0) == ED_ANCHOR) E[(size_t)(r - 1) * W + cc] = 0;
-          if (NB_E(1, 0) == ED_ANCHOR) E[(size_t)(r + 1) * W + cc] = 0;
-          if (NB_E(0, step) >= ED_ANCHOR) { nc += step; }
-          else if (NB_E(step, step) >= ED_ANCHOR) { nr += step; nc += step; }
-          else if (NB_E(-step, step) >= ED_ANCHOR) { nr -= step; nc += step; }
+          if (WCELL(vD, 0, 0) != (horizontal ? ED_HORIZONTAL : ED_VERTICAL)) break;
+          {
+            const size_t at = horizontal ? (size_t)x * W + a : (size_t)a * W + x;
+            const size_t sd = horizontal ? (size_t)W : (size_t)1;        // one pixel across
+            E[at] = ED_EDGE;
+            if (WCELL(vE, -1, 0) == ED_ANCHOR) E[at - sd] = 0;
+            if (WCELL(vE, 1, 0) == ED_ANCHOR) E[at + sd] = 0;
+          }
+          int nx = x, enew;
+          if ((enew = WCELL(vE, 0, 1)) >= ED_ANCHOR) { }
+          else if ((enew = WCELL(vE, step, 1)) >= ED_ANCHOR) nx = x + step;
+          else if ((enew = WCELL(vE, -step, 1)) >= ED_ANCHOR) nx = x - step;
           else {
-            const int Ag = NB_G(-1, step), Bg = NB_G(0, step), Cg = NB_G(1, step);
-            if (Ag > Bg) { if (Ag > Cg) nr--; else nr++; }
-            else if (Cg > Bg) nr++;
-            nc += step;
+            const int Ag = WCELL(vG, -1, 1), Bg = WCELL(vG, 0, 1), Cg = WCELL(vG, 1, 1);
+            if (Ag > Bg) { if (Ag > Cg) nx = x - 1; else nx = x + 1; }
+            else if (Cg > Bg) nx = x + 1;
+            enew = WCELL(vE, nx - x, 1);
           }
-        } else {
-          if (NB_E(0, -1) == ED_ANCHOR) E[(size_t)r * W + cc - 1] = 0;
-          if (NB_E(0, 1) == ED_ANCHOR) E[(size_t)r * W + cc + 1] = 0;
-          if (NB_E(step, 0) >= ED_ANCHOR) { nr += step; }
-          else if (NB_E(step, step) >= ED_ANCHOR) { nr += step; nc += step; }
-          else if (NB_E(step, -step) >= ED_ANCHOR) { nr += step; nc -= step; }
-          else {
-            const int Ag = NB_G(step, -1), Bg = NB_G(step, 0), Cg = NB_G(step, 1);
-            if (Ag > Bg) { if (Ag > Cg) nc--; else nc++; }
-            else if (Cg > Bg) nc++;
-            nr += step;
+          const int gnew = WCELL(vG, nx - x, 1);
+          x = nx; a += step; wk++;
+          r = horizontal ? x : a; cc = horizontal ? a : x;
+          if (enew == ED_EDGE || gnew < ED_GRAD_THRESH) {
+            if (chainLen > 0) {
+              chains[noChains].len = chainLen;
+              if (child0) chains[parent].child0 = noChains; else chains[parent].child1 = noChains;
+              noChains++;
+            }
+            ended = true;
+            break;
           }
+          pixels[len] = e_mk(r, cc); len++; chainLen++;
+          if (len + 2 >= (int)NP) { overflow = true; break; }
         }
-        // the pixel walked to is one of the nine (its E and G were fetched before this step's stores, none of which touches it:
-        // they go to the walker's own pixel and its two side neighbours, the move goes one column / row ahead)
-        const int enew = NB_E(nr - r, nc - cc), gnew = NB_G(nr - r, nc - cc);
-        r = nr; cc = nc;
-#undef NB_E
-#undef NB_G
-        if (enew == ED_EDGE || gnew < ED_GRAD_THRESH) {
-          if (chainLen > 0) {
-            chains[noChains].len = chainLen;
-            if (child0) chains[parent].child0 = noChains; else chains[parent].child1 = noChains;
-            noChains++;
-          }
-          ended = true;
-          break;
-        }
-        pixels[len] = e_mk(r, cc); len++; chainLen++;
-        if (len + 2 >= (int)NP) { overflow = true; break; }
+#undef WCELL
       }
       if (overflow) break;
       if (ended) continue;
@@ -667,6 +685,7 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
       }
     }
   }
+  }
   // ---- the edge segments are complete: the line stage runs on them with one lane per segment / per line (kernels below)
   b.nsegtab[f] = overflow ? -1 : nsegments;
 }
@@ -715,29 +734,31 @@ __global__ void __launch_bounds__(64) k_ed_split_join(EdConsts c, EdBuffers b) {
   if (s >= nseg || b.nslots[f] < 0) return;
   const int *segtab = b.segtab + (size_t)f * c.segtab_cap * 2;
   const unsigned *segpix = b.segpix + (size_t)f * c.W * c.H;
-  const int *nl = b.seg_nl + ((size_t)f * c.segtab_cap + s) * 3;
-  EdLine *L = b.lines + (size_t)f * LF_ED_LINE_CAP + nl[1];
-  const int nlines = e_split_segment(segpix + segtab[2 * s], segtab[2 * s + 1], s, c.min_len, L);
-  int last = -1;
-  if (nlines > 0) {
-    last = 0;
-    for (int j = 1; j < nlines; j++) {
-      if (!e_try_to_join(&L[last], &L[j], ED_MAX_DIST, ED_MAX_ERROR)) {
-        last++;
-        if (last != j) L[last] = L[j];
+  {
+    const int *nl = b.seg_nl + ((size_t)f * c.segtab_cap + s) * 3;
+    EdLine *L = b.lines + (size_t)f * LF_ED_LINE_CAP + nl[1];
+    const int nlines = e_split_segment(segpix + segtab[2 * s], segtab[2 * s + 1], s, c.min_len, L);
+    int last = -1;
+    if (nlines > 0) {
+      last = 0;
+      for (int j = 1; j < nlines; j++) {
+        if (!e_try_to_join(&L[last], &L[j], ED_MAX_DIST, ED_MAX_ERROR)) {
+          last++;
+          if (last != j) L[last] = L[j];
+        }
       }
+      if (last != 0) { if (e_try_to_join(&L[0], &L[last], ED_MAX_DIST, ED_MAX_ERROR)) last--; }
     }
-    if (last != 0) { if (e_try_to_join(&L[0], &L[last], ED_MAX_DIST, ED_MAX_ERROR)) last--; }
+    for (int j = last + 1; j < nlines; j++) L[j].len = -1;
   }
-  for (int j = last + 1; j < nlines; j++) L[j].len = -1;
 }
 // ValidateLineSegments: ONE LANE PER LINE SLOT
 __global__ void __launch_bounds__(64) k_ed_validate(EdConsts c, EdBuffers b) {
-  const int f = blockIdx.y, i = blockIdx.x * 64 + (int)threadIdx.x;
+  const int f = blockIdx.y;
   const int nslots = b.nslots[f];
-  if (i >= nslots) return;
   EdFrame F;
   e_bind_lines(F, c, b, f);
+  for (int i = blockIdx.x * 64 + (int)threadIdx.x; i < nslots; i += gridDim.x * 64) {
   const EdLine *ls = &F.lines[i];
   int valid = 0;
   if (ls->len >= 80) valid = 1;
@@ -757,6 +778,7 @@ __global__ void __launch_bounds__(64) k_ed_validate(EdConsts c, EdBuffers b) {
     if (!valid) valid = e_validate_rect(F, ls);
   }
   b.lvalid[(size_t)f * LF_ED_LINE_CAP + i] = (uint8_t)valid;
+  }
 }
 // the valid lines in list order -> segment rows: one wavefront per frame
 __global__ void __launch_bounds__(64) k_ed_emit(EdConsts c, EdBuffers b) {
@@ -794,10 +816,12 @@ void lf_edlines_launch(const EdConsts &c, const EdBuffers &b, int B, hipStream_t
   hipLaunchKernelGGL(k_ed_anchor, dim3((c.W * c.H + 255) / 256, B), dim3(256), 0, st, c, b);
   hipLaunchKernelGGL(k_ed_sort, dim3(B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_ed_link, dim3(B), dim3(64), 0, st, c, b);
+  // one lane per segment slot (blocks past the frame's segment count exit at once; a strided loop over fewer blocks was measured
+  // 3-5x slower); the validation strides 16 blocks per frame over its few hundred lines (2.1 -> 1.2 ms)
   const int sblocks = (c.segtab_cap + 63) / 64;
   hipLaunchKernelGGL(k_ed_split_count, dim3(sblocks, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_ed_scan_segments, dim3(B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_ed_split_join, dim3(sblocks, B), dim3(64), 0, st, c, b);
-  hipLaunchKernelGGL(k_ed_validate, dim3(LF_ED_LINE_CAP / 64, B), dim3(64), 0, st, c, b);
+  hipLaunchKernelGGL(k_ed_validate, dim3(16, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_ed_emit, dim3(B), dim3(64), 0, st, c, b);
 }
