@@ -728,7 +728,7 @@ def main():
         }
         if a.detector == "edlines" and not a.no_cpu:
             print("bench: --detector edlines: the cpu_baseline leg times the LSD configuration only; skipped", file=sys.stderr)
-        if not a.no_cpu and a.detector != "edlines":
+        if not a.no_cpu and a.detector != "edlines" and world == 1:      # (the CPU leg belongs to the one-GPU line: rank 0 at N = 1 only)
             ncpu = a.cpu_frames or max(16, min(FT, 6 * (os.cpu_count() or 1)))
             out["cpu_baseline"] = cpu_baseline(gray_all if strong else gray, depth_all if strong else depth, P, ncpu)   # (lines-only CPU path, also next to --points)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
