@@ -409,17 +409,25 @@ __device__ __forceinline__ double d_angle_diff(double a, double b) {          //
 // lf_sincos values the reference's sums use, lsd.cpp:1652-1653).  prec outside (1e-6, 1.5) -- possible for
 // the tolerance tau of refine() -- always takes the exact path (the wrap quirk of isaligned for angle
 // differences in (pi, 3pi/2] matters once prec > pi/2).
-template <class FV>
+// GIVEN: the caller hands over the seed's (cos, sin) -- the sweep gathers them for all 64 seeds of its window at once -- and the
+// seed's angle is fetched only where it is used (the exact fall-back before the first accepted pixel; a region of the seed alone
+// that the caller keeps: *reg_angle_io = -1e300): no dependent load in front of the growth.
+template <class FV, bool GIVEN = false>
 __device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec, double k_hi, double k_lo, double *reg_angle_io,
-                             u64 *n_steps) {
+                             u64 *n_steps, double seed_cos = 0.0, double seed_sin = 0.0) {
   uint32_t *ring = f.ring;
   const int N = f.N, M = f.M, lane = f.lane;
   const int seed = sy * N + sx;
   const bool fast = (prec > 1e-6 && prec < 1.5);
-  double reg_angle = f.angles[seed];
-  double sumdx = f.cossin[2 * seed], sumdy = f.cossin[2 * seed + 1];
+  double reg_angle, sumdx, sumdy;
+  bool seed_angle = false;                 // the region's angle is still angles[seed], not loaded yet (no pixel accepted)
+  if constexpr (GIVEN) { sumdx = seed_cos; sumdy = seed_sin; reg_angle = 0.0; seed_angle = true; }
+  else {
+    reg_angle = f.angles[seed];
+    sumdx = f.cossin[2 * seed]; sumdy = f.cossin[2 * seed + 1];
+  }
   double S2 = sumdx * sumdx + sumdy * sumdy;
-  bool angle_valid = true;     // reg_angle == atan2(sumdy, sumdx) of the current sums
+  bool angle_valid = !GIVEN;     // reg_angle == atan2(sumdy, sumdx) of the current sums (GIVEN: == angles[seed], pending)
   constexpr int LF_RING = FV::kRing;
   if (lane == 0) { uint32_t pk = (uint32_t)sx | ((uint32_t)sy << 16); f.reg[0] = pk; ring[0] = pk; fv_mark(f, sx, sy); }
   wave_mem_order();
@@ -483,7 +491,7 @@ __device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec
         S2 = sumdx * sumdx + sumdy * sumdy;
         thr_hi = k_hi * S2;
         thr_lo = k_lo * S2;
-        angle_valid = false;
+        angle_valid = false; seed_angle = false;
         lastL = L;
       }
       cand = cand && ((pendm >> lane) & 1ull);   // (for the exact path below: lanes already decided stay decided)
@@ -491,7 +499,7 @@ __device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec
     if (need_exact && !full) {   // the reference's own arithmetic for the rest of the window
       double a_exact = cand ? f.angles[ca] : LF_NOTDEF;
       for (;;) {
-        if (!angle_valid) { reg_angle = lf_atan2(sumdy, sumdx); angle_valid = true; }
+        if (!angle_valid) { reg_angle = seed_angle ? f.angles[seed] : lf_atan2(sumdy, sumdx); angle_valid = true; }
         bool ok = cand && lane > lastL && d_isaligned(a_exact, reg_angle, prec);
         u64 mask = __ballot(ok);
         if (mask == 0) break;
@@ -504,7 +512,7 @@ __device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec
         sumdx += cL;
         sumdy += sL;
         S2 = sumdx * sumdx + sumdy * sumdy;
-        angle_valid = false;
+        angle_valid = false; seed_angle = false;
         lastL = L;
       }
     }
@@ -519,7 +527,7 @@ __device__ LF_NI_GROW int d_region_grow(const FV &f, int sx, int sy, double prec
     wave_mem_order();
     cur += min(64, total - cur);
   }
-  if (!angle_valid) reg_angle = lf_atan2(sumdy, sumdx);   // value after the last accepted pixel (lsd.cpp:1654)
+  if (!angle_valid) reg_angle = seed_angle ? -1e300 : lf_atan2(sumdy, sumdx);   // value after the last accepted pixel (lsd.cpp:1654); GIVEN, seed alone: the caller loads angles[seed] if it keeps the region
   *reg_angle_io = reg_angle;
   if (lane == 0) *f.ring_ok = (size <= LF_RING) ? 1 : 0;   // (a list that shrinks later stays complete: fills are mirrored)
   wave_mem_order();
@@ -1237,6 +1245,7 @@ __device__ __forceinline__ void d_sweep_frame(FV &f, const LsdConsts &c, const L
   int wbase = -64, wlast = 63;
   uint32_t addr = 0u;
   int sxw = 0, syw = 0;        // this lane's seed of the window
+  lf_d2 wcs = (lf_d2){0.0, 0.0};   // plain view: its (cos, sin)
   bool v = false;
   // LU: the two tile slots -- origin of the staged 8 x 8 pixels, DMA possibly still in flight, slot of the last region
   int tox0 = -4096, toy0 = -4096, tox1 = -4096, toy1 = -4096, tcur = 0;
@@ -1254,6 +1263,7 @@ __device__ __forceinline__ void d_sweep_frame(FV &f, const LsdConsts &c, const L
       v = idx < nseeds;
       addr = v ? seeds[idx] : 0u;
       if constexpr (FV::kLU) { syw = (int)addr / c.N; sxw = (int)addr - syw * c.N; }   // (the bitmap is addressed by (x, y))
+      if constexpr (!FV::kLU) wcs = *(const lf_d2 *)&f.cossin[2 * (size_t)addr];   // (cos, sin) of the window's 64 seeds, one gather
     }
     bool isfree;                                                       // angles != NOTDEF holds for every listed pixel
     if constexpr (FV::kLU) isfree = v && lane > wlast && !fv_is_used(f, sxw, syw);
@@ -1295,11 +1305,11 @@ __device__ __forceinline__ void d_sweep_frame(FV &f, const LsdConsts &c, const L
     PROF(0);
     int reg_size;
     if constexpr (FV::kLU) reg_size = d_region_grow_lu(f, sx, sy, c.prec, c.k_hi, c.k_lo, &reg_angle, &n_steps);
-    else reg_size = d_region_grow(f, sx, sy, c.prec, c.k_hi, c.k_lo, &reg_angle, &n_steps);
+    else reg_size = d_region_grow<FV, true>(f, sx, sy, c.prec, c.k_hi, c.k_lo, &reg_angle, &n_steps, rl64(wcs.x, L), rl64(wcs.y, L));
     PROF(1);
     LF_STAT(n_regpx += (u64)reg_size);
     if (reg_size < c.min_reg_size) continue;
-    if constexpr (FV::kLU) { if (reg_angle == -1e300) reg_angle = f.angles[sy * c.N + sx]; }   // a region of the seed alone that is kept (min_reg_size <= 1)
+    if (reg_angle == -1e300) reg_angle = f.angles[sy * c.N + sx];   // a region of the seed alone that is kept (min_reg_size <= 1)
     Rect rec;
     d_region2rect(f, reg_size, reg_angle, c.prec, c.p, 0, &rec);
     PROF(2);

@@ -135,15 +135,18 @@ def _one_wave_cases(fixtures_lsd):
     return cases
 
 
-@pytest.mark.parametrize("lu", ["0", "1"])
-def test_one_wavefront_sweeps_vs_oracle(built_lib, fixtures_lsd, monkeypatch, lu):
+SWEEP_MODES = {"plain": "0", "lu": "1"}      # LF_SWEEP_LU
+
+
+@pytest.mark.parametrize("mode", list(SWEEP_MODES))
+def test_one_wavefront_sweeps_vs_oracle(built_lib, fixtures_lsd, monkeypatch, mode):
     """The kernels behind large batches, forced on small ones (LF_SWEEP_WAVES=1): k_lsd_sweep (global `used`; the default) and,
     with LF_SWEEP_LU=1, k_lsd_sweep_lu -- `used` + NOTDEF as a bitmap in LDS, the seeds' (cos, sin) tiles staged in LDS by DMA one
     region ahead -- for scaled images of up to 512 x 384 (k_lsd_sweep above that).  Segments and region labels bit-equal to the oracle, on the reference's own test
     images, on flat / noise frames, on images smaller than a tile, and on a 1280 x 720 frame."""
     from lineslam_amd import capi, synth
     monkeypatch.setenv("LF_SWEEP_WAVES", "1")
-    monkeypatch.setenv("LF_SWEEP_LU", lu)
+    monkeypatch.setenv("LF_SWEEP_LU", SWEEP_MODES[mode])
     cases = _one_wave_cases(fixtures_lsd)
     big, _, _ = synth.sequence(1, seed=9, w=1280, h=720)
     cases.append((big[0], 22.5))                                                         # 1024 x 576 scaled: not the LDS variant
@@ -158,13 +161,13 @@ def test_one_wavefront_sweeps_vs_oracle(built_lib, fixtures_lsd, monkeypatch, lu
         ctx.close()
 
 
-@pytest.mark.parametrize("lu", ["0", "1"])
-def test_one_wavefront_sweep_on_a_batch(built_lib, monkeypatch, lu):
+@pytest.mark.parametrize("mode", list(SWEEP_MODES))
+def test_one_wavefront_sweep_on_a_batch(built_lib, monkeypatch, mode):
     """k_lsd_sweep / k_lsd_sweep_lu on 24 different frames of one launch (LU: every frame its own LDS bitmap and tile slots), launch-file angle"""
     import torch
     from lineslam_amd import capi, synth
     monkeypatch.setenv("LF_SWEEP_WAVES", "1")
-    monkeypatch.setenv("LF_SWEEP_LU", lu)
+    monkeypatch.setenv("LF_SWEEP_LU", SWEEP_MODES[mode])
     g, _, _ = synth.sequence(24, seed=21)
     P = capi.default_params(launch=True)
     ctx = capi.Context(640, 480, max_batch=24, params=P)
