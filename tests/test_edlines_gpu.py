@@ -79,3 +79,34 @@ def test_detect3d_with_edlines(built_lib):
         assert len(n0.lines) > 40
     finally:
         ctx.close()
+
+
+def test_segment_capacity_is_reported_not_cut(built_lib):
+    """more EDLines segments than the context's seg_cap: the getter reports LF_ERR_CAPACITY (the reference's vector is unbounded),
+    the rows that fit are the first seg_cap rows of the full result, and a second frame of the batch below the capacity is
+    unaffected (the ordered emit of the parallel line stage: k_ed_emit)"""
+    import torch
+    from lineslam_amd import capi
+    img = np.load(os.path.join(HERE, "golden", "edlines_fixture.npz"))["house"]
+    flat = np.full_like(img, 90)
+    caps = capi.default_caps()
+    caps.seg_cap = 64
+    ctx = capi.Context(400, 400, max_batch=2, params=capi.default_params(), caps=caps)
+    try:
+        dg = torch.from_numpy(np.stack([img, flat])).cuda()
+        ctx.edlines_batch_device(dg.data_ptr(), 2)
+        want = O.edlines_oracle(img, flavour="lf")
+        assert len(want) > 64
+        with pytest.raises(capi.LinefrontError) as e:
+            ctx.lsd_segments(0, cap=64)
+        assert e.value.status == capi.LF_ERR_CAPACITY
+        assert len(ctx.lsd_segments(1, cap=64)) == 0
+        # the rows that were written are the head of the full list, in order
+        import ctypes as C
+        segs = np.zeros((64, 5), np.float64)
+        n = C.c_int()
+        r = capi.lib().lf_lsd_get_segments(ctx._h, 0, segs.ctypes.data, 64, C.byref(n))
+        assert r == capi.LF_ERR_CAPACITY and n.value == len(want)
+        assert np.array_equal(segs[:, :4], want[:64])
+    finally:
+        ctx.close()
