@@ -200,6 +200,42 @@ def cpu_baseline(gray, depth, P, n_frames):
             "variants": variants}
 
 
+def lsd_support_agreement(ctx, gray, P, n):
+    """The integer line-pixel support (LSD region labels) and the segment doubles of the HIP path on the first n bench frames
+    against the REFERENCE'S OWN lsd.c run here on the host (oracle/_ref, built by oracle/Makefile): (i) liblsd_ref.so, the source
+    as is on the host glibc; (ii) liblsd_ref_crlibm.so, the same source with sin / cos / atan2 correctly rounded
+    (oracle/crlibm_quad.c) -- glibc >= 2.28 returns the neighbouring double for ~0.5 % of arguments, the HIP path rounds
+    region2rect's angle, cosine and sine correctly.  Untimed; test infrastructure used as the checker."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    from concurrent.futures import ThreadPoolExecutor
+    if O.ref_lsd_lib() is None:
+        return None
+    have_cr = O.ref_lsd_lib(True) is not None
+    n = min(n, len(gray))
+    gl = [ctx.lsd_labels(k).astype(np.int32) for k in range(n)]
+    gs = [ctx.lsd_segments(k) for k in range(n)]
+
+    def one(k):
+        r = []
+        for cr in ((False, True) if have_cr else (False,)):
+            s, l = O.lsd_reference(gray[k], P.lsd_angle_th, P.lsd_density_th, crlibm=cr)
+            r += [np.array_equal(l, gl[k]), len(s) == len(gs[k]), len(s) == len(gs[k]) and np.array_equal(s, gs[k])]
+        return r
+    with ThreadPoolExecutor(max(1, min(os.cpu_count() or 1, 64))) as ex:
+        r = np.array(list(ex.map(one, range(n))), bool)
+    out = {"frames": n, "reference": "external/lsd/lsd-1.5/lsd.c compiled as is (oracle/_ref/liblsd_ref.so), host glibc",
+           "frames_with_reference_identical_labels": int(r[:, 0].sum()), "frames_with_reference_identical_segment_count": int(r[:, 1].sum()),
+           "frames_with_reference_identical_segment_doubles": int(r[:, 2].sum()),
+           "frames_differing_in_labels": [int(k) for k in np.nonzero(~r[:, 0])[0][:32]]}
+    if have_cr:
+        out["under_correctly_rounded_sin_cos_atan2"] = {
+            "reference": "the same lsd.c, sin / cos / atan2 bound to oracle/crlibm_quad.c (oracle/_ref/liblsd_ref_crlibm.so)",
+            "frames_with_reference_identical_labels": int(r[:, 3].sum()), "frames_with_reference_identical_segment_count": int(r[:, 4].sum()),
+            "frames_with_reference_identical_segment_doubles": int(r[:, 5].sum())}
+    return out
+
+
 def launch_plan(gpus, env, device_count):
     """What `--gpus N` means for THIS process (the driver's contract: N ranks, one per GPU, of ONE node):
       ("run", world)      this process is one of N ranks (N == 1, or torch.distributed.run / torchrun set WORLD_SIZE == N)
@@ -749,6 +785,11 @@ def main():
                 # of the difference is libm, and whether the GPU adds anything to it
                 out["quality"]["cpu_lf_flavour_vs_cpu_reference_port"] = pose_agreement(cpu_baseline.sets_lf, cpu_baseline.sets_ref)
                 out["quality"]["pair_pose_vs_cpu_lf_flavour"] = pose_agreement(gpu_sets, cpu_baseline.sets_lf)
+            if not strong and not dist_on:
+                try:
+                    out["quality"]["lsd_support_vs_reference_code"] = lsd_support_agreement(ctx, gray, P, ncpu)
+                except Exception as e:       # the checker must never cost the line
+                    out["quality"]["lsd_support_vs_reference_code"] = {"error": repr(e)}
     for c in ctxs:
         c.close()
     if rank == 0 and world == 1 and not dist_on and not a.no_config4 and not a.points and a.detector == "lsd" and not strong:

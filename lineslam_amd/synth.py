@@ -247,6 +247,19 @@ def sequence(n_frames, seed=0, fps=30.0, w=640, h=480, n_unique=None, workers=No
     return gray, depth, poses
 
 
+def sequence_frame(i, seed=0, n_unique=None, fps=30.0, w=640, h=480):
+    """Frame i of sequence(n, seed, n_unique=n_unique) on its own (gray, depth, pose), bit for bit, for any n > i with
+    n_unique < n (tests that need a few named frames of the bench batch without ray-casting all of it)."""
+    if n_unique is None:
+        return _full_frame((seed, i, fps, w, h))
+    j = i % (2 * n_unique - 2) if n_unique > 1 else 0
+    if j >= n_unique:
+        j = 2 * n_unique - 2 - j
+    g, d, T = _clean_frame((seed, j, fps, w, h))
+    gi, di = _noisy_frame(g, d, seed, i)
+    return gi, di, T
+
+
 def keypoints(depth, poses, n_own=320, seed=0, K=K_TUM):
     """Synthetic stand-in for the ORB side of BASELINE config 3 (the extractor itself is outside the accelerated path):
     every frame k owns n_own scene points (pixels with depth, back-projected); its key-point list is

@@ -347,6 +347,15 @@ static double o_rect_nfa(octx *c, const orect *r, double logNT) {
   return o_nfa(pts, alg, r->p, logNT);
 }
 
+/* Optional trace of the three libm calls of region2rect / get_theta (the only place where LSD's output depends on
+ * libm's last bit): rows of 6 doubles {atan2 y, atan2 x, atan2 result, theta after the +pi flip, cos, sin}.
+ * tests/test_oracle_lsd.py compares them with correctly rounded values to name the calls the host libm misrounds.
+ * Not thread-safe; NULL (the default) = off. */
+static double *g_theta_trace = 0;
+static int g_theta_trace_cap = 0, g_theta_trace_n = 0;
+void oracle_lsd_theta_trace(double *buf, int cap) { g_theta_trace = buf; g_theta_trace_cap = cap; g_theta_trace_n = 0; }
+int oracle_lsd_theta_trace_count(void) { return g_theta_trace_n; }
+
 /* lsd.cpp:1474-1512 get_theta */
 #ifdef ORACLE_LFMATH
 typedef struct { double th, t0; int flipped; lf_dd s0, c0; } o_theta_aux;
@@ -374,6 +383,12 @@ static double o_get_theta(const octx *c, int reg_size, double x, double y, doubl
 #else
   (void)aux;
   theta = fabs(Ixx) > fabs(Iyy) ? atan2(lambda - Ixx, Ixy) : atan2(Ixy, lambda - Iyy);
+  if (g_theta_trace && g_theta_trace_n < g_theta_trace_cap) {
+    double *t = g_theta_trace + 6 * g_theta_trace_n;
+    t[0] = fabs(Ixx) > fabs(Iyy) ? lambda - Ixx : Ixy;
+    t[1] = fabs(Ixx) > fabs(Iyy) ? Ixy : lambda - Iyy;
+    t[2] = theta;
+  }
   if (o_angle_diff(theta, reg_angle) > prec) theta += O_PI;
 #endif
   return theta;
@@ -400,6 +415,10 @@ static void o_region2rect(const octx *c, int reg_size, double reg_angle, double 
 #else
   dx = cos(theta);
   dy = sin(theta);
+  if (g_theta_trace && g_theta_trace_n < g_theta_trace_cap) {
+    double *t = g_theta_trace + 6 * g_theta_trace_n++;
+    t[3] = theta; t[4] = dx; t[5] = dy;
+  }
 #endif
   l_min = l_max = w_min = w_max = 0.0;
   for (i = 0; i < reg_size; i++) {

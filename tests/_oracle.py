@@ -38,6 +38,9 @@ def oracle_lib(flavour="ref"):
                                    dp, dp, dp, ip, C.POINTER(C.c_int), C.POINTER(C.c_long)]
         lib.oracle_log_gamma.restype = C.c_double
         lib.oracle_log_gamma.argtypes = [C.c_double]
+        lib.oracle_lsd_theta_trace.restype = None
+        lib.oracle_lsd_theta_trace.argtypes = [dp, C.c_int]
+        lib.oracle_lsd_theta_trace_count.restype = C.c_int
         _libs[flavour] = lib
     return _libs[flavour]
 
@@ -99,26 +102,48 @@ class _NTuple(C.Structure):
                 ("values", C.POINTER(C.c_double))]
 
 
-def ref_lsd_lib():
-    path = os.path.join(ODIR, "_ref", "liblsd_ref.so")
+def ref_lsd_lib(crlibm=False):
+    """crlibm=False: the reference's lsd.c on the host glibc (the pin).  crlibm=True: the DIAGNOSTIC build of the same
+    untouched lsd.c with sin / cos / atan2 correctly rounded (oracle/crlibm_quad.c; see oracle/Makefile)."""
+    key = "reflsd_cr" if crlibm else "reflsd"
+    path = os.path.join(ODIR, "_ref", "liblsd_ref_crlibm.so" if crlibm else "liblsd_ref.so")
     if not os.path.exists(path):
         return None
-    if "reflsd" not in _libs:
+    if key not in _libs:
         lib = C.CDLL(path)
         lib.LineSegmentDetection.restype = C.POINTER(_NTuple)
         lib.LineSegmentDetection.argtypes = [C.POINTER(_ImageDouble), C.c_double, C.c_double,
                                              C.c_double, C.c_double, C.c_double, C.c_double,
                                              C.c_int, C.c_double,
                                              C.POINTER(C.POINTER(_ImageInt))]
-        _libs["reflsd"] = lib
-    return _libs["reflsd"]
+        if crlibm:
+            for f in ("oracle_cr_sin", "oracle_cr_cos", "oracle_cr_atan2"):
+                getattr(lib, f).restype = C.c_double
+                getattr(lib, f).argtypes = [C.c_double] * (2 if f.endswith("atan2") else 1)
+        _libs[key] = lib
+    return _libs[key]
 
 
-def lsd_reference(gray_u8, ang_th=22.5, density_th=0.7, scale=0.8):
+def lsd_theta_trace(gray_u8, ang_th=22.5, density_th=0.7):
+    """The libm calls of region2rect / get_theta as the `ref` flavour (host libm) makes them on this image:
+    rows {atan2 y, atan2 x, atan2 result, theta, cos(theta), sin(theta)}.  Not thread-safe."""
+    lib = oracle_lib("ref")
+    buf = np.zeros((65536, 6), np.float64)
+    lib.oracle_lsd_theta_trace(_dp(buf), len(buf))
+    try:
+        lsd_oracle(gray_u8, ang_th, density_th, flavour="ref")
+        lib.oracle_lsd_theta_trace_count.restype = C.c_int
+        n = lib.oracle_lsd_theta_trace_count()
+    finally:
+        lib.oracle_lsd_theta_trace(None, 0)
+    return buf[:n].copy()
+
+
+def lsd_reference(gray_u8, ang_th=22.5, density_th=0.7, scale=0.8, crlibm=False):
     """The reference's LineSegmentDetection (external/lsd/lsd-1.5/lsd.c compiled as-is) with the
     fixed parameters of lsd_scale() (lsd.cpp:2070-2090) and the u8->double copy of callLsd."""
-    lib = ref_lsd_lib()
-    assert lib is not None, "oracle/_ref/liblsd_ref.so not built (needs /root/reference)"
+    lib = ref_lsd_lib(crlibm)
+    assert lib is not None, "oracle/_ref/liblsd_ref%s.so not built (needs /root/reference)" % ("_crlibm" if crlibm else "")
     g = np.ascontiguousarray(gray_u8, dtype=np.uint8)
     h, w = g.shape
     img = g.astype(np.float64)

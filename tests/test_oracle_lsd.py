@@ -58,6 +58,53 @@ def test_lfmath_flavour_equals_the_reference(fixtures_lsd, name, ang):
     assert (d == 0).sum() >= len(d) - 1 and d.max() < 2e-15
 
 
+# Frames of the bench batch (synth.sequence(1147, seed=2, n_unique=256), launch parameters).  309 and 311 are the two of
+# the 1147 whose region labels differ between the HIP path and the reference on glibc 2.35 (tests/test_fullsize_gpu.py).
+BENCH_FRAMES = [0, 1, 128, 309, 311, 700, 1146]
+
+
+def _bench_frame(k):
+    from lineslam_amd import synth
+    return synth.sequence_frame(k, seed=2, n_unique=256)[0]
+
+
+@pytest.mark.parametrize("k", BENCH_FRAMES)
+def test_bench_frames_against_the_reference_itself(k):
+    """(i) the `ref` flavour IS the reference's lsd.c on bench frames too (labels and segment doubles);
+    (ii) the `lf` flavour (= the HIP kernels, bit for bit) IS the reference's lsd.c once that code's sin / cos / atan2 are
+    correctly rounded (the diagnostic build liblsd_ref_crlibm.so: the untouched source, three libm symbols rebound) --
+    labels AND segment doubles, so nothing but the host libm's rounding of those three functions separates the HIP path
+    from the reference;
+    (iii) where the two builds of the reference disagree, the disagreement is traced to named calls in region2rect /
+    get_theta (lsd.cpp:1474-1604) that the host glibc misrounds: for each one the correctly rounded value is the double
+    nearest to the exact value (mpmath, 240 bits), glibc's is its neighbour."""
+    if O.ref_lsd_lib() is None or O.ref_lsd_lib(True) is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    from lineslam_amd import capi
+    P = capi.default_params(launch=True)
+    g = _bench_frame(k)
+    s_ref, l_ref = O.lsd_oracle(g, P.lsd_angle_th, P.lsd_density_th, flavour="ref")
+    s_lf, l_lf = O.lsd_oracle(g, P.lsd_angle_th, P.lsd_density_th, flavour="lf")
+    s_gl, l_gl = O.lsd_reference(g, P.lsd_angle_th, P.lsd_density_th)
+    s_cr, l_cr = O.lsd_reference(g, P.lsd_angle_th, P.lsd_density_th, crlibm=True)
+    assert np.array_equal(l_ref, l_gl) and np.array_equal(s_ref, s_gl)          # (i)
+    assert np.array_equal(l_lf, l_cr) and np.array_equal(s_lf, s_cr)            # (ii)
+    tr = O.lsd_theta_trace(g, P.lsd_angle_th, P.lsd_density_th)                 # (iii)
+    cr = O.ref_lsd_lib(True)
+    bad = []
+    for y, x, at, th, c, s in tr:
+        for name, got, want in (("atan2", at, cr.oracle_cr_atan2(y, x)), ("cos", c, cr.oracle_cr_cos(th)), ("sin", s, cr.oracle_cr_sin(th))):
+            if got != want:
+                mp = pytest.importorskip("mpmath")
+                mp.mp.prec = 240
+                ex = {"atan2": lambda: mp.atan2(mp.mpf(y), mp.mpf(x)), "cos": lambda: mp.cos(mp.mpf(th)), "sin": lambda: mp.sin(mp.mpf(th))}[name]()
+                assert abs(mp.mpf(want) - ex) < abs(mp.mpf(got) - ex), (name, got, want, ex)         # glibc is the misrounded one
+                assert abs(got - want) <= np.spacing(abs(want)) * 1.0000001                          # ... by one ulp
+                bad.append(name)
+    if not np.array_equal(l_gl, l_cr) or not np.array_equal(s_gl, s_cr):
+        assert bad, "the two builds of the reference differ without a misrounded libm call"
+
+
 def test_seed_order_and_stats(fixtures_lsd):
     segs, labels, dbg = O.lsd_oracle(fixtures_lsd["tum"], 40.0, flavour="ref", debug=True)
     seeds = dbg["seeds"]
