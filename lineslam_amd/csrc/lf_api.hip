@@ -395,14 +395,13 @@ static int alloc_lsd(lf_ctx *c) {
   memset(&fb, 0, sizeof fb);
   fc.W = c->W; fc.H = c->H;
   fc.cand_cap = lc.seg_cap; fc.line_cap = c->caps.line_cap; fc.seg_cap = lc.seg_cap;   // every LSD segment is examined
-  fc.pts_slots = 2 * fc.line_cap < fc.cand_cap ? 2 * fc.line_cap : fc.cand_cap;     // one per long segment (k_cand_slots), twice the lines a frame may keep
+  fc.pts_rows = 0;
   ALLOC(c, fb.gxy, B * (size_t)c->W * c->H * 2);
   ALLOC(c, c->d_frame_ids, B);
   ALLOC(c, fb.cand_flag, B * fc.cand_cap);
   ALLOC(c, fb.cand_out, B * (size_t)fc.cand_cap * LF_CAND_STRIDE);
-  ALLOC(c, fb.pts, B * (size_t)fc.pts_slots * LF_MAX_SAMPLES * 3);
-  ALLOC(c, fb.pts_cnt, B);
-  ALLOC(c, fb.cand_slot, B * (size_t)fc.cand_cap);
+  ALLOC(c, fb.cand_mask, B * (size_t)fc.cand_cap * 2);
+  ALLOC(c, fb.pts, (size_t)fc.line_cap * LF_MAX_SAMPLES * 3);      // lf_mle_lines' staging only
   ALLOC(c, fb.recs, B * (size_t)fc.line_cap);
   ALLOC(c, fb.nlines, B);
   ALLOC(c, fb.mle_list, B * 3 * (size_t)fc.line_cap);
@@ -1421,7 +1420,7 @@ int lf_mle_lines(lf_ctx *c, const double *pts, const int32_t *pt_offset, const i
   const int L = c->fc.line_cap;
   std::vector<double> hp((size_t)n_lines * LF_MAX_SAMPLES * 3, 0.0), ho((size_t)n_lines * LF_CAND_STRIDE, 0.0);
   std::vector<lf_line_record> hr((size_t)n_lines);
-  std::vector<int> hslot((size_t)n_lines), hlist((size_t)3 * L, 0);
+  std::vector<int> hlist((size_t)3 * L, 0);
   int cnt[3] = {0, 0, 0};
   memset(hr.data(), 0, sizeof(lf_line_record) * (size_t)n_lines);
   for (int i = 0; i < n_lines; i++) {
@@ -1429,17 +1428,17 @@ int lf_mle_lines(lf_ctx *c, const double *pts, const int32_t *pt_offset, const i
     for (int k = 0; k < 6; k++) ho[(size_t)i * LF_CAND_STRIDE + k] = AB_init[6 * (size_t)i + k];
     ho[(size_t)i * LF_CAND_STRIDE + 26] = (double)npts[i];
     hr[i].lid = i; hr[i].seg = i;
-    hslot[i] = i;
     const int which = npts[i] <= 32 ? 1 : 2;          // the work lists of k_records
     hlist[(size_t)which * L + cnt[which]++] = i;
   }
   HIPCHK(c, hipMemcpyAsync(c->fb.pts, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fb.cand_out, ho.data(), ho.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->fb.cand_slot, hslot.data(), hslot.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fb.recs, hr.data(), hr.size() * sizeof(lf_line_record), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fb.mle_list, hlist.data(), hlist.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->fb.mle_cnt, cnt, sizeof cnt, hipMemcpyHostToDevice, c->stream));
-  lf_front_launch_mle(c->fc, c->fb, 1, c->stream);
+  FrontConsts fcm = c->fc;
+  fcm.pts_rows = 1;                                   // candidate i == line i == row block i of fb.pts
+  lf_front_launch_mle(fcm, c->fb, 1, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(out, c->fb.recs, sizeof(lf_line_record) * (size_t)n_lines, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(ho.data(), c->fb.cand_out, ho.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));

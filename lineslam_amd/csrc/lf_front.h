@@ -18,7 +18,8 @@ struct FrontConsts {
   int cand_cap;      // candidates (LSD segments) examined per frame (= seg_cap: every segment LSD reports is examined)
   int line_cap;      // records per frame
   int seg_cap;       // row capacity of the LSD segment output
-  int pts_slots;     // support-point slots per frame (one per 3D line; >= line_cap)
+  int pts_rows;      // 0: k_mle re-derives a line's supporting points from its segment and inlier mask (the batch path);
+                     // 1: lf_mle_lines -- the caller's points, row block i of `pts` belongs to candidate i
 };
 
 struct FrontBuffers {
@@ -30,10 +31,9 @@ struct FrontBuffers {
   const uint64_t *frame_ids; // [B]  keys of the counter-based generator
   int *cand_flag;            // [B][cand_cap]: 0 short, 1 no depth, 2 3D line
   double *cand_out;          // [B][cand_cap][LF_CAND_STRIDE]
-  double *pts;               // [B][pts_slots][LF_MAX_SAMPLES*3] supporting points of each RANSAC line, in slots handed out
-  int *pts_cnt;              // [B]  by an atomic counter per frame (zeroed by lf_front_launch);
-  int *cand_slot;            // [B][cand_cap] slot of a candidate's points, -1 if the frame ran out of slots (then it also
-                             //   has more than line_cap lines: lf_frame_get_lines reports LF_ERR_CAPACITY)
+  unsigned long long *cand_mask;       // [B][cand_cap][2] RANSAC inliers of a 3D line as a mask over the candidate's valid depth samples
+                             //   (bit i = valid sample i, in sample order): with the segment it IS the list of supporting points
+  double *pts;               // [line_cap][LF_MAX_SAMPLES*3] lf_mle_lines only (pts_rows = 1): the caller's supporting points
   lf_line_record *recs;      // [B][line_cap]
   int *nlines;               // [B]  (may exceed line_cap: overflow)
   int *mle_list;             // [B][3][line_cap] line ids for the MLE stage by #support points: <= 16, 17..32, more

@@ -286,29 +286,32 @@ __device__ __forceinline__ void f_jac_line(const double *pos, const double *M, c
   }
 }
 
-// Support-point slots of the frame's candidates: segment s gets the slot of its rank among the segments that pass the length
-// filter (lineslam.cpp:218) -- every one of them may become a 3D line -- or -1 beyond pts_slots (= 2 line_cap; k_records reports
-// the frame as over capacity if a kept line is left without one).  One wavefront per frame; deterministic, unlike a counter
-// bumped in completion order.
-__global__ void __launch_bounds__(64) k_cand_slots(FrontConsts c, FrontBuffers b) {
-  const int f = blockIdx.x, lane = f_lane();
-  int nseg = b.nsegs[f];
-  if (nseg > c.seg_cap) nseg = c.seg_cap;
-  if (nseg > c.cand_cap) nseg = c.cand_cap;
-  int base = 0;
-  for (int s0 = 0; s0 < c.cand_cap; s0 += 64) {
-    const int s = s0 + lane;
-    bool lng = false;
-    if (s < nseg) {
-      const double *sg = b.segs + ((size_t)f * c.seg_cap + s) * 5;
-      const double pa = sg[0], pb = sg[1], qc = sg[2], qd = sg[3];
-      lng = lf_sqrt((pa - qc) * (pa - qc) + (pb - qd) * (pb - qd)) > c.P.line_segment_len_thresh;
-    }
-    const u64 m = __ballot(lng);
-    const int rank = base + __popcll(m & f_lt());
-    if (s < c.cand_cap) b.cand_slot[(size_t)f * c.cand_cap + s] = (lng && rank < c.pts_slots) ? rank : -1;
-    base += __popcll(m);
-  }
+// Sample j of a 2D segment (pa, pb) - (qc, qd) back-projected with the depth map (lineslam.cpp:252-288): false if the sample
+// lies outside the image or has no depth.  Used by k_line3d (all samples of a candidate) and again by k_mle, which re-derives the
+// supporting points of a kept line from the segment and the 128-bit inlier mask k_line3d leaves behind -- the same operations
+// on the same operands, so the same doubles -- instead of reading them from a per-frame pool of point slots (rounds 3-4:
+// 2.5 KB per slot, 2 x line_cap slots per frame, and a frame could run out of them).
+__device__ __forceinline__ bool f_sample_point(const FrontConsts &c, const FrontBuffers &b, const float *depth, double pa, double pb,
+                                               double qc, double qd, double numSmp, int j, double *X, double *Y, double *Z) {
+  if (!((double)j <= numSmp && j < LF_MAX_SAMPLES)) return false;
+  double ptx = pa * (1 - j / numSmp) + qc * (j / numSmp);
+  double pty = pb * (1 - j / numSmp) + qd * (j / numSmp);
+  if (ptx < 0 || pty < 0 || ptx >= c.W || pty >= c.H) return false;
+  int row, col;
+  if ((__builtin_floor(ptx) == ptx) && (__builtin_floor(pty) == pty)) {
+    col = (int)(ptx - 1); if (col < 0) col = 0;
+    row = (int)(pty - 1); if (row < 0) row = 0;
+  } else { col = (int)ptx; row = (int)pty; }
+  float dv = depth[(size_t)row * b.depth_row_stride + col];
+  double depval = (double)dv, zval = -1;
+  if (depval < F_EPS || dv != dv) { } else zval = depval / c.P.depth_scaling;
+  if (!(zval > 0)) return false;
+  double x = c.Kinv[0] * ptx + c.Kinv[1] * pty + c.Kinv[2] * 1.0;
+  double y = c.Kinv[3] * ptx + c.Kinv[4] * pty + c.Kinv[5] * 1.0;
+  double z = c.Kinv[6] * ptx + c.Kinv[7] * pty + c.Kinv[8] * 1.0;
+  x = x / z; y = y / z;
+  *X = x * zval; *Y = y * zval; *Z = zval;
+  return true;
 }
 
 __global__ void __launch_bounds__(64) k_line3d(FrontConsts c, FrontBuffers b) {
@@ -336,30 +339,8 @@ __global__ void __launch_bounds__(64) k_line3d(FrontConsts c, FrontBuffers b) {
   int np = 0;
   for (int h = 0; h < 2; h++) {
     int j = lane + 64 * h;
-    bool ok = false;
     double X = 0, Y = 0, Z = 0;
-    if ((double)j <= numSmp && j < LF_MAX_SAMPLES) {
-      double ptx = pa * (1 - j / numSmp) + qc * (j / numSmp);
-      double pty = pb * (1 - j / numSmp) + qd * (j / numSmp);
-      if (!(ptx < 0 || pty < 0 || ptx >= c.W || pty >= c.H)) {
-        int row, col;
-        if ((__builtin_floor(ptx) == ptx) && (__builtin_floor(pty) == pty)) {
-          col = (int)(ptx - 1); if (col < 0) col = 0;
-          row = (int)(pty - 1); if (row < 0) row = 0;
-        } else { col = (int)ptx; row = (int)pty; }
-        float dv = depth[(size_t)row * b.depth_row_stride + col];
-        double depval = (double)dv, zval = -1;
-        if (depval < F_EPS || dv != dv) { } else zval = depval / P.depth_scaling;
-        if (zval > 0) {
-          double x = c.Kinv[0] * ptx + c.Kinv[1] * pty + c.Kinv[2] * 1.0;
-          double y = c.Kinv[3] * ptx + c.Kinv[4] * pty + c.Kinv[5] * 1.0;
-          double z = c.Kinv[6] * ptx + c.Kinv[7] * pty + c.Kinv[8] * 1.0;
-          x = x / z; y = y / z;
-          X = x * zval; Y = y * zval; Z = zval;
-          ok = true;
-        }
-      }
-    }
+    const bool ok = f_sample_point(c, b, depth, pa, pb, qc, qd, numSmp, j, &X, &Y, &Z);
     u64 mk = __ballot(ok);
     if (ok) {
       int pos = np + __popcll(mk & f_lt());
@@ -456,17 +437,9 @@ __global__ void __launch_bounds__(64) k_line3d(FrontConsts c, FrontBuffers b) {
   bool have = (nbest / numSmp > P.ratio_of_collinear_pts) &&
               (lf_sqrt((LA[0] - LB[0]) * (LA[0] - LB[0]) + (LA[1] - LB[1]) * (LA[1] - LB[1]) + (LA[2] - LB[2]) * (LA[2] - LB[2])) > P.line3d_length_thresh);
   if (!have) { if (lane == 0) *flag = 1; return; }                                          // lineslam.cpp:302-307
-  // ---- hand the supporting points (line.pts, in list order) to the MLE kernel: the slot was fixed by k_cand_slots (rank of the
-  // segment among the frame's long segments -- independent of the order in which the wavefronts of this kernel finish)
-  {
-    const int slot = b.cand_slot[(size_t)f * c.cand_cap + cand];
-    if (slot >= 0) {
-      double *pts = b.pts + ((size_t)f * c.pts_slots + slot) * (LF_MAX_SAMPLES * 3);
-      bool in0 = (best0 >> lane) & 1ull, in1 = (best1 >> lane) & 1ull;
-      if (in0) { int r = __popcll(best0 & f_lt()); for (int k = 0; k < 3; k++) pts[3 * r + k] = S.pos[3 * lane + k]; }
-      if (in1) { int r = __popcll(best0) + __popcll(best1 & f_lt()); for (int k = 0; k < 3; k++) pts[3 * r + k] = S.pos[3 * (lane + 64) + k]; }
-    }
-  }
+  // ---- hand the supporting points (line.pts, in list order) to the MLE kernel: as the inlier mask over the candidate's valid
+  // samples (bit i of word i / 64 = valid sample i); k_mle re-derives the points from the segment with f_sample_point
+  if (lane == 0) { u64 *mk = b.cand_mask + ((size_t)f * c.cand_cap + cand) * 2; mk[0] = best0; mk[1] = best1; }
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < 3; k++) { out[k] = LA[k]; out[3 + k] = LB[k]; }
@@ -484,13 +457,11 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
   lf_line_record *recs = b.recs + (size_t)f * c.line_cap;
   int *list0 = b.mle_list + (size_t)f * 3 * c.line_cap, *list1 = list0 + c.line_cap, *list2 = list1 + c.line_cap;
   int base = 0, n0 = 0, n1 = 0, n2 = 0;
-  bool noslot = false;
   for (int s0 = 0; s0 < nseg; s0 += 64) {
     int s = s0 + lane;
     bool have = s < nseg && flag[s] == 2;
     u64 m = __ballot(have);
     int lid = base + __popcll(m & f_lt());
-    if (__ballot(have && lid < c.line_cap && b.cand_slot[(size_t)f * c.cand_cap + s] < 0) != 0ull) noslot = true;
     {   // MLE work lists by number of RANSAC support points: <= 16, 17..32, more
       bool kept = have && lid < c.line_cap;
       int nsup = kept ? (int)b.cand_out[((size_t)f * c.cand_cap + s) * LF_CAND_STRIDE + 26] : 0;
@@ -522,9 +493,7 @@ __global__ void __launch_bounds__(64) k_records(FrontConsts c, FrontBuffers b) {
     base += __popcll(m);
   }
   if (lane == 0) {
-    // (a kept line without a support-point slot -- more than pts_slots long segments in front of it -- has no refined end
-    // points: the frame is reported as over capacity, like one with more than line_cap lines)
-    b.nlines[f] = (noslot && base <= c.line_cap) ? c.line_cap + 1 : base;
+    b.nlines[f] = base;        // (may exceed line_cap: the frame is over capacity, the first line_cap records are complete)
     b.mle_cnt[3 * f] = n0; b.mle_cnt[3 * f + 1] = n1; b.mle_cnt[3 * f + 2] = n2;
   }
 }
@@ -967,18 +936,39 @@ __device__ __forceinline__ void f_mle_line(const FrontConsts &c, const FrontBuff
   lf_line_record *R = b.recs + (size_t)f * c.line_cap + lid;
   const int seg = R->seg;
   double *out = b.cand_out + ((size_t)f * c.cand_cap + seg) * LF_CAND_STRIDE;
-  const int pslot = b.cand_slot[(size_t)f * c.cand_cap + seg];
-  if (pslot < 0) return;                     // no support points were kept (frame over capacity, reported by the getters)
-  const double *pts = b.pts + ((size_t)f * c.pts_slots + pslot) * (LF_MAX_SAMPLES * 3);
   int ns = (int)out[26];
   if (ns > Cfg::ROWS) ns = Cfg::ROWS;
   double LA[3] = {out[0], out[1], out[2]}, LB[3] = {out[3], out[4], out[5]};
+  if (c.pts_rows) {            // lf_mle_lines: the caller's supporting points, row block `seg` of b.pts
+    const double *pts = b.pts + (size_t)seg * (LF_MAX_SAMPLES * 3);
+    for (int i = lane; i < ns; i += G)
+#pragma unroll
+      for (int k = 0; k < 3; k++) S.pos[3 * i + k] = pts[3 * i + k];
+  } else {                     // the inliers of k_line3d's RANSAC, in sample order: valid samples are numbered as they come, the mask picks
+    const double *sg = b.segs + ((size_t)f * c.seg_cap + seg) * 5;
+    const double pa = sg[0], pb = sg[1], qc = sg[2], qd = sg[3], numSmp = out[24];
+    const float *depth = b.depth + (size_t)f * b.depth_frame_stride;
+    const u64 *mk = b.cand_mask + ((size_t)f * c.cand_cap + seg) * 2;
+    const u64 m0 = mk[0], m1 = mk[1];
+    const u64 gmask = (G == 64) ? ~0ull : (((1ull << (G & 63)) - 1ull) << g.gbase), glt = (1ull << lane) - 1ull;
+    int nvalid = 0, nrow = 0;
+    for (int j0 = 0; (double)j0 <= numSmp && j0 < LF_MAX_SAMPLES; j0 += G) {
+      double X = 0, Y = 0, Z = 0;
+      const bool ok = f_sample_point(c, b, depth, pa, pb, qc, qd, numSmp, j0 + lane, &X, &Y, &Z);
+      const u64 mv = (__ballot(ok) & gmask) >> g.gbase;
+      const int vi = nvalid + __popcll(mv & glt);
+      const bool in = ok && (((vi < 64 ? m0 >> vi : m1 >> (vi - 64)) & 1ull) != 0ull);
+      const u64 mi = (__ballot(in) & gmask) >> g.gbase;
+      const int row = nrow + __popcll(mi & glt);
+      if (in && row < ns) { S.pos[3 * row] = X; S.pos[3 * row + 1] = Y; S.pos[3 * row + 2] = Z; }
+      nvalid += __popcll(mv); nrow += __popcll(mi);
+    }
+  }
+  g_order<G>();
   for (int i = lane; i < ns; i += G) {
-    double pos[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, cov[9], DU[9], Wsq[3];
+    double pos[3] = {S.pos[3 * i], S.pos[3 * i + 1], S.pos[3 * i + 2]}, cov[9], DU[9], Wsq[3];
     f_pt_cov(pos, c.K[0], P, cov);
     f_whiten(cov, DU, Wsq);
-#pragma unroll
-    for (int k = 0; k < 3; k++) S.pos[3 * i + k] = pos[k];
 #pragma unroll
     for (int k = 0; k < 9; k++) S.DU[9 * i + k] = DU[k];
   }
@@ -1314,7 +1304,6 @@ static void launch_mle_kernels(const FrontConsts &c, const FrontBuffers &b, int 
 }
 void lf_front_launch_mle(const FrontConsts &c, const FrontBuffers &b, int B, hipStream_t st) { launch_mle_kernels(c, b, B, st); }
 void lf_front_launch(const FrontConsts &c, const FrontBuffers &b, int B, hipStream_t st) {
-  hipLaunchKernelGGL(k_cand_slots, dim3(B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_sobel5, dim3((c.W + 255) / 256, (c.H + SOBEL_ROWS - 1) / SOBEL_ROWS, B), dim3(256), 0, st, c, b);
   hipLaunchKernelGGL(k_line3d, dim3(c.cand_cap, B), dim3(64), 0, st, c, b);
   hipLaunchKernelGGL(k_records, dim3(B), dim3(64), 0, st, c, b);

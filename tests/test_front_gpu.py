@@ -76,3 +76,25 @@ def test_detect3d_no_depth_and_flat(built_lib, frames):
     assert len(ctx.detect3d(g[0], np.full_like(d[0], np.nan), synth.K_TUM)) == 0
     assert len(ctx.detect3d(np.full_like(g[0], 77), d[0], synth.K_TUM)) == 0
     ctx.close()
+
+
+def test_many_long_segments_few_lines(built_lib, frames):
+    """A frame whose long 2D segments outnumber 2 x line_cap while its 3D lines fit line_cap (most of the depth map missing).
+    Rounds 3-4 handed the supporting points over through 2 x line_cap point slots per frame and reported such a frame as over
+    capacity (with stale records behind the kept ones); the points are now re-derived in k_mle from segment + inlier mask, so
+    there is nothing to run out of: the frame is complete and equals the oracle."""
+    from lineslam_amd import capi
+    g, d = frames
+    dd = d[0].copy()
+    dd[:, 140:] = np.nan                                   # depth only on the left fifth: few segments become 3D lines
+    P = capi.default_params(launch=True)
+    so, _ = O.lsd_oracle(g[0], P.lsd_angle_th, flavour="lf")
+    n_long = int((np.hypot(so[:, 0] - so[:, 2], so[:, 1] - so[:, 3]) > P.line_segment_len_thresh).sum())
+    recs_o, _, _ = O.detect3d_oracle(g[0], dd, synth.K_TUM, P, 3, so)
+    caps = capi.default_caps()
+    caps.line_cap = max(len(recs_o) + 2, 16)
+    assert 2 * caps.line_cap < n_long and 0 < len(recs_o) <= caps.line_cap, (n_long, len(recs_o))
+    ctx = capi.Context(640, 480, max_batch=1, params=P, caps=caps)
+    recs = ctx.detect3d(g[0], dd, synth.K_TUM, frame_id=3)              # (raises on LF_ERR_CAPACITY)
+    assert len(recs) == len(recs_o) and recs.tobytes() == recs_o.tobytes()
+    ctx.close()
