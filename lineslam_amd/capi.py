@@ -10,6 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblinefront.so")
+if os.environ.get("LF_LIB"):      # A/B experiments only (tools/exp/ab.sh): another build of the same library
+    LIB_PATH = os.path.abspath(os.environ["LF_LIB"])
 
 LF_OK, LF_ERR_INVALID, LF_ERR_NO_DEVICE, LF_ERR_HIP, LF_ERR_CAPACITY, LF_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 
