@@ -489,6 +489,9 @@ LF_API int lf_comm_unique_id(uint8_t id[LF_COMM_ID_BYTES]);
 LF_API int lf_comm_init(lf_ctx *ctx, int world_size, int rank, const uint8_t id[LF_COMM_ID_BYTES], int max_keyframes);
 LF_API int lf_comm_attach(lf_ctx *ctx, lf_ctx *owner);     /* share owner's communicator (same device, same process) */
 LF_API int lf_comm_destroy(lf_ctx *ctx);
+/* What the communicator itself reports (ncclCommCount / ncclCommUserRank) and how many ncclAllGather calls this context has
+ * issued: lets a multi-rank run show that the exchange went through RCCL with the rank count it was launched with. */
+LF_API int lf_comm_info(lf_ctx *ctx, int *n_ranks, int *rank, long long *n_allgathers);
 /* The exchange of key-frame line maps: the n_kf frame slots kf_slots[] (HOST array) of this context's last batch are
  * packed -- per key frame one header row (line count, node id + id_offset) followed by line_cap lf_line_record rows, all
  * 1040-byte rows -- and gathered from every rank with ONE ncclAllGather on the context stream.  The result is the map

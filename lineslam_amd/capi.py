@@ -123,6 +123,7 @@ SYMBOLS = {
     "lf_comm_init": (_i, [_vp, _i, _i, _vp, _i]),
     "lf_comm_attach": (_i, [_vp, _vp]),
     "lf_comm_destroy": (_i, [_vp]),
+    "lf_comm_info": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "lf_allgather_keyframes": (_i, [_vp, _vp, _i, C.c_uint64, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _pi, _pi]),
     "lf_line_matching_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, C.c_uint64, _i, _vp, _vp, _vp, _i, _pi]),
 }
@@ -618,6 +619,12 @@ class Context:
 
     def comm_attach(self, owner):
         self._chk(lib().lf_comm_attach(self._h, owner._h), "lf_comm_attach")
+
+    def comm_info(self):
+        """(ranks of the RCCL communicator, this context's rank in it, ncclAllGather calls issued by this context)."""
+        n, r, g = C.c_int(), C.c_int(), C.c_longlong()
+        self._chk(lib().lf_comm_info(self._h, C.byref(n), C.byref(r), C.byref(g)), "lf_comm_info")
+        return n.value, r.value, g.value
 
     def comm_destroy(self):
         self._chk(lib().lf_comm_destroy(self._h), "lf_comm_destroy")

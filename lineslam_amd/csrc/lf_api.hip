@@ -81,6 +81,7 @@ struct lf_ctx {
   int orb_last = 0;
   // ---- key-frame exchange over RCCL
   ncclComm_t comm = nullptr;
+  long long n_allgathers = 0;       // ncclAllGather calls this context has issued (lf_comm_info)
   bool comm_owner = false;
   int comm_world = 0, comm_rank = 0, comm_max_kf = 0;
   int xbuf_world = 0, xbuf_max_kf = 0;      // geometry the exchange buffers were allocated for
@@ -1454,6 +1455,8 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
@@ -1473,6 +1476,8 @@ static RcclApi &rccl() {
   a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.h, "ncclGetUniqueId");
   a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.h, "ncclCommInitRank");
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.h, "ncclCommDestroy");
+  a.CommCount = (decltype(a.CommCount))dlsym(a.h, "ncclCommCount");
+  a.CommUserRank = (decltype(a.CommUserRank))dlsym(a.h, "ncclCommUserRank");
   a.AllGather = (decltype(a.AllGather))dlsym(a.h, "ncclAllGather");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.h, "ncclGetErrorString");
   a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather;
@@ -1573,6 +1578,20 @@ int lf_comm_destroy(lf_ctx *c) {
   c->h_xslots.clear();
   return LF_OK;
 }
+int lf_comm_info(lf_ctx *c, int *n_ranks, int *rank, long long *n_allgathers) {
+  if (!c) return LF_ERR_INVALID;
+  if (!c->comm) { c->err = "lf_comm_init has not been called"; return LF_ERR_INVALID; }
+  if (!rccl().CommCount || !rccl().CommUserRank) return LF_ERR_UNSUPPORTED;
+  int n = 0, r = 0;
+  ncclResult_t e = rccl().CommCount(c->comm, &n);
+  if (e != ncclSuccess) return fail_nccl(c, e, "ncclCommCount");
+  e = rccl().CommUserRank(c->comm, &r);
+  if (e != ncclSuccess) return fail_nccl(c, e, "ncclCommUserRank");
+  if (n_ranks) *n_ranks = n;
+  if (rank) *rank = r;
+  if (n_allgathers) *n_allgathers = c->n_allgathers;
+  return LF_OK;
+}
 int lf_allgather_keyframes(lf_ctx *c, const int32_t *kf_slots, int n_kf, uint64_t id_offset, const lf_line_record **d_recs,
                            const int32_t **d_nlines, const uint64_t **d_ids, int *n_frames, int *ext_line_cap) {
   if (!c || !kf_slots || n_kf < 1 || !d_recs || !d_nlines || !d_ids || !n_frames || !ext_line_cap) return LF_ERR_INVALID;
@@ -1593,6 +1612,7 @@ int lf_allgather_keyframes(lf_ctx *c, const int32_t *kf_slots, int n_kf, uint64_
   HIPCHK(c, hipGetLastError());
   const size_t bytes = (size_t)n_kf * (L + 1) * sizeof(lf_line_record);
   ncclResult_t r = rccl().AllGather(c->d_xsend, c->d_xrecv, bytes, ncclUint8, c->comm, c->stream);   // the ONE collective
+  if (r == ncclSuccess) c->n_allgathers++;
   if (r != ncclSuccess) return fail_nccl(c, r, "ncclAllGather");
   const int ns = c->comm_world * n_kf;
   hipLaunchKernelGGL(k_unpack_headers, dim3((ns + 255) / 256), dim3(256), 0, c->stream, (const lf_line_record *)c->d_xrecv, L, ns, c->d_xnlines, c->d_xids);

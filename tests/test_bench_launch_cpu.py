@@ -32,7 +32,7 @@ def test_plan_without_a_launcher_spawns_or_fails_loudly():
     what, argv = bench.launch_plan(8, {}, 8)
     assert what == "spawn"
     assert "torch.distributed.run" in argv and argv[argv.index("--nproc-per-node") + 1] == "8"
-    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert "--standalone" in argv and argv[argv.index("--local-addr") + 1] == "127.0.0.1"    # the launcher picks the port itself
     with pytest.raises(SystemExit) as e:   # `python3 bench.py --gpus 2` on a 1-GPU box: never a silent one-rank run
         bench.launch_plan(2, {}, 1)
     assert "needs 2 devices" in str(e.value)

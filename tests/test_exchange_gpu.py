@@ -88,6 +88,16 @@ def test_bench_multi_rank_path_with_one_rank(built_lib, carrier):
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["quality"]["valid_pairs"] >= 35
     assert ("%s carrier" % carrier) in j["config"]["parallelism"]
+    # the line evidences its own exchange: the carrier, every rank's rate, and -- for the library carrier -- what the RCCL
+    # communicator reports (ncclCommCount == the ranks launched) and that ncclAllGather was really issued, once per step and
+    # context, by liblinefront.so (not by torch)
+    x = j["exchange"]
+    assert x["carrier"].startswith(carrier) and len(x["frames_per_s_by_rank"]) == 1 and x["frames_per_s_by_rank"][0] > 0
+    if carrier == "lib":
+        assert x["rccl_ranks_seen"] == [1] and x["rccl_rank_ids"] == [0]
+        assert x["rccl_allgathers_issued_by_rank"][0] >= 3 + 1          # timed steps + warm-up (+ the untimed quality pass)
+    else:
+        assert x["rccl_ranks_seen"] is None
 
 
 @pytest.mark.parametrize("world,block", [(2, 8), (3, 5)])
