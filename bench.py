@@ -444,7 +444,21 @@ def main():
     F = len(gray)                                        # frames this rank processes per step
     nfl = max(1, a.inflight)
     streams = [torch.cuda.Stream() for _ in range(nfl)]
-    ctxs = [capi.Context(640, 480, max_batch=F, params=P, device=local, stream=st.cuda_stream) for st in streams]
+    # residency: everything of a batch stays in HBM; the first context says what one costs, every further one in flight is
+    # created only if the device still has room for it (with 10 % to spare) -- a sequence too long for `nfl` batches in flight
+    # runs with fewer, and the line says so (config.passes_in_flight, residency)
+    ctxs = [capi.Context(640, 480, max_batch=F, params=P, device=local, stream=streams[0].cuda_stream)]
+    ctx_bytes = ctxs[0].device_bytes()[0]
+    for st in streams[1:]:
+        held, free_b, total_b = ctxs[0].device_bytes()
+        if free_b < 1.1 * ctx_bytes:
+            print("bench: %.1f GB free, a batch needs %.1f GB: %d passes in flight instead of %d" % (free_b / 1e9, ctx_bytes / 1e9, len(ctxs), nfl), file=sys.stderr)
+            break
+        ctxs.append(capi.Context(640, 480, max_batch=F, params=P, device=local, stream=st.cuda_stream))
+    nfl = len(ctxs)
+    streams = streams[:nfl]
+    residency = {"bytes_per_context": int(ctx_bytes), "contexts": nfl, "device_total_bytes": int(ctxs[0].device_bytes()[2]),
+                 "bytes_per_frame": int(ctx_bytes // max(F, 1))}
     ctx = ctxs[0]
     if a.points and not a.serial_points:
         for c in ctxs:
@@ -792,7 +806,7 @@ def main():
             "stage_ms": {"lsd_data_parallel": float(np.mean(pre_ms)), "lsd_sweep": sw,
                          "lines3d_msld_mle": float(np.mean(front_ms)), "match_pose": float(np.mean(pair_ms))},
             "serial": serial, "value_including_h2d": (h2d or {}).get("value"), "including_h2d": h2d,
-            "points": point_stats, "strong_scaling": strong_info, "exchange": exchange_info,
+            "points": point_stats, "strong_scaling": strong_info, "exchange": exchange_info, "residency": residency,
             "quality": {"valid_pairs": int(valid.sum()), "pairs": int(len(valid)), "pairs_over_a_capacity": n_over,
                         "ate_rmse_m_vs_ground_truth": ate.ate_rmse(est[:, :3, 3], gt[:, :3, 3])},
         }

@@ -477,6 +477,11 @@ LF_API int lf_match_external_device(lf_ctx *ctx, const int32_t *query_frames, co
                                     const int32_t *d_ext_nlines, const uint64_t *d_ext_ids, int ext_frames,
                                     int ext_line_cap);
 
+/* Device memory: bytes this context holds (everything of a batch stays resident: ~18 MB per 640x480 frame of max_batch), and the
+ * device's free / total bytes now.  A context whose buffers do not fit returns LF_ERR_CAPACITY from lf_ctx_create* with the
+ * buffer's name in lf_last_error -- callers that keep several batches in flight size them with this. */
+LF_API int lf_ctx_device_bytes(lf_ctx *ctx, unsigned long long *held, unsigned long long *dev_free, unsigned long long *dev_total);
+
 /* ---- multi-GPU inside the library: ONE RCCL collective per batch of key frames ----------------
  * One process per GPU.  A context joins a communicator of `world_size` ranks: rank 0 obtains a 128-byte id with
  * lf_comm_unique_id and hands it to the other ranks by any side channel (MPI, torch.distributed, a file, ROS), then every

@@ -123,6 +123,7 @@ SYMBOLS = {
     "lf_comm_init": (_i, [_vp, _i, _i, _vp, _i]),
     "lf_comm_attach": (_i, [_vp, _vp]),
     "lf_comm_destroy": (_i, [_vp]),
+    "lf_ctx_device_bytes": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "lf_comm_info": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "lf_allgather_keyframes": (_i, [_vp, _vp, _i, C.c_uint64, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _pi, _pi]),
     "lf_line_matching_node_pair": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, C.c_uint64, _i, _vp, _vp, _vp, _i, _pi]),
@@ -619,6 +620,12 @@ class Context:
 
     def comm_attach(self, owner):
         self._chk(lib().lf_comm_attach(self._h, owner._h), "lf_comm_attach")
+
+    def device_bytes(self):
+        """(bytes of device memory this context holds, free bytes on its device now, total bytes of the device)."""
+        h, f, t = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+        self._chk(lib().lf_ctx_device_bytes(self._h, C.byref(h), C.byref(f), C.byref(t)), "lf_ctx_device_bytes")
+        return h.value, f.value, t.value
 
     def comm_info(self):
         """(ranks of the RCCL communicator, this context's rank in it, ncclAllGather calls issued by this context)."""

@@ -82,6 +82,7 @@ struct lf_ctx {
   // ---- key-frame exchange over RCCL
   ncclComm_t comm = nullptr;
   long long n_allgathers = 0;       // ncclAllGather calls this context has issued (lf_comm_info)
+  size_t alloc_bytes = 0;           // device memory this context has allocated (lf_ctx_device_bytes)
   bool comm_owner = false;
   int comm_world = 0, comm_rank = 0, comm_max_kf = 0;
   int xbuf_world = 0, xbuf_max_kf = 0;      // geometry the exchange buffers were allocated for
@@ -122,7 +123,20 @@ static int dev_alloc(lf_ctx *c, T **p, size_t count, const char *what) {
   void *q = nullptr;
   const size_t bytes = count * sizeof(T);
   hipError_t e = hipMalloc(&q, bytes + 256 + (guard_on() ? LF_GUARD_BYTES : 0));
-  if (e != hipSuccess) return fail_hip(c, e, "hipMalloc");
+  if (e != hipSuccess) {
+    if (e == hipErrorOutOfMemory) {       // name the buffer and the device's state: a batch sized past the HBM is a capacity error
+      size_t fr = 0, tot = 0;
+      (void)hipGetLastError();
+      (void)hipMemGetInfo(&fr, &tot);
+      char buf[320];
+      snprintf(buf, sizeof buf, "device memory: %s needs %.2f GB, %.2f of %.2f GB free (this context holds %.2f GB already)", what,
+               bytes / 1e9, fr / 1e9, tot / 1e9, c->alloc_bytes / 1e9);
+      c->err = buf;
+      return LF_ERR_CAPACITY;
+    }
+    return fail_hip(c, e, "hipMalloc");
+  }
+  c->alloc_bytes += bytes;
   c->allocs.push_back(q);
   if (guard_on()) {
     (void)hipMemset((char *)q + bytes, 0xA5, 256 + LF_GUARD_BYTES);
@@ -377,7 +391,7 @@ static int alloc_lsd(lf_ctx *c) {
   ALLOC(c, b.seeds, B * NM);
   ALLOC(c, b.nseeds, B);
   ALLOC(c, b.used, B * NM);
-  ALLOC(c, b.ndbits, B * (size_t)lc.M * (size_t)((lc.N + 31) / 32));
+  if (lc.sweep_lu) ALLOC(c, b.ndbits, B * (size_t)lc.M * (size_t)((lc.N + 31) / 32));      // k_lsd_sweep_lu's initial bitmap (opt-in)
   ALLOC(c, b.reg, B * NM);
   ALLOC(c, b.tmp, B * NM);
   ALLOC(c, b.mw_tag, B * LF_MW_MAXW * NM);
@@ -1576,6 +1590,16 @@ int lf_comm_destroy(lf_ctx *c) {
   }
   c->comm = nullptr; c->comm_owner = false;
   c->h_xslots.clear();
+  return LF_OK;
+}
+int lf_ctx_device_bytes(lf_ctx *c, unsigned long long *held, unsigned long long *dev_free, unsigned long long *dev_total) {
+  if (!c) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t fr = 0, tot = 0;
+  HIPCHK(c, hipMemGetInfo(&fr, &tot));
+  if (held) *held = c->alloc_bytes;
+  if (dev_free) *dev_free = fr;
+  if (dev_total) *dev_total = tot;
   return LF_OK;
 }
 int lf_comm_info(lf_ctx *c, int *n_ranks, int *rank, long long *n_allgathers) {

@@ -509,7 +509,6 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
   EdChainRec *chains = F.ch;
   int *chainNos = F.chain_nos;
   const unsigned *A = b.anchors + (size_t)f * c.anchor_cap;
-  double *segs = b.segs + (size_t)f * c.seg_cap * 5;
   const int nos_cap = (W + H) * 8;
   int noAnchors = b.nanch[f];
   bool overflow = noAnchors > c.anchor_cap;
@@ -623,6 +622,7 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
     if (overflow) break;
     if (len - duplicatePixelCount < ED_MIN_PATH) {
       for (int q = lane; q < len; q += 64) E[(size_t)e_pr(pixels[q]) * W + e_pc(pixels[q])] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // (lane-strided stores, read back by every lane as uniform loads: ordered explicitly)
       continue;
     }
     if ((size_t)nsegpix + (size_t)len + 2 >= NP) { overflow = true; break; }
@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
           int index = n - 2;
           while (index >= 0) { if (e_near(fp, seg[index])) { n--; index--; } else break; }
           if (chains[cn].len > 1 && n > 0) { fp = cp[chains[cn].len - 2]; if (e_near(fp, seg[n - 1])) chains[cn].len--; }
-          { const int cl = chains[cn].len; for (int l = lane; l < cl; l += 64) seg[n + l] = cp[cl - 1 - l]; if (cl > 0) n += cl; }   // (64 pixels per trip: the lanes share the copy)
+          { const int cl = chains[cn].len; for (int l = lane; l < cl; l += 64) seg[n + l] = cp[cl - 1 - l]; if (cl > 0) n += cl; __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }   // (64 pixels per trip: the lanes share the copy)
           chains[cn].len = 0;
         }
       }
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
           int index = n - 2, startIndex = 0;
           while (index >= 0) { if (e_near(cp[0], seg[index])) { n--; index--; } else break; }
           if (chains[cn].len > 1 && n > 0) { if (e_near(cp[1], seg[n - 1])) startIndex = 1; }
-          { const int cl = chains[cn].len - startIndex; for (int l = lane; l < cl; l += 64) seg[n + l] = cp[startIndex + l]; if (cl > 0) n += cl; }
+          { const int cl = chains[cn].len - startIndex; for (int l = lane; l < cl; l += 64) seg[n + l] = cp[startIndex + l]; if (cl > 0) n += cl; __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
           chains[cn].len = 0;
         }
       }
@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(64) k_ed_link(EdConsts c, EdBuffers b) {
           int index = n - 2, startIndex = 0;
           while (index >= 0) { if (e_near(cp[0], seg[index])) { n--; index--; } else break; }
           if (chains[cn].len > 1 && n > 0) { if (e_near(cp[1], seg[n - 1])) startIndex = 1; }
-          { const int cl = chains[cn].len - startIndex; for (int l = lane; l < cl; l += 64) seg[n + l] = cp[startIndex + l]; if (cl > 0) n += cl; }
+          { const int cl = chains[cn].len - startIndex; for (int l = lane; l < cl; l += 64) seg[n + l] = cp[startIndex + l]; if (cl > 0) n += cl; __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
           chains[cn].len = 0;
         }
         if (nsegments >= c.segtab_cap) { overflow = true; break; }

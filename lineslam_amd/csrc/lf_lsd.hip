@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) k_ll_angle(LsdConsts c, LsdBuffers b) {
     b.modgrad[f * NM + adr] = norm;
     *(lf_d2 *)&b.cossin[2 * (f * NM + adr)] = (lf_d2){ca, sa};
   }
-  {
+  if (c.sweep_lu) {       // (only the opt-in LDS variant of the sweep reads it; not written, not allocated otherwise)
     // NOTDEF bitmap of the frame, rows padded to whole 32-bit words (k_lsd_sweep_lu's initial `unavailable` mask): a wavefront
     // covers two tile rows of 32 pixels -- the two halves of one ballot; pixels outside the image count as unavailable
     const u64 ndm = __ballot(bin == LF_BIN_NONE);
