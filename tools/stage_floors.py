@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from lineslam_amd import capi, synth
 F, NFL, STEPS = 1147, 4, 12
-gray, depth, _ = synth.sequence(F, seed=2, n_unique=8)
+gray, depth, _ = synth.sequence(F, seed=2, n_unique=int(os.environ.get("LF_FLOORS_UNIQUE", "256")))   # (the bench batch)
 P = capi.default_params(launch=True)
 streams = [torch.cuda.Stream() for _ in range(NFL)]
 ctxs = [capi.Context(640, 480, max_batch=F, params=P, stream=st.cuda_stream) for st in streams]
