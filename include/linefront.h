@@ -312,6 +312,24 @@ LF_API int lf_solve_node_pair(lf_ctx *ctx, const lf_line_record *newer, int n_ne
                               uint64_t id_older, const float *pts_older, int n_pts_older, const int32_t *lm_query,
                               const int32_t *lm_train, int n_lm, const int32_t *pm_query, const int32_t *pm_train,
                               int n_pm, const double K[9], lf_pair_result *out);
+/* bool Node::getRelativeTransformationTo(const Node* earlier_node, std::vector<cv::DMatch>* initial_matches,
+ *      Eigen::Matrix4f& resulting_transformation, float& rmse, std::vector<cv::DMatch>& matches) const
+ * (src/node.h:124-128, src/node.cpp:1134-1338): the point-feature RANSAC that matchNodePair runs in builds WITHOUT USE_LINES,
+ * for two nodes in HOST memory.  pts_*: feature_locations_3d_ ([n][4] floats, z = NaN without depth); match_*: the
+ * members of initial_matches; min_matches / ransac_iterations / max_dist_for_inliers: the ParameterServer options of those
+ * names (20 / 200 / 3; launch/lineslam.launch: min_matches 10).  Outputs: T (row-major, newer -> older), rmse, *found = the
+ * return value, inlier_idx[0 .. *n_inliers) = indices into the caller's match arrays of `matches`, in the order the
+ * reference keeps them (ascending distance).  g2o_refinement_iterations ("g2o_transformation_refinement", 0 by default): the
+ * EdgeSE3PointXYZDepth refinement at the end of the reference function is not restated -- values > 0 return
+ * LF_ERR_UNSUPPORTED.  rand() -> the library's counter generator (the reference seeds with clock()); ties of equal
+ * distance keep the caller's order (std::sort leaves them unspecified).  At most 1024 matches, 4096 points per node.
+ * Synchronous. */
+LF_API int lf_relative_transformation_legacy(lf_ctx *ctx, const float *pts_newer, int n_pts_newer, uint64_t id_newer,
+                                             const float *pts_older, int n_pts_older, uint64_t id_older,
+                                             const int32_t *match_query, const int32_t *match_train, const float *match_dist,
+                                             int n_matches, int min_matches, int ransac_iterations, double max_dist_for_inliers,
+                                             int g2o_refinement_iterations, float T[16], float *rmse, int32_t *inlier_idx, int cap,
+                                             int *n_inliers, int *found);
 /* void MLEstimateLine3d(RandomLine3d& line, int maxIter) (src/line/utils.h, utils.cpp:980-1050) for n_lines lines in
  * HOST memory: line i has npts[i] support points pts[pt_offset[i] .. ) (xyz doubles, the RANSAC consensus set
  * `line.pts`, at most 104 each; their covariances are compPt3dCov(pt, K) as at lineslam.cpp:283-285) and the RANSAC

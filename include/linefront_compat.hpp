@@ -164,16 +164,30 @@ class Node {
     return (unsigned)matches->size();
   }
 
-  // Node::getRelativeTransformationTo (src/node.h:124-128): legacy point-RANSAC entry, routed to the same
-  // solver; initial_matches = the point matches.  `matches` receives the point
-  // inliers when point matches were given, the line inliers otherwise.
-  bool getRelativeTransformationTo(const Node* target_node, std::vector<DMatch>* initial_matches,
+  // Node::getRelativeTransformationTo (src/node.h:124-128, src/node.cpp:1134-1338): the point-feature RANSAC itself -- what
+  // matchNodePair runs in builds WITHOUT USE_LINES (with USE_LINES it calls getTransform_PtsLines_ransac: matchNodePair
+  // above).  initial_matches = the result of featureMatching; `matches` receives the inlier DMatches in the order the
+  // reference keeps them (ascending distance).  The ParameterServer options it reads are members here (defaults of
+  // src/parameter_server.cpp:82,95,96,98); its g2o step (g2o_transformation_refinement > 0, EdgeSE3PointXYZDepth) is not
+  // restated and is refused (lf::Error, LF_ERR_UNSUPPORTED).
+  int min_matches = 20, ransac_iterations = 200, g2o_transformation_refinement = 0;
+  double max_dist_for_inliers = 3.0;
+  bool getRelativeTransformationTo(const Node* earlier_node, std::vector<DMatch>* initial_matches,
                                    float resulting_transformation[16], float& rmse, std::vector<DMatch>& matches) const {
-    MatchingResult mr = matchNodePair(target_node, initial_matches);
-    for (int i = 0; i < 16; i++) resulting_transformation[i] = mr.final_trafo[i];
-    rmse = mr.rmse;
-    matches = (initial_matches && !initial_matches->empty()) ? mr.inlier_matches : mr.inlier_line_matches;
-    return mr.edge.id1 >= 0;
+    std::vector<int32_t> q, t, idx(initial_matches->size() + 1);
+    std::vector<float> d;
+    for (const DMatch& m : *initial_matches) { q.push_back(m.queryIdx); t.push_back(m.trainIdx); d.push_back(m.distance); }
+    int n = 0, found = 0;
+    check(lf_relative_transformation_legacy(ctx->h, feature_locations_3d_.empty() ? nullptr : feature_locations_3d_[0].data(),
+                                            (int)feature_locations_3d_.size(), (uint64_t)id_,
+                                            earlier_node->feature_locations_3d_.empty() ? nullptr : earlier_node->feature_locations_3d_[0].data(),
+                                            (int)earlier_node->feature_locations_3d_.size(), (uint64_t)earlier_node->id_, q.data(), t.data(),
+                                            d.data(), (int)q.size(), min_matches, ransac_iterations, max_dist_for_inliers,
+                                            g2o_transformation_refinement, resulting_transformation, &rmse, idx.data(), (int)idx.size(), &n,
+                                            &found), "lf_relative_transformation_legacy");
+    matches.clear();
+    for (int i = 0; i < n; i++) matches.push_back((*initial_matches)[(size_t)idx[i]]);
+    return found != 0;
   }
 };
 

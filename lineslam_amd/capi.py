@@ -123,6 +123,8 @@ SYMBOLS = {
     "lf_comm_init": (_i, [_vp, _i, _i, _vp, _i]),
     "lf_comm_attach": (_i, [_vp, _vp]),
     "lf_comm_destroy": (_i, [_vp]),
+    "lf_relative_transformation_legacy": (_i, [_vp, _vp, _i, C.c_uint64, _vp, _i, C.c_uint64, _vp, _vp, _vp, _i, _i, _i, C.c_double, _i,
+                                               _vp, C.POINTER(C.c_float), _vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     "lf_ctx_device_bytes": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "lf_comm_info": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "lf_allgather_keyframes": (_i, [_vp, _vp, _i, C.c_uint64, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _pi, _pi]),
@@ -620,6 +622,24 @@ class Context:
 
     def comm_attach(self, owner):
         self._chk(lib().lf_comm_attach(self._h, owner._h), "lf_comm_attach")
+
+    def relative_transformation_legacy(self, pts_newer, id_newer, pts_older, id_older, match_q, match_t, match_d, min_matches=20,
+                                       ransac_iterations=200, max_dist_for_inliers=3.0, g2o_iterations=0):
+        """Node::getRelativeTransformationTo (node.cpp:1134-1338, builds without USE_LINES) for two host-resident nodes.
+        Returns (found, T [4,4] float32 newer -> older, rmse, inlier indices into the match arrays)."""
+        pn = np.ascontiguousarray(pts_newer, np.float32).reshape(-1, 4)
+        po = np.ascontiguousarray(pts_older, np.float32).reshape(-1, 4)
+        q, t = np.ascontiguousarray(match_q, np.int32), np.ascontiguousarray(match_t, np.int32)
+        d = np.ascontiguousarray(match_d, np.float32)
+        T = np.zeros(16, np.float32)
+        rmse, n, found = C.c_float(), C.c_int(), C.c_int()
+        idx = np.zeros(max(len(q), 1), np.int32)
+        self._chk(lib().lf_relative_transformation_legacy(self._h, pn.ctypes.data, len(pn), int(id_newer), po.ctypes.data, len(po), int(id_older),
+                                                          q.ctypes.data, t.ctypes.data, d.ctypes.data, len(q), int(min_matches),
+                                                          int(ransac_iterations), float(max_dist_for_inliers), int(g2o_iterations),
+                                                          T.ctypes.data, C.byref(rmse), idx.ctypes.data, len(idx), C.byref(n), C.byref(found)),
+                  "lf_relative_transformation_legacy")
+        return bool(found.value), T.reshape(4, 4), float(rmse.value), idx[:n.value].copy()
 
     def device_bytes(self):
         """(bytes of device memory this context holds, free bytes on its device now, total bytes of the device)."""

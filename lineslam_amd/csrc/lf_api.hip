@@ -11,6 +11,7 @@
 #include "lf_points.h"
 #include "lf_orb.h"
 #include "lf_edlines.h"
+#include "lf_pair_legacy.h"
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -54,6 +55,9 @@ struct lf_ctx {
   bool hybrid_ready = false;         // hybrid (points + lines) buffers are allocated on first use
   int *d_pm_q = nullptr, *d_pm_t = nullptr, *d_npm = nullptr;
   float *d_pts_stage = nullptr;      // lf_match_node_pair_hybrid staging: 2 x LF_NODE_PT_CAP float4
+  int *d_legacy_i = nullptr;         // lf_relative_transformation_legacy staging: match q | t | inlier indices (3 x LF_LEGACY_CAP)
+  float *d_legacy_f = nullptr;       //   match distances
+  LegacyResult *d_legacy_r = nullptr;
   // the point front end (ORB extraction, projectTo3D) on its own stream, next to the line front end (lf_ctx_point_stream)
   hipStream_t pstream = nullptr;
   hipEvent_t ev_pts_in = nullptr, ev_pts_done = nullptr, ev_pts_free = nullptr;
@@ -1418,6 +1422,56 @@ int lf_refine_pair(lf_ctx *c, const lf_line_record *newer, int n_newer, const fl
   r = lf_pair_get_result(c, 0, &res);
   if (r != LF_OK) return r;
   for (int i = 0; i < 16; i++) T[i] = res.T[i];
+  return LF_OK;
+}
+
+int lf_relative_transformation_legacy(lf_ctx *c, const float *pts_newer, int n_pts_newer, uint64_t id_newer, const float *pts_older,
+                                      int n_pts_older, uint64_t id_older, const int32_t *match_query, const int32_t *match_train,
+                                      const float *match_dist, int n_matches, int min_matches, int ransac_iterations,
+                                      double max_dist_for_inliers, int g2o_refinement_iterations, float T[16], float *rmse,
+                                      int32_t *inlier_idx, int cap, int *n_inliers, int *found) {
+  if (!c || !T || !rmse || !n_inliers || !found || n_matches < 0 || n_pts_newer < 0 || n_pts_older < 0 || ransac_iterations < 0 ||
+      (n_matches && (!match_query || !match_train || !match_dist || !pts_newer || !pts_older)))
+    return LF_ERR_INVALID;
+  if (g2o_refinement_iterations > 0) {
+    c->err = "the g2o step of getRelativeTransformationTo (EdgeSE3PointXYZDepth, node.cpp:1283-1327) is not restated: pass 0";
+    return LF_ERR_UNSUPPORTED;
+  }
+  if (n_matches > LF_LEGACY_CAP || n_pts_newer > LF_NODE_PT_CAP || n_pts_older > LF_NODE_PT_CAP) return LF_ERR_CAPACITY;
+  for (int k = 0; k < n_matches; k++)
+    if (match_query[k] < 0 || match_query[k] >= n_pts_newer || match_train[k] < 0 || match_train[k] >= n_pts_older) return LF_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->d_pts_stage) ALLOC(c, c->d_pts_stage, (size_t)2 * LF_NODE_PT_CAP * 4);
+  if (!c->d_legacy_i) { ALLOC(c, c->d_legacy_i, (size_t)3 * LF_LEGACY_CAP); ALLOC(c, c->d_legacy_f, (size_t)LF_LEGACY_CAP); ALLOC(c, c->d_legacy_r, 1); }
+  if (n_pts_newer) HIPCHK(c, hipMemcpyAsync(c->d_pts_stage, pts_newer, sizeof(float) * 4 * (size_t)n_pts_newer, hipMemcpyHostToDevice, c->stream));
+  if (n_pts_older) HIPCHK(c, hipMemcpyAsync(c->d_pts_stage + (size_t)LF_NODE_PT_CAP * 4, pts_older, sizeof(float) * 4 * (size_t)n_pts_older, hipMemcpyHostToDevice, c->stream));
+  if (n_matches) {
+    HIPCHK(c, hipMemcpyAsync(c->d_legacy_i, match_query, sizeof(int) * (size_t)n_matches, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_legacy_i + LF_LEGACY_CAP, match_train, sizeof(int) * (size_t)n_matches, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_legacy_f, match_dist, sizeof(float) * (size_t)n_matches, hipMemcpyHostToDevice, c->stream));
+  }
+  LegacyArgs a;
+  a.pts_q = c->d_pts_stage; a.pts_t = c->d_pts_stage + (size_t)LF_NODE_PT_CAP * 4;
+  a.mq = c->d_legacy_i; a.mt = c->d_legacy_i + LF_LEGACY_CAP; a.md = c->d_legacy_f; a.n = n_matches;
+  a.min_matches = min_matches; a.iterations = ransac_iterations; a.max_dist_m = (float)max_dist_for_inliers;
+  a.seed = c->params.rng_seed; a.stream = ((id_newer << 32) ^ (uint64_t)(uint32_t)id_older ^ 0x5000000000000000ULL);
+  {   // errorFunction2 constants (misc.cpp:704-711) and sigma_depth (misc2.h:23), host libm as in the reference
+    const double cam_angle_x = 58.0 / 180.0 * M_PI, cam_angle_y = 45.0 / 180.0 * M_PI;
+    const double sx = 3 * tan(cam_angle_x / 640), sy = 3 * tan(cam_angle_y / 480);
+    a.pm.raster_cov_x = sx * sx; a.pm.raster_cov_y = sy * sy; a.pm.sigma_depth = 0.01;
+  }
+  a.out = c->d_legacy_r; a.out_inliers = c->d_legacy_i + 2 * LF_LEGACY_CAP;
+  lf_legacy_launch(a, c->stream);
+  HIPCHK(c, hipGetLastError());
+  LegacyResult r;
+  HIPCHK(c, hipMemcpyAsync(&r, c->d_legacy_r, sizeof r, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 16; i++) T[i] = r.T[i];
+  *rmse = r.rmse; *found = r.found; *n_inliers = r.n_inliers;
+  if (r.n_inliers > 0) {
+    if (!inlier_idx || cap < r.n_inliers) return LF_ERR_CAPACITY;
+    HIPCHK(c, hipMemcpy(inlier_idx, c->d_legacy_i + 2 * LF_LEGACY_CAP, sizeof(int) * (size_t)r.n_inliers, hipMemcpyDeviceToHost));
+  }
   return LF_OK;
 }
 

@@ -8,8 +8,8 @@ meaning as the reference so that the parity tests read like the reference's call
     node.getTransform_PtsLines_ransac(train, pt, ln)          <-> src/line/utils.h:147-153 (caller-supplied matches)
     node.getTransformFromHybridMatchesG2O(earlier, pt, ln, T) <-> src/transformation_estimation.h:21-26
     node.matchNodePair(older)                <-> Node::matchNodePair          (node.cpp:1494-1615)
-    node.getRelativeTransformationTo(older)  <-> Node::getRelativeTransformationTo (node.h:124-128): the
-        legacy point-RANSAC entry, routed to the same solver; `initial_matches` are the point matches.
+    node.getRelativeTransformationTo(older, matches) <-> Node::getRelativeTransformationTo (node.h:124-128): the
+        point-feature RANSAC of builds without USE_LINES (node.cpp:1134-1338), its own kernel; `initial_matches` from featureMatching.
 Points: `node.feature_locations_3d_` ([n,4] float32: x,y,z,1, z = NaN without depth) is filled by the caller
 (keypoint extraction / descriptor matching are outside the accelerated path); when point matches are passed,
 the hybrid solver (BASELINE config 3) runs.
@@ -152,8 +152,19 @@ class Node:
             mr.edge_information = np.eye(6) * r.information_scale
         return mr
 
-    def getRelativeTransformationTo(self, target_node, initial_matches=None):
-        """(found, transformation, rmse, inlier matches) -- node.h:124-128."""
-        mr = self.matchNodePair(target_node, initial_matches)
-        inl = mr.inlier_matches if initial_matches is not None and len(initial_matches) else mr.inlier_line_matches
-        return mr.edge_id1 >= 0, mr.final_trafo, mr.rmse, inl
+    def getRelativeTransformationTo(self, earlier_node, initial_matches, min_matches=20, ransac_iterations=200,
+                                    max_dist_for_inliers=3.0, g2o_transformation_refinement=0):
+        """bool Node::getRelativeTransformationTo(earlier_node, initial_matches, resulting_transformation, rmse, matches)
+        (node.h:124-128, node.cpp:1134-1338): the point-feature RANSAC of builds without USE_LINES (with USE_LINES
+        matchNodePair calls getTransform_PtsLines_ransac instead -- matchNodePair above).  initial_matches: (queryIdx, trainIdx,
+        distance) tuples from featureMatching.  Returns (found, transformation [4,4] float32, rmse, inlier matches in the order
+        the reference keeps them).  The keyword arguments are the ParameterServer options of those names."""
+        self._ctx.set_params(self.params)
+        m = list(initial_matches)
+        q = np.asarray([x[0] for x in m], np.int32)
+        t = np.asarray([x[1] for x in m], np.int32)
+        d = np.asarray([x[2] if len(x) > 2 else 0.0 for x in m], np.float32)
+        found, T, rmse, idx = self._ctx.relative_transformation_legacy(self.feature_locations_3d_, self.id_, earlier_node.feature_locations_3d_,
+                                                                       earlier_node.id_, q, t, d, min_matches, ransac_iterations,
+                                                                       max_dist_for_inliers, g2o_transformation_refinement)
+        return found, T, rmse, [m[i] for i in idx.tolist()]

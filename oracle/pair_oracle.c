@@ -541,3 +541,151 @@ double oracle_r2r_angle(double y, double x, int flip, double *s, double *c) {
   lf_sincos_cr_near(theta, flip, th, t0, s0, c0, s, c);
   return theta;
 }
+
+/* ================================================================ legacy point-feature RANSAC
+ * Node::getRelativeTransformationTo (src/node.cpp:1134-1338) without its g2o step (:1283-1327, off by default), with
+ * sample_matches_prefer_by_distance (:1085-1108), getTransformFromMatches (src/transformation_estimation_euclidean.cpp:7-56)
+ * and computeInliersAndError (:1021-1080).  Sequential twin of csrc/lf_pair_legacy.hip; rand() -> the counter generator
+ * (draw d of iteration n = counter 20002 n + d), std::sort's tie order -> stable.  pts: float4 per feature.
+ * Returns found; out_inl = indices into the caller's match arrays, in the kept (ascending distance) order. */
+static int o_legacy_score(const float *pq, const float *pt, const int *mq, const int *mt, const int *perm, int n, const float *tf,
+                          double thr2, const lf_point_model *pm, int *list, double *err_out) {
+  int i, cnt = 0;
+  double mean = 0.0;
+  for (i = 0; i < n; i++) {
+    int m = perm[i];
+    const float *x1 = pq + 4 * (size_t)mq[m], *x2 = pt + 4 * (size_t)mt[m];
+    double e;
+    if (x1[2] == 0.0f || x2[2] == 0.0f) continue;
+    e = lf_error_function2(x1, x2, tf, pm);
+    if (e > thr2) continue;
+    if (!(e >= 0.0)) continue;
+    mean += e;
+    list[cnt++] = i;
+  }
+  *err_out = cnt < 3 ? 1e9 : sqrt(mean / (double)cnt);
+  return cnt;
+}
+static int o_legacy_transform(const float *pq, const float *pt, const int *mq, const int *mt, const int *perm, const int *list,
+                              int cnt, float max_dist_m, float *tf) {
+  lf_tfc t;
+  int k, c, have_prev = 0;
+  float pf[3] = {0, 0, 0}, pp[3] = {0, 0, 0};
+  lf_tfc_reset(&t);
+  for (k = 0; k < cnt; k++) {
+    int m = perm[list[k]];
+    const float *from = pq + 4 * (size_t)mq[m], *to = pt + 4 * (size_t)mt[m];
+    float w;
+    if (from[2] != from[2] || to[2] != to[2]) continue;
+    w = 1 / (to[2] + from[2]);
+    if (max_dist_m > 0) {
+      if (have_prev) {
+        float df = ((from[0] - pf[0]) * (from[0] - pf[0]) + (from[1] - pf[1]) * (from[1] - pf[1])) + (from[2] - pf[2]) * (from[2] - pf[2]);
+        float dt = ((to[0] - pp[0]) * (to[0] - pp[0]) + (to[1] - pp[1]) * (to[1] - pp[1])) + (to[2] - pp[2]) * (to[2] - pp[2]);
+        float d = df - dt;
+        if ((d < 0 ? -d : d) > max_dist_m * max_dist_m) return 0;
+      }
+      for (c = 0; c < 3; c++) { pf[c] = from[c]; pp[c] = to[c]; }
+      have_prev = 1;
+    }
+    lf_tfc_add(&t, from, to, w);
+  }
+  lf_tfc_get(&t, tf);
+  return 1;
+}
+int oracle_legacy_ransac(const float *pts_q, const float *pts_t, const int *mq, const int *mt, const float *md, int n,
+                         int min_matches, int iterations, double max_dist_for_inliers, uint64_t seed, uint64_t stream, float *T,
+                         float *rmse_out, int *out_inl, int *n_inl, int *dbg /* [3] valid iterations, best iteration, iterations run */) {
+  lf_point_model pm;
+  const float max_dist_m = (float)max_dist_for_inliers;
+  float rmse = 1e6f;
+  int i, it, nbest = 0, valid_iterations = 0, best_iter = -1, real_iterations = 0, enough = 0;
+  int *perm, *cur, *ref, *best;
+  o_point_model(&pm);
+  for (i = 0; i < 16; i++) T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  *n_inl = 0; *rmse_out = rmse;
+  if (dbg) { dbg[0] = 0; dbg[1] = -1; dbg[2] = 0; }
+  if (!(n > min_matches)) return 0;
+  perm = (int *)malloc(sizeof(int) * (size_t)n * 4); cur = perm + n; ref = cur + n; best = ref + n;
+  {
+    unsigned min_thr = (unsigned)min_matches;
+    const double thr2 = (double)(max_dist_m * max_dist_m);
+    if ((double)min_thr > 0.75 * (double)n) min_thr = (unsigned)(0.75 * (double)n);
+    for (i = 0; i < n; i++) {
+      int j, rank = 0;
+      for (j = 0; j < n; j++) rank += (md[j] < md[i] || (md[j] == md[i] && j < i)) ? 1 : 0;
+      perm[rank] = i;
+    }
+    for (it = 0; it < iterations && n >= 4; it++) {
+      double refined_error = 1e6, inlier_error = 0.0;
+      int nref = 0, ncur, refinements;
+      float rtf[16];
+      for (i = 0; i < 16; i++) rtf[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+      {
+        int ids[4], ns = 0, safety = 0, k;
+        uint64_t ctr = (uint64_t)it * 20002ull;
+        while (ns < 4) {
+          int id1 = (int)(lf_rand31(seed, stream, ctr) % (uint32_t)n), id2 = (int)(lf_rand31(seed, stream, ctr + 1) % (uint32_t)n), pos = 0, dup = 0;
+          ctr += 2;
+          if (id1 > id2) id1 = id2;
+          while (pos < ns && ids[pos] <= id1) { if (ids[pos] == id1) dup = 1; pos++; }
+          if (!dup) { for (k = ns; k > pos; k--) ids[k] = ids[k - 1]; ids[pos] = id1; ns++; }
+          if (++safety > 10000) break;
+        }
+        for (k = 0; k < ns; k++) cur[k] = ids[k];
+        ncur = ns;
+      }
+      real_iterations++;
+      for (refinements = 1; refinements < 20; refinements++) {
+        float tf[16];
+        int nan = 0;
+        if (!o_legacy_transform(pts_q, pts_t, mq, mt, perm, cur, ncur, max_dist_m, tf)) break;
+        for (i = 0; i < 16; i++) nan = nan || (tf[i] != tf[i]);
+        if (nan) break;
+        ncur = o_legacy_score(pts_q, pts_t, mq, mt, perm, n, tf, thr2, &pm, cur, &inlier_error);
+        if ((unsigned)ncur < min_thr || inlier_error > (double)max_dist_m) break;
+        if (ncur >= nref && inlier_error <= refined_error) {
+          int prev = nref;
+          memcpy(rtf, tf, sizeof rtf);
+          memcpy(ref, cur, sizeof(int) * (size_t)ncur);
+          nref = ncur;
+          refined_error = inlier_error;
+          if (ncur == prev) break;
+        } else break;
+      }
+      if (nref > 0) {
+        valid_iterations++;
+        if (refined_error <= (double)rmse && nref >= nbest && (unsigned)nref >= min_thr) {
+          rmse = (float)refined_error;
+          memcpy(T, rtf, sizeof rtf);
+          memcpy(best, ref, sizeof(int) * (size_t)nref);
+          nbest = nref;
+          best_iter = it;
+          if ((double)nref > (double)n * 0.5) it += 10;
+          if ((double)nref > (double)n * 0.75) it += 10;
+          if ((double)nref > (double)n * 0.8) break;
+        }
+      }
+    }
+    if (valid_iterations == 0) {
+      float I4[16];
+      double inlier_error;
+      int nc;
+      for (i = 0; i < 16; i++) I4[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+      nc = o_legacy_score(pts_q, pts_t, mq, mt, perm, n, I4, thr2, &pm, cur, &inlier_error);
+      if ((unsigned)nc > min_thr && inlier_error < (double)max_dist_m) {
+        memcpy(T, I4, sizeof I4);
+        memcpy(best, cur, sizeof(int) * (size_t)nc);
+        nbest = nc;
+        rmse = (float)inlier_error;
+        valid_iterations++;
+      }
+    }
+    enough = (unsigned)nbest >= min_thr;
+  }
+  for (i = 0; i < nbest; i++) out_inl[i] = perm[best[i]];
+  *n_inl = nbest; *rmse_out = rmse;
+  if (dbg) { dbg[0] = valid_iterations; dbg[1] = best_iter; dbg[2] = real_iterations; }
+  free(perm);
+  return enough;
+}

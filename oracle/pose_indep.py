@@ -617,3 +617,103 @@ def mle_line(pts, A0, B0, f, P):
             J[3 * i:3 * i + 3] = mahvec_jacobian(pts[i], covs[i], para)
     cov = np.linalg.inv(J.T @ J)
     return para[:3], para[3:], cov[:3, :3], cov[3:, 3:], (i1, i2), float(cost(para) @ cost(para))
+
+
+# ---------------------------------------------------------------------------------------------- legacy point RANSAC
+def legacy_ransac(pts_q, pts_t, mq, mt, md, min_matches=20, iterations=200, max_dist=3.0, seed=0, stream=0):
+    """Node::getRelativeTransformationTo (src/node.cpp:1134-1338) without its g2o step, written from the reference with
+    numpy (Kabsch class above = pcl::TransformationFromCorrespondences, error_function2 = misc.cpp:699-786 through
+    numpy.linalg.solve).  Shares no source with csrc/ or oracle/pair_oracle.c.  Returns (found, T float32 4x4, rmse float32,
+    inlier indices into the match arrays in the kept order, (valid iterations, best iteration, iterations run))."""
+    pts_q, pts_t = np.asarray(pts_q, np.float32).reshape(-1, 4), np.asarray(pts_t, np.float32).reshape(-1, 4)
+    mq, mt, md = np.asarray(mq, int), np.asarray(mt, int), np.asarray(md, np.float32)
+    n = len(mq)
+    T = np.eye(4, dtype=np.float32)
+    rmse = np.float32(1e6)
+    if not n > min_matches:
+        return False, T, rmse, np.zeros(0, int), (0, -1, 0)
+    min_thr = min_matches
+    if min_thr > 0.75 * n:
+        min_thr = int(0.75 * n)
+    max_dist_m = np.float32(max_dist)
+    thr2 = float(max_dist_m * max_dist_m)
+    perm = np.argsort(md, kind="stable")                     # (ties keep the caller's order)
+
+    def score(tf):
+        tf_d = np.asarray(tf, np.float64)
+        inl, mean = [], 0.0
+        for i in range(n):
+            x1, x2 = pts_q[mq[perm[i]]], pts_t[mt[perm[i]]]
+            if x1[2] == 0.0 or x2[2] == 0.0:
+                continue
+            e = error_function2(x1, x2, tf_d)
+            if e > thr2 or not (e >= 0.0):
+                continue
+            mean += e
+            inl.append(i)
+        return inl, (1e9 if len(inl) < 3 else float(np.sqrt(mean / len(inl))))
+
+    def transform(lst):
+        kb = Kabsch()
+        prev = None
+        for i in lst:
+            f, t = pts_q[mq[perm[i]]][:3], pts_t[mt[perm[i]]][:3]
+            if np.isnan(f[2]) or np.isnan(t[2]):
+                continue
+            w = np.float32(1) / np.float32(t[2] + f[2])
+            if max_dist_m > 0:
+                if prev is not None:
+                    a, b = (f - prev[0]).astype(np.float32), (t - prev[1]).astype(np.float32)
+                    df = np.float32(np.float32(a[0] * a[0] + a[1] * a[1]) + a[2] * a[2])
+                    dt = np.float32(np.float32(b[0] * b[0] + b[1] * b[1]) + b[2] * b[2])
+                    if abs(np.float32(df - dt)) > max_dist_m * max_dist_m:
+                        return None
+                prev = (f, t)
+            kb.add(f, t, w)
+        return kb.transformation()
+
+    best, valid_iterations, best_iter, real_iterations = [], 0, -1, 0
+    it = 0
+    while it < iterations and n >= 4:
+        refined_error, refined, rtf = 1e6, [], np.eye(4, dtype=np.float32)
+        ids, ctr, safety = set(), it * 20002, 0
+        while len(ids) < 4:
+            id1, id2 = rand31(seed, stream, ctr) % n, rand31(seed, stream, ctr + 1) % n
+            ctr += 2
+            ids.add(min(id1, id2))
+            safety += 1
+            if safety > 10000:
+                break
+        cur = sorted(ids)
+        real_iterations += 1
+        for _ in range(1, 20):
+            tf = transform(cur)
+            if tf is None or np.isnan(tf).any():
+                break
+            cur, err = score(tf)
+            if len(cur) < min_thr or err > float(max_dist_m):
+                break
+            if len(cur) >= len(refined) and err <= refined_error:
+                prev = len(refined)
+                rtf, refined, refined_error = tf, list(cur), err
+                if len(cur) == prev:
+                    break
+            else:
+                break
+        if refined:
+            valid_iterations += 1
+            if refined_error <= float(rmse) and len(refined) >= len(best) and len(refined) >= min_thr:
+                rmse, T, best, best_iter = np.float32(refined_error), rtf, refined, it
+                if len(refined) > n * 0.5:
+                    it += 10
+                if len(refined) > n * 0.75:
+                    it += 10
+                if len(refined) > n * 0.8:
+                    break
+        it += 1
+    if valid_iterations == 0:
+        cur, err = score(np.eye(4, dtype=np.float32))
+        if len(cur) > min_thr and err < float(max_dist_m):
+            T, best, rmse = np.eye(4, dtype=np.float32), cur, np.float32(err)
+            valid_iterations += 1
+    return len(best) >= min_thr, T, rmse, perm[np.asarray(best, int)] if best else np.zeros(0, int), (valid_iterations, best_iter, real_iterations)

@@ -382,3 +382,26 @@ def orb_adjust_oracle(gray_frames_u8, thresh=20.0, min_thresh=2.0, max_thresh=10
                                      C.c_double(min_thresh), C.c_double(max_thresh), C.c_double(inc), C.c_double(dec), C.c_int(min_features),
                                      C.c_int(max_features), C.c_int(max_iters), C.c_void_p(thr.ctypes.data), C.c_void_p(cnt.ctypes.data))
     return thr, cnt, st.value
+
+
+def legacy_ransac_oracle(pts_q, pts_t, mq, mt, md, id_newer, id_older, min_matches=20, iterations=200, max_dist=3.0, seed=0,
+                         flavour="ref"):
+    """oracle_legacy_ransac (oracle/pair_oracle.c): Node::getRelativeTransformationTo without its g2o step.
+    Returns (found, T [4,4] f32, rmse, inlier indices into the match arrays, (valid iterations, best iteration, iterations run))."""
+    lib = oracle_lib(flavour)
+    pq = np.ascontiguousarray(pts_q, np.float32).reshape(-1, 4)
+    pt = np.ascontiguousarray(pts_t, np.float32).reshape(-1, 4)
+    q, t, d = np.ascontiguousarray(mq, np.int32), np.ascontiguousarray(mt, np.int32), np.ascontiguousarray(md, np.float32)
+    T = np.zeros(16, np.float32)
+    rmse, n = C.c_float(), C.c_int()
+    inl = np.zeros(max(len(q), 1), np.int32)
+    dbg = np.zeros(3, np.int32)
+    fp = C.POINTER(C.c_float)
+    lib.oracle_legacy_ransac.restype = C.c_int
+    lib.oracle_legacy_ransac.argtypes = [fp, fp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), fp, C.c_int, C.c_int, C.c_int, C.c_double,
+                                         C.c_uint64, C.c_uint64, fp, fp, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.POINTER(C.c_int32)]
+    stream = ((int(id_newer) << 32) ^ (int(id_older) & 0xFFFFFFFF) ^ 0x5000000000000000) & 0xFFFFFFFFFFFFFFFF
+    f = lib.oracle_legacy_ransac(pq.ctypes.data_as(fp), pt.ctypes.data_as(fp), _ip(q), _ip(t), d.ctypes.data_as(fp), len(q), int(min_matches),
+                                 int(iterations), float(max_dist), int(seed), stream, T.ctypes.data_as(fp), C.byref(rmse), _ip(inl),
+                                 C.byref(n), _ip(dbg))
+    return bool(f), T.reshape(4, 4), float(rmse.value), inl[:n.value].copy(), tuple(int(v) for v in dbg)
