@@ -278,7 +278,7 @@ def launch_probe(world):
         print(json.dumps({"probe": True, "n_gpus": n}))
 
 
-def config4_leg(steps=50, warmup=5, keyframes=256, device=0):
+def config4_leg(steps=50, warmup=5, keyframes=256, device=0, queries=8):
     """BASELINE.json configs[3], timed in this process: batched loop closure -- ONE query frame against `keyframes` DISTINCT
     key-frame line maps (synthetic trajectory seed 6, launch-file parameters, the map laid out as the RCCL all-gather delivers
     it) in ONE launch per step.  Two timings: all-pairs line matching alone (lf_line_matching_device = Node::lineMatching x 256,
@@ -332,6 +332,43 @@ def config4_leg(steps=50, warmup=5, keyframes=256, device=0):
             out["matches_total"] = int(sum(len(ctx.pair_matches(i)[0]) for i in range(NK)))
         out["matching_and_pose" if pose else "matching_only"] = leg
     ctx.close()
+    # the same map against SEVERAL query frames in one launch (a loop-closure sweep of the newest Q nodes): Q x NK pairs fill the
+    # chip (the single-query shape above is one partial wave of workgroups)
+    try:
+        Q = queries
+        g2, d2, _ = synth.sequence(NK + Q, seed=6)
+        big = capi.Context(640, 480, max_batch=Q * NK, params=P, device=device, stream=st.cuda_stream)
+        dg2, dd2 = torch.from_numpy(g2).cuda(), torch.from_numpy(d2).cuda()
+        big.detect3d_batch_device(dg2.data_ptr(), dd2.data_ptr(), NK + Q, synth.K_TUM, np.arange(NK + Q, dtype=np.uint64))
+        big.synchronize()
+        r2, n2, _ = big.device_records(torch)
+        ext2 = (r2[:NK].contiguous(), n2[:NK].contiguous(), (torch.arange(NK, device="cuda", dtype=torch.int64) + 1000).contiguous())
+        e2 = (ext2[0].data_ptr(), ext2[1].data_ptr(), ext2[2].data_ptr(), NK, big.line_cap)
+        qq = np.repeat(np.arange(NK, NK + Q, dtype=np.int32), NK)
+        tt = np.tile(np.arange(NK, dtype=np.int32), Q)
+        bq = {"queries": Q, "pairs_per_launch": Q * NK}
+        for pose in (False, True):
+            fn = (lambda: big.match_external_device(qq, tt, *e2)) if pose else (lambda: big.line_matching_device(qq, tt, ext=e2))
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ks = max(5, steps // 3)
+            ev[0].record(st)
+            for _ in range(ks):
+                fn()
+            ev[1].record(st)
+            torch.cuda.synchronize()
+            ms = ev[0].elapsed_time(ev[1]) / ks
+            bq["matching_and_pose" if pose else "matching_only"] = {"value": Q * NK / (ms * 1e-3), "unit": "pairs/s", "launch_ms_hip_events": ms}
+            if not pose:
+                algo2 = int(sum(int(n) * (72 + 11) * 8 + int(n) * 12 for n in n2[:NK].cpu().numpy()) * Q + int(n2[NK:NK + Q].sum().item()) * (72 + 11) * 8)
+                bq["matching_only"]["roofline"] = {"bound": "hbm", "kernel": "k_match", "achieved": algo2 / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                                   "unit": "GB/s", "frac": algo2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo2}
+        big.close()
+        out["batched_queries"] = bq
+    except Exception as e:                                # (a side shape: never costs the leg)
+        out["batched_queries"] = {"error": repr(e)}
     return out
 
 
@@ -406,7 +443,7 @@ def main():
                           "config": {"workload": c4["workload"], "lines_per_keyframe": c4["lines_per_keyframe"], "lines_query": c4["lines_query"],
                                      "matches_total": c4["matches_total"]},
                           "roofline": dict(m["roofline"], algorithmic_bytes_per_launch=c4["algorithmic_bytes_per_launch"], kernel_ms=m["launch_ms_hip_events"]),
-                          "with_pose": c4["matching_and_pose"]}))
+                          "with_pose": c4["matching_and_pose"], "batched_queries": c4.get("batched_queries")}))
         return
     # LF_BENCH_FORCE_EXCHANGE=1: run the multi-rank code path (process group, keyframe all-gather, loop-closure
     # matching against the gathered map) even with one rank -- the only way to exercise it on a 1-GPU box
