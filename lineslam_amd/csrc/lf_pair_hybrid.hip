@@ -117,15 +117,12 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
       int i = tid + PT_N * h;
       if (i < np) {
         lf_point_meas pmm; h_pmeas(ws, i, &pmm);
-        lf_point_blocks Bk;
+        // the landmark's blocks are produced in place: a workspace row has the layout of lf_point_blocks (V 9 | W 18 | bl 3 | Hpp 36 | bp 6);
+        // round 4 filled a local struct and copied it (2.5 KB of scratch per lane)
+        lf_point_blocks *Bk = reinterpret_cast<lf_point_blocks *>(ws + WP_B + (size_t)i * 72);
         double p[3] = {ws[WP_L + 3 * i], ws[WP_L + 3 * i + 1], ws[WP_L + 3 * i + 2]};
-        lf_ptmatch_blocks_xp(&X, M.xp, p, &pmm, hd, hub, &Bk);
-        double *o = ws + WP_B + (size_t)i * 72;
-        for (int k = 0; k < 9; k++) o[k] = Bk.V[k];
-        for (int k = 0; k < 18; k++) o[9 + k] = Bk.W[k];
-        for (int k = 0; k < 3; k++) { o[27 + k] = Bk.bl[k]; double a = lf_fabs(Bk.V[4 * k]); if (a > mxl) mxl = a; }
-        for (int k = 0; k < 36; k++) o[30 + k] = Bk.Hpp[k];
-        for (int k = 0; k < 6; k++) o[66 + k] = Bk.bp[k];
+        lf_ptmatch_blocks_xp(&X, M.xp, p, &pmm, hd, hub, Bk);
+        for (int k = 0; k < 3; k++) { double a = lf_fabs(Bk->V[4 * k]); if (a > mxl) mxl = a; }
       }
     }
     __syncthreads();                           // the point blocks are in the workspace
@@ -147,16 +144,8 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
       for (int h = 0; h < HP_SLOT; h++) {
         int i = tid + PT_N * h;
         if (i < np) {
-          lf_point_blocks Bk;
-          const double *o = ws + WP_B + (size_t)i * 72;
-          for (int k = 0; k < 9; k++) Bk.V[k] = o[k];
-          for (int k = 0; k < 18; k++) Bk.W[k] = o[9 + k];
-          for (int k = 0; k < 3; k++) Bk.bl[k] = o[27 + k];
-          double Vi[9], T[36], u[6];
-          if (!lf_ptmatch_eliminate(&Bk, lambda, Vi, T, u)) bad = 1;
-          for (int k = 0; k < 9; k++) ws[WP_VI + (size_t)i * 9 + k] = Vi[k];
-          for (int k = 0; k < 36; k++) ws[WP_TU + (size_t)i * 42 + k] = T[k];
-          for (int k = 0; k < 6; k++) ws[WP_TU + (size_t)i * 42 + 36 + k] = u[k];
+          const lf_point_blocks *Bk = reinterpret_cast<const lf_point_blocks *>(ws + WP_B + (size_t)i * 72);
+          if (!lf_ptmatch_eliminate(Bk, lambda, ws + WP_VI + (size_t)i * 9, ws + WP_TU + (size_t)i * 42, ws + WP_TU + (size_t)i * 42 + 36)) bad = 1;
         }
       }
       __syncthreads();                         // the points' T | u rows are in the workspace: subtracted first, then the lines'
@@ -182,14 +171,10 @@ __device__ void h_refine(HShared &S, const HCtx &pc, const int *pset, int np, co
         for (int h = 0; h < HP_SLOT; h++) {
           int i = tid + PT_N * h;
           if (i < np) {
-            lf_point_blocks Bk;
-            const double *o = ws + WP_B + (size_t)i * 72;
-            for (int k = 0; k < 18; k++) Bk.W[k] = o[9 + k];
-            for (int k = 0; k < 3; k++) Bk.bl[k] = o[27 + k];
-            double Vi[9], dl[3], pn[3], s = 0;
-            for (int k = 0; k < 9; k++) Vi[k] = ws[WP_VI + (size_t)i * 9 + k];
-            lf_ptmatch_backsub(&Bk, Vi, dp, dl);
-            for (int k = 0; k < 3; k++) { pn[k] = ws[WP_L + 3 * i + k] + dl[k]; ws[WP_LN + 3 * i + k] = pn[k]; s += dl[k] * (lambda * dl[k] + Bk.bl[k]); }
+            const lf_point_blocks *Bk = reinterpret_cast<const lf_point_blocks *>(ws + WP_B + (size_t)i * 72);
+            double dl[3], pn[3], s = 0;
+            lf_ptmatch_backsub(Bk, ws + WP_VI + (size_t)i * 9, dp, dl);
+            for (int k = 0; k < 3; k++) { pn[k] = ws[WP_L + 3 * i + k] + dl[k]; ws[WP_LN + 3 * i + k] = pn[k]; s += dl[k] * (lambda * dl[k] + Bk->bl[k]); }
             lf_point_meas pmm; h_pmeas(ws, i, &pmm);
             M.red[0][i] = s;
             M.red[1][i] = lf_ptmatch_chi2(&Xn, pn, &pmm, hd, hub);
