@@ -233,7 +233,9 @@ const char *lf_status_str(int s) {
     default: return "unknown status";
   }
 }
-const char *lf_last_error(const lf_ctx *c) { return c ? c->err.c_str() : ""; }
+// lf_last_error(NULL): the message of the last lf_ctx_create* that FAILED on this thread (its context is gone with its message)
+static thread_local std::string g_create_err;
+const char *lf_last_error(const lf_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------
@@ -508,7 +510,8 @@ int lf_ctx_create_caps(lf_ctx **out, int device, void *hip_stream, int width, in
     if ((r = alloc_lsd(c)) != LF_OK) break;
     if ((r = upload_lsd_tables(c)) != LF_OK) break;
   } while (0);
-  if (r != LF_OK) { lf_ctx_destroy(c); return r; }
+  if (r != LF_OK) { g_create_err = c->err; lf_ctx_destroy(c); return r; }
+  g_create_err.clear();
   *out = c;
   return LF_OK;
 }

@@ -13,7 +13,9 @@
 #define LF_RANSAC_MAX_ITERS 1024  // sample table capacity
 #define LF_MOTION_STRIDE 16
 #define LF_MAX_PT_MATCHES 512     // point matches per pair handled by the hybrid pose kernel (8 per lane)
-#define LF_PAIR_WS_DOUBLES (LF_MAX_MATCHES * 48 + 8)   // per pair: the matches' compact measurements (48 doubles each) + the RANSAC winner
+// per pair: the matches' compact measurements (48 doubles each) + the RANSAC winner (8 + 8: record, float model) + the blocks of
+// the wavefront-per-pair refinement (lf_pose_wave.h: V | W | bl 78, the columns of Vi 36, two landmark sets 12 per match)
+#define LF_PAIR_WS_DOUBLES (LF_MAX_MATCHES * (48 + 78 + 36 + 12) + 16)
 
 struct PairConsts {
   lf_params P;

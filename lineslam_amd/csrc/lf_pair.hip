@@ -15,8 +15,10 @@
 #include "lf_pair.h"
 #include "lf_pose.h"
 #include <float.h>
+#include <stdlib.h>
 #include "lf_pose_wg.h"
 #include "lf_pose_res.h"
+#include "lf_pose_wave.h"
 
 // ------------------------------------------------------------------------------ k_match
 __device__ __forceinline__ double m_pt_line2d(const double *p, const double *l) {   // utils.cpp:1250-1264
@@ -521,6 +523,12 @@ __global__ void __launch_bounds__(RS_N) k_ransac(PairConsts c, PairBuffers b) {
     const int best = my_cnt > 0 ? my_it : -1;
     win[0] = best; win[1] = my_cnt > 0 ? my_cnt : 0;
     for (int s = 0; s < 3; s++) win[2 + s] = best >= 0 ? S.smp[3 * best + s] : 0;
+    if (best >= 0) {   // the winning model once more, for the wavefront-per-pair refinement (it re-scores it; r_model needs ~190 registers)
+      float tf[16], *wtf = (float *)(cm + WV_OFF_TF);
+      const int s3[3] = {S.smp[3 * best], S.smp[3 * best + 1], S.smp[3 * best + 2]};
+      r_model(s3, cm, tf);
+      for (int i = 0; i < 16; i++) wtf[i] = tf[i];
+    }
   }
 }
 
@@ -629,6 +637,101 @@ __global__ void __launch_bounds__(RT_N) LF_POSE_ATTR k_pose(PairConsts c, PairBu
   }
 }
 
+// ------------------------------------------------------------------------------ k_pose_w (round 6: the default refinement stage)
+// The same stage as k_pose with WV_W low-footprint wavefronts per pair (lf_pose_wave.h): <= 128 registers and ~8 KB of LDS each, so that
+// its wavefronts are placed beside the front end's instead of waiting for empty compute units.  Results are bit-identical to
+// k_pose (which stays selectable: LF_POSE_RES=1 in the environment).
+#ifndef LF_POSEW_WAVES
+#define LF_POSEW_WAVES 4        // 512 / 4 = 128 registers: the budget of the kernel and of every phase it calls
+#endif
+__device__ __forceinline__ void w_pair(WaveShared &S, const PairConsts &c, const PairBuffers &b) {
+  const int pr = blockIdx.x, tid = threadIdx.x;
+  const int fq = w_uni(b.pair_q[pr]), ft = w_uni(b.pair_t[pr]);   // (loaded by every lane alike: scalar from here on)
+  lf_pair_result *res = b.results + pr;
+  double *ws = b.ws + (size_t)pr * LF_PAIR_WS_DOUBLES;
+  const double *cm = ws;                                          // [nLn][R_CM], laid down by k_ransac
+  const int *win = (const int *)(cm + R_WIN_OFF);
+  const lf_params &P = c.P;
+  const PoseGate g = r_gate(c, b, pr, fq, ft);
+  const int nLn = w_uni(g.nLn), n_all = w_uni(g.n_all), lw = w_uni(g.lw), min_inlier = w_uni(g.min_inlier);
+  const int id_t = w_uni((int)g.id_t), id_q = w_uni((int)g.id_q);     // (the result record keeps them as int)
+  const bool go = w_uni((int)g.go) != 0;
+  float rmse_out = 1e9f;
+  int valid = 0, n_inl = 0, best_iter = -1, rounds = 0;
+  bool have_tf = false;                       // (the transform stays in S.tf: nothing of it is live across the phases' calls)
+  const double thr = P.max_mah_dist_for_inliers;
+  if (go) {
+    best_iter = w_uni(win[0]);
+    const int nbest = w_uni(win[1]);
+    if (0 + nbest >= 3) {                                                                    // :725-728
+      float sse_best = 0;
+      const float *wtf = (const float *)(cm + WV_OFF_TF);       // the winning model (k_ransac), re-scored for its inlier list / sse
+      if (tid < 16) S.tf[tid] = wtf[tid];
+      w_order();
+      double refined_rmse = 0;
+      int nref = 0;
+      int *inl = b.inliers + (size_t)pr * LF_MAX_MATCHES;
+      // round -1: the refinement of the RANSAC winner's inliers (25 iterations, :730); rounds 0..19: the re-scoring loop (:775-839)
+      for (int iter = -1; iter < 20; ++iter) {
+        int nset;
+        if (iter < 0) {
+          nset = w_uni(w_score(S, cm, nLn, thr, 0));
+          sse_best = S.sse_f;
+          refined_rmse = lf_sqrt(sse_best / (0 + nset));                                       // :731
+        } else {
+          const int ncur = w_uni(w_score(S, cm, nLn, thr, 1));                                   // into a scratch list first (kept only if it improves)
+          const double tmp_sse = S.sse_d;
+          if (!(0 + ncur * lw > 0 + nref * lw)) break;
+          for (int i = tid; i < ncur; i += WV_T) { S.set[i] = S.idx[i]; inl[i] = S.idx[i]; }
+          w_order();
+          nref = ncur;
+          refined_rmse = lf_sqrt(tmp_sse / (0 + ncur));
+          rounds++;
+          nset = nref;
+        }
+        w_refine(S, ws, P.g2o_line_error_weight, P.g2o_BA_kernel_delta, P.g2o_BA_use_kernel, nset, iter < 0 ? 25 : 20);
+      }
+      n_inl = nref;
+      rmse_out = (float)refined_rmse;
+      have_tf = true;
+      valid = ((0 + lw * nref) >= min_inlier) ? 1 : 0;
+    }
+  }
+  if (tid == 0) {
+    for (int i = 0; i < 16; i++) res->T[i] = have_tf ? S.tf[i] : ((i % 5 == 0) ? 1.0f : 0.0f);
+    res->rmse = rmse_out;
+    res->valid = valid;
+    res->n_matches = n_all;
+    res->n_inliers = n_inl;
+    res->n_point_matches = 0;
+    res->n_point_inliers = 0;
+    res->id_older = valid ? id_t : -1;             // node.cpp:1606-1607
+    res->id_newer = valid ? id_q : -1;
+    res->ransac_best_iter = best_iter;
+    res->refine_rounds = rounds;
+    float r2 = rmse_out * rmse_out;                                   // float arithmetic as node.cpp:1533-1534
+    res->information_scale = valid ? (double)((float)(0 + n_inl * lw) / r2) : 0.0;
+    res->overflow = ((n_all > c.match_cap || n_all > LF_MAX_MATCHES) ? LF_OVF_MATCHES : 0) |
+                    ((b.nlines[fq] > c.line_cap || b.nlines_t[ft] > (b.line_cap_t < c.line_cap ? b.line_cap_t : c.line_cap)) ? LF_OVF_LINES : 0);
+    res->reserved_ = 0;
+  }
+}
+
+// (waves-per-SIMD 4 = the 128-register budget, inherited by every phase; with 16.3 KB of LDS per pair the compiler's occupancy
+// estimate is 3 and it says so: the budget is what is wanted, not the fourth wavefront)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"
+__global__ void __launch_bounds__(WV_T, LF_POSEW_WAVES) k_pose_w(PairConsts c, PairBuffers b) {
+  __shared__ WaveShared S;
+  w_pair(S, c, b);
+}
+#pragma clang diagnostic pop
+
+static bool pose_resident_selected() {          // LF_POSE_RES=1: the resident workgroup-per-pair k_pose of rounds 2-5 (A/B on one box)
+  static const bool v = [] { const char *e = getenv("LF_POSE_RES"); return e && e[0] == '1'; }();
+  return v;
+}
+
 void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t st, int solver, bool run_match) {
   if (run_match) hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(MT_N), 0, st, c, b);
   if (solver == LF_SOLVER_NONE) return;
@@ -637,6 +740,7 @@ void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipS
   else {
 #ifndef LF_EXP_SKIP_POSE   // (throughput experiments only)
     hipLaunchKernelGGL(k_ransac, dim3(n_pairs), dim3(RS_N), 0, st, c, b);
+    if (!pose_resident_selected()) { hipLaunchKernelGGL(k_pose_w, dim3(n_pairs), dim3(WV_T), 0, st, c, b); return; }
 #ifdef LF_POSE_WAVES
     static bool attr_set = false;
     if (!attr_set) { hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PoseShared)); attr_set = true; }
