@@ -52,6 +52,36 @@ def _latest_profile(suffix):
     return os.path.join(d, c[-1]) if c else None
 
 
+def csrc_sha256():
+    """sha256 over lineslam_amd/csrc (file names + contents, sorted): what the committed counter profiles are stamped with
+    (tools/valu_summary.py, tools/pmc_summary.py write it); a profile measured on other sources is reported as stale."""
+    import hashlib
+    d = os.path.join(ROOT, "lineslam_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def clock_calibration():
+    """tools/micro/clock.hip (built by lineslam_amd/build.py): ~50 ms of a dependent v_fma_f64 chain on one wavefront (its ns per
+    fma = the shader clock this box really runs) and ~25 ms of independent fma on the whole chip (TFLOP/s fp64).  The same code
+    measures 9.2 k frames/s on one box of the pool and 9.7 k on another; these two numbers say whether a box is slow or the code is."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "micro", "clock_cal")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "--short"], capture_output=True, text=True, timeout=60).stdout
+        j = json.loads(out.strip().splitlines()[-1])
+        j["source"] = "tools/micro/clock.hip --short"
+        return j
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +118,7 @@ def parse():
                     help="ONLY BASELINE configs[3] (1 query frame vs 256 key-frame line maps, one launch per step): prints its own line, "
                          "metric loop-closure pairs/s; without the flag the default line carries the same measurement as its `config4` object")
     ap.add_argument("--no-config4", action="store_true", help="leave the config4 leg out of the default line")
+    ap.add_argument("--no-legs", action="store_true", help="leave the config3 / edlines / latency legs out of the default line")
     ap.add_argument("--default-params", action="store_true",
                     help="ParameterServer defaults (lsd_angle_thres 22.5, min_matches 20) instead of the shipped "
                          "launch/lineslam.launch values (40, 10), which are what the reference actually runs with")
@@ -372,6 +403,135 @@ def config4_leg(steps=50, warmup=5, keyframes=256, device=0, queries=8):
     return out
 
 
+def side_leg(kind, gray, depth, device, steps=4, warmup=2, nfl=4):
+    """A BASELINE configuration that is not the headline, timed in this process on the headline's frames, pipelined as the
+    headline (`nfl` passes in flight), inputs resident:
+      "config3"  BASELINE configs[2]: fused point + line odometry -- ORB (600 key points, second HIP stream) + projectTo3D +
+                 Hamming feature matching + the hybrid RANSAC / LM solver next to the line front end (src/node.cpp:1504-1530)
+      "edlines"  line_detect_algorithm = EDLINES (src/line/lineslam.cpp:225-235) instead of LSD, otherwise the headline workload
+    Returns ms_per_step, frames/s, stage_ms of the last timed pass of every context and the issue-rate roofline."""
+    import torch
+    from lineslam_amd import capi, synth
+    F = len(gray)
+    K = synth.K_TUM
+    P = capi.default_params(launch=True)
+    if kind == "edlines":
+        P.line_detector = 1
+    streams = [torch.cuda.Stream() for _ in range(nfl)]
+    ctxs = []
+    for st in streams:
+        if ctxs:
+            held, free_b, _ = ctxs[0].device_bytes()
+            if free_b < 1.1 * held:
+                break
+        ctxs.append(capi.Context(640, 480, max_batch=F, params=P, device=device, stream=st.cuda_stream))
+    nfl = len(ctxs)
+    dg, dd = torch.from_numpy(gray).cuda(), torch.from_numpy(depth).cuda()
+    ids = np.arange(F, dtype=np.uint64)
+    pq, pt = np.arange(1, F, dtype=np.int32), np.arange(0, F - 1, dtype=np.int32)
+    NK = 600
+    pts_state = None
+    if kind == "config3":
+        for c in ctxs:
+            c.point_stream(True)
+        pts_state = [dict(kp=torch.zeros((F, NK, 2), dtype=torch.float32, device="cuda"), desc=torch.zeros((F, NK, 32), dtype=torch.uint8, device="cuda"),
+                          nkp=torch.zeros(F, dtype=torch.int32, device="cuda"), pts=torch.zeros((F, NK, 4), dtype=torch.float32, device="cuda"),
+                          npts=torch.zeros(F, dtype=torch.int32, device="cuda"), kept=torch.zeros((F, NK), dtype=torch.int32, device="cuda"),
+                          mq=torch.zeros((F, NK), dtype=torch.int32, device="cuda"), mt=torch.zeros((F, NK), dtype=torch.int32, device="cuda"),
+                          md=torch.zeros((F, NK), dtype=torch.float32, device="cuda"), nm=torch.zeros(F, dtype=torch.int32, device="cuda")) for _ in ctxs]
+
+    def step(i):
+        c, st = ctxs[i % nfl], streams[i % nfl]
+        with torch.cuda.stream(st):
+            if kind == "config3":
+                ps = pts_state[i % nfl]
+                c.orb_extract_device(dg.data_ptr(), dd.data_ptr(), F, ps["kp"].data_ptr(), ps["desc"].data_ptr(), ps["nkp"].data_ptr(), NK,
+                                     fast_threshold=20, max_keypoints=NK)
+                c.project_keypoints_device(dd.data_ptr(), F, ps["kp"].data_ptr(), ps["nkp"].data_ptr(), NK, K, ps["pts"].data_ptr(),
+                                           ps["npts"].data_ptr(), ps["kept"].data_ptr(), max_keypoints=NK)
+            c.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), F, K, ids)
+            if kind == "config3":
+                c.point_join()
+                ps["dsel"] = torch.gather(ps["desc"], 1, ps["kept"].long().clamp_(0, NK - 1).unsqueeze(-1).expand(-1, -1, 32)).contiguous()
+                c.feature_match_pairs_device(ps["dsel"].data_ptr(), ps["npts"].data_ptr(), NK, pq, pt, ps["mq"].data_ptr(),
+                                             ps["mt"].data_ptr(), ps["md"].data_ptr(), ps["nm"].data_ptr(), nn_distance_ratio=0.75)
+                c.match_pairs_hybrid_device_pm(pq, pt, ps["pts"].data_ptr(), NK, ps["mq"].data_ptr(), ps["mt"].data_ptr(),
+                                               ps["nm"].data_ptr(), NK, K)
+            else:
+                c.match_pairs_device(pq, pt)
+    for i in range(max(warmup, nfl)):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    used = ctxs[:min(nfl, steps)]
+    stage = {k: float(np.mean([c.stage_ms(j) for c in used])) for j, k in enumerate(("detector_data_parallel", "lsd_sweep", "lines3d_msld_mle", "match_pose"))}
+    res = [ctxs[(steps - 1) % nfl].pair_result(i, allow_overflow=True) for i in range(0, F - 1, max(1, (F - 1) // 64))]
+    out = {"workload": ("BASELINE configs[2]: ORB (600 key points) + projectTo3D + Hamming matching + hybrid point / line RANSAC + joint LM, next to the line front end"
+                        if kind == "config3" else "line_detect_algorithm = EDLINES: the EDLines detector instead of LSD, then the headline's 3D / MSLD / MLE / match / pose"),
+           "frames": F, "steps": steps, "warmup": max(warmup, nfl), "passes_in_flight": nfl, "ms_per_step": dt / steps * 1e3, "value": F * steps / dt, "unit": "frames/s",
+           "stage_ms": stage, "valid_pairs_of_sample": int(sum(1 for r in res if r.valid)), "pairs_sampled": len(res)}
+    if kind == "config3":
+        out["point_matches_per_pair"] = float(np.mean([r.n_point_matches for r in res]))
+        out["point_inliers_per_pair"] = float(np.mean([r.n_point_inliers for r in res]))
+        out["line_inliers_per_pair"] = float(np.mean([r.n_inliers for r in res]))
+    for c in ctxs:
+        c.close()
+    return out
+
+
+def latency_leg(gray, depth, P, device, cpu_ms_per_frame=None):
+    """The plug-in shape (INTEGRATION.md: Node::Node -> lf_detect3d, Node::matchNodePair -> lf_match_node_pair, src/node.cpp:208-215,
+    1494-1615): wall-clock latency of ONE call with host buffers in and host records / results out, and of small batches
+    (B = 8, 64: lf_detect3d_batch_device on resident frames + lf_match_pairs_device of the B - 1 odometry pairs + read-back).  A small
+    batch runs the multi-wavefront sweep k_lsd_sweep_mw<W> (W chosen by the library from B: 8 wavefronts per frame up to 160
+    frames, the one-wavefront sweep above); a frame's sweep is a dependent chain, so B = 1 is latency-, not throughput-sized."""
+    import torch
+    from lineslam_amd import capi, synth
+    K = synth.K_TUM
+    out = {"sweep_wavefronts_per_frame": "8 (k_lsd_sweep_mw<8>) for B <= 160 frames, 1 (k_lsd_sweep) above: chosen by the library from the batch size"}
+    ctx = capi.Context(640, 480, max_batch=2, params=P, device=device)
+    ctx.detect3d(gray[0], depth[0], K, frame_id=0)           # set-up (tables, lazy allocations) outside the timed calls
+    t, recs = [], []
+    for k in range(1, 7):
+        t0 = time.perf_counter()
+        recs.append(ctx.detect3d(gray[k], depth[k], K, frame_id=k))
+        t.append(time.perf_counter() - t0)
+    tm = []
+    for k in range(1, len(recs)):
+        t0 = time.perf_counter()
+        ctx.match_node_pair(recs[k], k + 1, recs[k - 1], k, allow_overflow=True)
+        tm.append(time.perf_counter() - t0)
+    ctx.close()
+    out["B1"] = {"lf_detect3d_ms": float(np.median(t) * 1e3), "lf_match_node_pair_ms": float(np.median(tm) * 1e3),
+                 "frame_plus_pair_ms": float((np.median(t) + np.median(tm)) * 1e3), "calls": len(t),
+                 "note": "host grey + depth in, records out; host records in, pair result out (median of the calls)"}
+    if cpu_ms_per_frame:
+        out["B1"]["cpu_port_single_thread_ms_per_frame_and_pair"] = cpu_ms_per_frame
+    for B in (8, 64):
+        c = capi.Context(640, 480, max_batch=B, params=P, device=device)
+        dg, dd = torch.from_numpy(gray[:B]).cuda(), torch.from_numpy(depth[:B]).cuda()
+        ids = np.arange(B, dtype=np.uint64)
+        pq, pt = np.arange(1, B, dtype=np.int32), np.arange(0, B - 1, dtype=np.int32)
+        ts = []
+        for rep in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            c.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), B, K, ids)
+            c.match_pairs_device(pq, pt)
+            c.synchronize()
+            r = [c.pair_result(i, allow_overflow=True) for i in range(B - 1)]
+            ts.append(time.perf_counter() - t0)
+        out["B%d" % B] = {"batch_ms": float(np.median(ts[1:]) * 1e3), "ms_per_frame": float(np.median(ts[1:]) * 1e3 / B),
+                          "stage_ms": {k: c.stage_ms(j) for j, k in enumerate(("lsd_data_parallel", "lsd_sweep", "lines3d_msld_mle", "match_pose"))},
+                          "note": "resident frames in, %d pair results read back; one call sequence, nothing else in flight" % (B - 1)}
+        c.close()
+    return out
+
+
 ROT_BUDGET_RAD, TRANS_BUDGET_M = 1e-4, 1e-3     # BASELINE.json north_star: SE(3) pose within 1e-4 rad / 1e-3 m
 
 
@@ -465,6 +625,7 @@ def main():
         build.build()
     if dist_on:
         dist.barrier()
+    clock_cal = clock_calibration() if (rank == 0 and world == 1) else None     # (on the idle chip, before anything is allocated)
     if strong and a.points:
         raise SystemExit("bench.py: --scaling strong runs the headline (lines-only) workload")
     P = capi.default_params(launch=not a.default_params)
@@ -481,25 +642,18 @@ def main():
     F = len(gray)                                        # frames this rank processes per step
     nfl = max(1, a.inflight)
     streams = [torch.cuda.Stream() for _ in range(nfl)]
+    # HIP binds a stream to one of its few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) at the stream's FIRST use: the pass
+    # streams take theirs now, in order, before anything else (the null stream's uploads, the set-up pass) claims one -- two passes
+    # sharing a hardware queue run one after the other (measured: 143 instead of 122 ms per step)
+    for st in streams:
+        with torch.cuda.stream(st):
+            torch.zeros(1, device="cuda")
+    torch.cuda.synchronize()
     # residency: everything of a batch stays in HBM; the first context says what one costs, every further one in flight is
     # created only if the device still has room for it (with 10 % to spare) -- a sequence too long for `nfl` batches in flight
     # runs with fewer, and the line says so (config.passes_in_flight, residency)
     ctxs = [capi.Context(640, 480, max_batch=F, params=P, device=local, stream=streams[0].cuda_stream)]
-    ctx_bytes = ctxs[0].device_bytes()[0]
-    for st in streams[1:]:
-        held, free_b, total_b = ctxs[0].device_bytes()
-        if free_b < 1.1 * ctx_bytes:
-            print("bench: %.1f GB free, a batch needs %.1f GB: %d passes in flight instead of %d" % (free_b / 1e9, ctx_bytes / 1e9, len(ctxs), nfl), file=sys.stderr)
-            break
-        ctxs.append(capi.Context(640, 480, max_batch=F, params=P, device=local, stream=st.cuda_stream))
-    nfl = len(ctxs)
-    streams = streams[:nfl]
-    residency = {"bytes_per_context": int(ctx_bytes), "contexts": nfl, "device_total_bytes": int(ctxs[0].device_bytes()[2]),
-                 "bytes_per_frame": int(ctx_bytes // max(F, 1))}
     ctx = ctxs[0]
-    if a.points and not a.serial_points:
-        for c in ctxs:
-            c.point_stream(True)
     dg, dd = torch.from_numpy(gray).cuda(), torch.from_numpy(depth).cuda()
     torch.cuda.synchronize()
     if strong:
@@ -512,20 +666,59 @@ def main():
     # keyframe line maps for the loop-closure exchange (config 5): fixed-stride records, one all-gather per step
     kf = (plan["kf_local"] if strong else parallel.pick_keyframes(F, a.keyframes)) if dist_on else None
 
-    pts_state = None
-    if a.points:
-        NK = 600          # max_keypoints (launch/lineslam.launch:14); key points and descriptors come from the ORB extractor
-        pts_state = []
-        for _ in range(nfl):
-            pts_state.append(dict(
+    pts_state = {}
+    NK = 600              # max_keypoints (launch/lineslam.launch:14); key points and descriptors come from the ORB extractor
+    orb_adj = capi.orb_adjuster(max_keypoints=NK, max_iters=max(1, a.adjuster_iters)) if a.points else None
+
+    def points_of(c):     # the point-side buffers of one context (created with it)
+        if id(c) not in pts_state:
+            if not a.serial_points:
+                c.point_stream(True)
+            pts_state[id(c)] = dict(
                 kp=torch.zeros((F, NK, 2), dtype=torch.float32, device="cuda"), desc=torch.zeros((F, NK, 32), dtype=torch.uint8, device="cuda"),
                 nkp=torch.zeros(F, dtype=torch.int32, device="cuda"),
                 pts=torch.zeros((F, NK, 4), dtype=torch.float32, device="cuda"), npts=torch.zeros(F, dtype=torch.int32, device="cuda"),
                 kept=torch.zeros((F, NK), dtype=torch.int32, device="cuda"),
                 mq=torch.zeros((F, NK), dtype=torch.int32, device="cuda"), mt=torch.zeros((F, NK), dtype=torch.int32, device="cuda"),
                 md=torch.zeros((F, NK), dtype=torch.float32, device="cuda"), nm=torch.zeros(F, dtype=torch.int32, device="cuda"),
-                thr=torch.zeros(F, dtype=torch.int32, device="cuda")))
-        orb_adj = capi.orb_adjuster(max_keypoints=NK, max_iters=max(1, a.adjuster_iters))
+                thr=torch.zeros(F, dtype=torch.int32, device="cuda"))
+        return pts_state[id(c)]
+
+    # residency: everything of a batch stays in HBM.  The first context runs one set-up pass of the configured path (so that the
+    # buffers allocated on first use are counted: point side, staging), then says what a batch costs; every further context in
+    # flight is created only if the device still has room for it (with 10 % to spare) -- a sequence too long for `nfl` batches in
+    # flight runs with fewer, and the line says so (config.passes_in_flight, residency)
+    def setup_pass(c):
+        with torch.cuda.stream(streams[0]):
+            if a.points:
+                stp = points_of(c)
+                c.orb_extract_device(dg.data_ptr(), dd.data_ptr(), F, stp["kp"].data_ptr(), stp["desc"].data_ptr(), stp["nkp"].data_ptr(), NK,
+                                     fast_threshold=20, max_keypoints=NK)
+                c.project_keypoints_device(dd.data_ptr(), F, stp["kp"].data_ptr(), stp["nkp"].data_ptr(), NK, K, stp["pts"].data_ptr(),
+                                           stp["npts"].data_ptr(), stp["kept"].data_ptr(), max_keypoints=NK)
+            c.detect3d_batch_device(dg.data_ptr(), dd.data_ptr(), F, K, ids)
+            if a.points:
+                c.point_join()
+                dsel = torch.gather(stp["desc"], 1, stp["kept"].long().clamp_(0, NK - 1).unsqueeze(-1).expand(-1, -1, 32)).contiguous()
+                c.feature_match_pairs_device(dsel.data_ptr(), stp["npts"].data_ptr(), NK, pq, pt, stp["mq"].data_ptr(), stp["mt"].data_ptr(),
+                                             stp["md"].data_ptr(), stp["nm"].data_ptr(), nn_distance_ratio=0.75)
+                c.match_pairs_hybrid_device_pm(pq, pt, stp["pts"].data_ptr(), NK, stp["mq"].data_ptr(), stp["mt"].data_ptr(), stp["nm"].data_ptr(), NK, K)
+            elif len(pq):
+                c.match_pairs_device(pq, pt)
+        torch.cuda.synchronize()
+    free_before = ctxs[0].device_bytes()[1] + ctxs[0].device_bytes()[0]
+    setup_pass(ctxs[0])
+    ctx_bytes = max(ctxs[0].device_bytes()[0], free_before - ctxs[0].device_bytes()[1])     # library allocations + this context's torch buffers
+    for st in streams[1:]:
+        held, free_b, total_b = ctxs[0].device_bytes()
+        if free_b < 1.1 * ctx_bytes:
+            print("bench: %.1f GB free, a batch needs %.1f GB: %d passes in flight instead of %d" % (free_b / 1e9, ctx_bytes / 1e9, len(ctxs), nfl), file=sys.stderr)
+            break
+        ctxs.append(capi.Context(640, 480, max_batch=F, params=P, device=local, stream=st.cuda_stream))
+    nfl = len(ctxs)
+    streams = streams[:nfl]
+    residency = {"bytes_per_context": int(ctx_bytes), "contexts": nfl, "device_total_bytes": int(ctxs[0].device_bytes()[2]),
+                 "bytes_per_frame": int(ctx_bytes // max(F, 1)), "measured": "after one set-up pass of the configured path (lazily allocated buffers included)"}
 
     n_lc = min(64, F)   # loop-closure queries per step on every rank (config 4 style: local frames vs all keyframes)
     lc_q, lc_t = parallel.loop_closure_pairs(n_lc, F - 1, world, len(kf)) if dist_on else (None, None)
@@ -571,7 +764,7 @@ def main():
 
     def step_on(ctx):
         if a.points:
-            st = pts_state[ctxs.index(ctx)]
+            st = points_of(ctx)
             # Node::Node, ORB branch: AORB detection + removeDepthless + retainBest(600) + ORB descriptors, on the device -- on the
             # context's point stream, beside the line front end issued right after it (node.cpp:208-217: two threads)
             if a.adjuster_iters > 0:     # every pass starts the sequence again: the adapter starts from its initial threshold
@@ -774,7 +967,7 @@ def main():
         est = ate.chain_odometry(Ts, valid)
         gt = np.linalg.inv(poses[0])[None] @ poses
         point_stats = {"detector": ("AORB behind VideoDynamicAdaptedFeatureDetector (adjuster_max_iterations %d): thresholds %d..%d, mean %.1f" % (
-                           a.adjuster_iters, int(pts_state[0]["thr"].min()), int(pts_state[0]["thr"].max()), float(pts_state[0]["thr"].float().mean())))
+                           a.adjuster_iters, int(points_of(ctxs[0])["thr"].min()), int(points_of(ctxs[0])["thr"].max()), float(points_of(ctxs[0])["thr"].float().mean())))
                        if a.adjuster_iters > 0 else "AORB at the adjuster's start threshold 20 (adjuster_max_iterations 0, the default)",
                        "point_matches_per_pair": float(np.mean([r.n_point_matches for r in res])),
                        "point_inliers_per_pair": float(np.mean([r.n_point_inliers for r in res])),
@@ -815,6 +1008,15 @@ def main():
                         "wave_wait_frac": {k: round(v["wave_wait_frac"], 3) for k, v in vj.items() if k.startswith(("k_lsd_sweep", "k_mle", "k_pose"))}}
             except Exception:
                 valu = None
+        sha_now = csrc_sha256()
+        stale = None
+        if vpath:
+            try:
+                stale = json.load(open(vpath)).get("csrc_sha256") != sha_now     # (the counter passes were measured on other kernel sources)
+            except Exception:
+                stale = None
+        if valu_issue is not None:
+            valu_issue["stale"] = stale
         algo = SWEEP_BYTES_PER_FRAME * F
         achieved = algo / (sw * 1e-3) / 1e9
         fe_bytes = ALGO_BYTES_PER_FRAME * F
@@ -839,21 +1041,31 @@ def main():
                        "per segment (3D fit), per pair (pose); %d passes in flight on separate HIP streams" % nfl +
                        (("; %d ranks share ONE sequence in round-robin blocks, 1 all-gather of %d block-boundary line maps per rank and step (%s carrier)" if strong else
                          "; %d ranks, 1 sequence each, 1 all-gather of %d key-frame maps per step (%s carrier)") % (world, len(kf), carrier) if dist_on else "")},
-            "roofline": {"bound": "hbm", "kernel": "k_lsd_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel_ms": sw, "algorithmic_bytes_per_launch": algo,
-                         "kernel_ms_one_pass_in_flight": (serial or {}).get("stage_ms", {}).get("lsd_sweep"),
-                         "frac_one_pass_in_flight": (algo / ((serial["stage_ms"]["lsd_sweep"]) * 1e-3) / 1e9 / HBM_PEAK_GBS) if serial else None,
-                         # the whole front end (LSD data-parallel + sweep + 3D lines / MSLD / MLE) against SURVEY 8(d)'s 25.3 MB per frame
-                         "front_end": ({"algorithmic_bytes_per_pass": fe_bytes, "ms_one_pass_in_flight": fe_ms,
-                                        "achieved": fe_bytes / (fe_ms * 1e-3) / 1e9, "frac": fe_bytes / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                                       if fe_ms else None),
-                         "valu": valu, "valu_issue": valu_issue, "bound_by_counters": bound_by_kernel,
-                         "binding_wall": "fp64 VALU issue + dependent-chain latency (see valu_issue; HBM is at ~3 % of peak over the whole path and binds nowhere)",
-                         "note": "the sweep is charged its OWN algorithmic bytes (angles + modgrad read once, used read + written: 3.54 MB per "
-                                 "frame); it is a dependent chain per frame, bound by the latency of its gathers (56 % of its wave cycles "
-                                 "wait on memory, SQ_WAIT_ANY), so the HBM fraction is small by construction; kernel_ms is its HIP-event "
-                                 "duration in the timed region, where it shares the chip with the other passes in flight"},
+            "roofline": {
+                # what binds the step, from this run's clock: the chip's VALUs must ISSUE one pass's wave instructions (counted by
+                # SQ_INSTS_VALU in the committed counter profile of these sources) -- fp64 VALU issue + the dependent chains that
+                # keep the issue slots from being filled; HBM binds nowhere (sub-object `hbm`: the dominant kernel against 8 TB/s)
+                "bound": "valu+latency", "kernel": "whole pass (k_lsd_sweep, k_mle, k_pose_w, k_line3d ...)",
+                "achieved": (valu_issue["valu_wave_insts_per_pass"] / (ms_per_step * 1e-3) / 1e9) if valu_issue else None,
+                "peak": 1024 * SCLK_GHZ / 4.0, "unit": "G wave-instr/s",
+                "frac": valu_issue["frac"] if valu_issue else None,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "counters_stale": stale, "csrc_sha256": sha_now,
+                "hbm": {"bound": "hbm", "kernel": "k_lsd_sweep", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": sw, "algorithmic_bytes_per_launch": algo,
+                        "kernel_ms_one_pass_in_flight": (serial or {}).get("stage_ms", {}).get("lsd_sweep"),
+                        "frac_one_pass_in_flight": (algo / ((serial["stage_ms"]["lsd_sweep"]) * 1e-3) / 1e9 / HBM_PEAK_GBS) if serial else None,
+                        # the whole front end (LSD data-parallel + sweep + 3D lines / MSLD / MLE) against SURVEY 8(d)'s 25.3 MB per frame
+                        "front_end": ({"algorithmic_bytes_per_pass": fe_bytes, "ms_one_pass_in_flight": fe_ms,
+                                       "achieved": fe_bytes / (fe_ms * 1e-3) / 1e9, "frac": fe_bytes / (fe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                      if fe_ms else None),
+                        "note": "the sweep is charged its OWN algorithmic bytes (angles + modgrad read once, used read + written: 3.54 MB per "
+                                "frame); it is a dependent chain per frame, bound by the latency of its gathers, so the HBM fraction is small "
+                                "by construction; kernel_ms is its HIP-event duration in the timed region, where it shares the chip with the "
+                                "other passes in flight"},
+                "valu": valu, "valu_issue": valu_issue, "bound_by_counters": bound_by_kernel,
+                "clock_calibration": clock_cal,
+                "binding_wall": "fp64 VALU issue + dependent-chain latency (frac = issue time of one pass / ms_per_step; HBM is at ~3 % of peak over the whole path)"},
             "stage_ms": {"lsd_data_parallel": float(np.mean(pre_ms)), "lsd_sweep": sw,
                          "lines3d_msld_mle": float(np.mean(front_ms)), "match_pose": float(np.mean(pair_ms))},
             "serial": serial, "value_including_h2d": (h2d or {}).get("value"), "including_h2d": h2d,
@@ -896,6 +1108,19 @@ def main():
             out["config4"] = config4_leg(device=local)
         except Exception as e:                            # (a failure of the side leg must not cost the headline line)
             out["config4"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not dist_on and not a.no_legs and not a.points and a.detector == "lsd" and not strong:
+        # the BASELINE configurations and call shapes the headline does not cover, on the driver's record (each guarded: a side leg
+        # must never cost the headline line)
+        for name, fn in (("config3", lambda: side_leg("config3", gray, depth, local, nfl=nfl)),
+                         ("edlines", lambda: side_leg("edlines", gray, depth, local, nfl=nfl)),
+                         ("latency", lambda: latency_leg(gray, depth, P, local,
+                                                         cpu_ms_per_frame=(1e3 / out["cpu_baseline"]["variants"]["single_thread"]["value"]) if "cpu_baseline" in out else None))):
+            try:
+                out[name] = fn()
+                if name != "latency" and out["roofline"].get("valu_issue"):
+                    out[name]["note_roofline"] = "bound as the headline (fp64 VALU issue + latency); no separate counter profile of this leg is stamped for these sources"
+            except Exception as e:
+                out[name] = {"error": repr(e)}
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

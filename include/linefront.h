@@ -323,6 +323,11 @@ LF_API int lf_solve_node_pair(lf_ctx *ctx, const lf_line_record *newer, int n_ne
  * EdgeSE3PointXYZDepth refinement at the end of the reference function is not restated -- values > 0 return
  * LF_ERR_UNSUPPORTED.  rand() -> the library's counter generator (the reference seeds with clock()); ties of equal
  * distance keep the caller's order (std::sort leaves them unspecified).  At most 1024 matches, 4096 points per node.
+ * Restated for the DEFAULT values of two more ParameterServer options, which are not parameters here: with
+ * allow_features_without_depth = true the reference samples from a depth-filtered, sorted COPY of the matches while it scores
+ * the unsorted initial_matches (node.cpp:1151-1170: the inlier order is the caller's), and with segment_to_optimize > 0
+ * getTransformFromMatches weights by component [3] instead of z (src/transformation_estimation_euclidean.cpp:24-33); a host
+ * that sets either must keep its CPU path.  Non-finite match distances are LF_ERR_INVALID (they have no rank).
  * Synchronous. */
 LF_API int lf_relative_transformation_legacy(lf_ctx *ctx, const float *pts_newer, int n_pts_newer, uint64_t id_newer,
                                              const float *pts_older, int n_pts_older, uint64_t id_older,

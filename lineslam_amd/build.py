@@ -29,10 +29,20 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _build_micro(hipcc, force):
+    """tools/micro/clock.hip -> tools/micro/clock_cal: the clock / fp64-rate calibration bench.py reports next to its line
+    (a stand-alone binary, not part of the library; bench.py goes on without it)."""
+    micro = os.path.join(os.path.dirname(HERE), "tools", "micro")
+    src, exe = os.path.join(micro, "clock.hip"), os.path.join(micro, "clock_cal")
+    if os.path.exists(src) and (force or not os.path.exists(exe) or os.path.getmtime(src) > os.path.getmtime(exe)):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-w", src, "-o", exe], check=False)
+
+
 def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    _build_micro(hipcc, force)
     if not force and not _stale():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + FLAGS + os.environ.get("LF_EXTRA_CFLAGS", "").split() + sources() + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))

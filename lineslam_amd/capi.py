@@ -222,7 +222,8 @@ class Context:
                                      height, max_batch, C.byref(self.params), C.byref(caps) if caps is not None else None)
         if r != LF_OK:
             self._h = _vp()
-            raise LinefrontError(r, "lf_ctx_create_caps")
+            lib().lf_last_error.restype = C.c_char_p      # lf_last_error(NULL): the message of the create that just failed on this thread
+            raise LinefrontError(r, "lf_ctx_create_caps", (lib().lf_last_error(None) or b"").decode())
         self.caps = LfCaps()
         lib().lf_ctx_get_caps(self._h, C.byref(self.caps))
         self.line_cap = self.caps.line_cap

@@ -1440,12 +1440,28 @@ int lf_relative_transformation_legacy(lf_ctx *c, const float *pts_newer, int n_p
     c->err = "the g2o step of getRelativeTransformationTo (EdgeSE3PointXYZDepth, node.cpp:1283-1327) is not restated: pass 0";
     return LF_ERR_UNSUPPORTED;
   }
-  if (n_matches > LF_LEGACY_CAP || n_pts_newer > LF_NODE_PT_CAP || n_pts_older > LF_NODE_PT_CAP) return LF_ERR_CAPACITY;
-  for (int k = 0; k < n_matches; k++)
+  if (n_matches > LF_LEGACY_CAP || n_pts_newer > LF_NODE_PT_CAP || n_pts_older > LF_NODE_PT_CAP) {
+    char m[160];
+    snprintf(m, sizeof m, "legacy point RANSAC: %d matches / %d + %d points exceed the compiled capacities (%d matches, %d points per node)",
+             n_matches, n_pts_newer, n_pts_older, LF_LEGACY_CAP, LF_NODE_PT_CAP);
+    c->err = m;
+    return LF_ERR_CAPACITY;
+  }
+  for (int k = 0; k < n_matches; k++) {
     if (match_query[k] < 0 || match_query[k] >= n_pts_newer || match_train[k] < 0 || match_train[k] >= n_pts_older) return LF_ERR_INVALID;
+    // a NaN distance has no rank: the kernel's rank sort (std::sort of the reference is undefined there too) would leave
+    // permutation slots unwritten and read points through them
+    if (!(match_dist[k] == match_dist[k]) || match_dist[k] > 3.0e38f || match_dist[k] < -3.0e38f) {
+      c->err = "legacy point RANSAC: a match distance is not finite";
+      return LF_ERR_INVALID;
+    }
+  }
   HIPCHK(c, hipSetDevice(c->device));
   if (!c->d_pts_stage) ALLOC(c, c->d_pts_stage, (size_t)2 * LF_NODE_PT_CAP * 4);
-  if (!c->d_legacy_i) { ALLOC(c, c->d_legacy_i, (size_t)3 * LF_LEGACY_CAP); ALLOC(c, c->d_legacy_f, (size_t)LF_LEGACY_CAP); ALLOC(c, c->d_legacy_r, 1); }
+  // (each buffer on its own test: a failure of a later allocation must not leave the earlier pointer as the "all allocated" flag)
+  if (!c->d_legacy_i) ALLOC(c, c->d_legacy_i, (size_t)3 * LF_LEGACY_CAP);
+  if (!c->d_legacy_f) ALLOC(c, c->d_legacy_f, (size_t)LF_LEGACY_CAP);
+  if (!c->d_legacy_r) ALLOC(c, c->d_legacy_r, 1);
   if (n_pts_newer) HIPCHK(c, hipMemcpyAsync(c->d_pts_stage, pts_newer, sizeof(float) * 4 * (size_t)n_pts_newer, hipMemcpyHostToDevice, c->stream));
   if (n_pts_older) HIPCHK(c, hipMemcpyAsync(c->d_pts_stage + (size_t)LF_NODE_PT_CAP * 4, pts_older, sizeof(float) * 4 * (size_t)n_pts_older, hipMemcpyHostToDevice, c->stream));
   if (n_matches) {

@@ -135,6 +135,10 @@ def test_full_sequence_integer_support_vs_the_reference_code(full):
           % (r[:, 0].sum(), F, r[:, 3].sum(), r[:, 2].sum(), r[:, 4].sum(), np.nonzero(~r[:, 0])[0].tolist()))
     assert r[:, 3].all() and r[:, 4].all(), np.nonzero(~(r[:, 3] & r[:, 4]))[0]
     assert r[:, 0].sum() >= F - 6 and r[:, 1].sum() >= F - 6, (r[:, 0].sum(), r[:, 1].sum())     # measured: 1145, 1145
+    # the segment DOUBLES against the reference as it is actually built on this host (no diagnostic libm): measured 874 of 1147
+    # identical (76 %); the rest differ in the last bits of a rectangle's angle / end points through the same misrounded calls.
+    # A floor, so that a regression against the real build is caught and not only one against the diagnostic build.
+    assert r[:, 2].sum() >= 0.70 * F, r[:, 2].sum()
 
 
 def test_full_sequence_properties(full):

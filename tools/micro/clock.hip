@@ -19,25 +19,34 @@ __global__ void k_tput(double *o, int n) {
   }
   o[threadIdx.x + blockIdx.x * blockDim.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
-int main() {
+int main(int argc, char **argv) {
+  const bool brief = argc > 1 && argv[1][0] == '-' && argv[1][1] == '-' && argv[1][2] == 's';   // --short: one JSON line for bench.py
   double *d; unsigned long long *dc, hc;
   hipMalloc(&d, sizeof(double) * 256 * 4096); hipMemset(d, 0, sizeof(double) * 256 * 4096); hipMalloc(&dc, 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms;
-  for (int rep = 0; rep < 3; rep++) {
+  double chain_ns = 0, chain_ms = 0, chain_mhz = 0, tput_ms = 0, tput_tf = 0;
+  for (int rep = 0; rep < (brief ? 2 : 3); rep++) {      // (--short: the first repetition warms the clocks up, the second is reported)
     const int n = 2000000;
     hipEventRecord(e0); hipLaunchKernelGGL(k_chain, dim3(1), dim3(64), 0, 0, d, n, dc); hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1); hipMemcpy(&hc, dc, 8, hipMemcpyDeviceToHost);
-    printf("one wave, dependent fma chain: %.1f ms for %d fma -> %.2f ns per fma; s_memtime-style counter %.0f ticks -> %.1f MHz; fma latency if 2.4 GHz: %.1f cycles\n",
-           ms, 4 * n, ms * 1e6 / (4.0 * n), (double)hc, hc / (ms * 1e3), ms * 1e6 / (4.0 * n) * 2.4);
+    chain_ms = ms; chain_ns = ms * 1e6 / (4.0 * n); chain_mhz = hc / (ms * 1e3);
+    if (!brief)
+      printf("one wave, dependent fma chain: %.1f ms for %d fma -> %.2f ns per fma; s_memtime-style counter %.0f ticks -> %.1f MHz; fma latency if 2.4 GHz: %.1f cycles\n",
+             ms, 4 * n, ms * 1e6 / (4.0 * n), (double)hc, hc / (ms * 1e3), ms * 1e6 / (4.0 * n) * 2.4);
   }
-  for (int rep = 0; rep < 3; rep++) {
+  for (int rep = 0; rep < (brief ? 2 : 3); rep++) {
     const int n = 200000, blocks = 256 * 8;      // 8 waves of 4 per CU ... 2 waves per SIMD x 4 SIMDs x 256 CUs
     hipEventRecord(e0); hipLaunchKernelGGL(k_tput, dim3(blocks), dim3(256), 0, 0, d, n); hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
     const double fma = (double)blocks * 256 * 8.0 * n;
-    printf("full chip, independent fma: %.1f ms -> %.2f TFLOP/s fp64 (2 flops per fma); per SIMD %.2f wave-fma per ns (16 lanes per cycle at f GHz = f / 4)\n",
-           ms, 2 * fma / (ms * 1e-3) / 1e12, fma / 64 / 1024 / (ms * 1e6));
+    tput_ms = ms; tput_tf = 2 * fma / (ms * 1e-3) / 1e12;
+    if (!brief)
+      printf("full chip, independent fma: %.1f ms -> %.2f TFLOP/s fp64 (2 flops per fma); per SIMD %.2f wave-fma per ns (16 lanes per cycle at f GHz = f / 4)\n",
+             ms, 2 * fma / (ms * 1e-3) / 1e12, fma / 64 / 1024 / (ms * 1e6));
   }
+  if (brief)
+    printf("{\"dependent_fma_chain_ms\": %.3f, \"ns_per_dependent_fma\": %.4f, \"cycle_counter_mhz\": %.1f, \"full_chip_fma_ms\": %.3f, \"fp64_tflops\": %.2f}\n",
+           chain_ms, chain_ns, chain_mhz, tput_ms, tput_tf);
   return 0;
 }

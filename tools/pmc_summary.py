@@ -24,7 +24,10 @@ sw = [k for k in rows if k.startswith("k_lsd_sweep")]
 if sw:
     k = sw[0]
     n = max(cnt[k], 1)
-    js = {"frames": 1147, "kernel": k, "fetch_kb": tot["FETCH_SIZE"][k] / n, "write_kb": tot["WRITE_SIZE"].get(k, 0.0) / n,
+    import sys as _s, os as _o
+    _s.path.insert(0, _o.path.dirname(_o.path.dirname(_o.path.abspath(__file__))))
+    from bench import csrc_sha256
+    js = {"csrc_sha256": csrc_sha256(), "frames": 1147, "kernel": k, "fetch_kb": tot["FETCH_SIZE"][k] / n, "write_kb": tot["WRITE_SIZE"].get(k, 0.0) / n,
           "hbm_bytes_per_launch": (tot["FETCH_SIZE"][k] + tot["WRITE_SIZE"].get(k, 0.0)) / n * 1024.0,
           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of one serial bench pass (--inflight 1), "
                   "(FETCH+WRITE)*1024 per launch; the sweep's accesses are narrow 16-byte / 1-byte gathers, so the gfx950 x2 correction "

@@ -20,7 +20,10 @@ for ln in lines[1:]:
               "wave_valu_frac": g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES"),
               "valu_insts_per_dispatch": g("SQ_INSTS_VALU"),      # (the table of tools/sq_summary.py is already per dispatch)
               "l2_hit": hit / (hit + miss) if hit + miss > 0 else None}
-json.dump({"source": src + " (rocprofv3 --pmc SQ_* / GRBM_GUI_ACTIVE passes of one serial bench pass) " + note,
+import sys as _s, os as _o
+_s.path.insert(0, _o.path.dirname(_o.path.dirname(_o.path.abspath(__file__))))
+from bench import csrc_sha256
+json.dump({"csrc_sha256": csrc_sha256(), "source": src + " (rocprofv3 --pmc SQ_* / GRBM_GUI_ACTIVE passes of one serial bench pass) " + note,
            "definition": "valu_busy_chip = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): fraction of the chip's VALU issue "
                          "cycles in use while the kernel runs (every VALU instruction of these kernels is fp64 or integer address arithmetic); "
                          "wave_*: fractions of SQ_WAVE_CYCLES",
