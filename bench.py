@@ -496,7 +496,7 @@ def latency_leg(gray, depth, P, device, cpu_ms_per_frame=None):
     ctx = capi.Context(640, 480, max_batch=2, params=P, device=device)
     ctx.detect3d(gray[0], depth[0], K, frame_id=0)           # set-up (tables, lazy allocations) outside the timed calls
     t, recs = [], []
-    for k in range(1, 7):
+    for k in range(1, min(7, len(gray))):
         t0 = time.perf_counter()
         recs.append(ctx.detect3d(gray[k], depth[k], K, frame_id=k))
         t.append(time.perf_counter() - t0)
@@ -506,12 +506,16 @@ def latency_leg(gray, depth, P, device, cpu_ms_per_frame=None):
         ctx.match_node_pair(recs[k], k + 1, recs[k - 1], k, allow_overflow=True)
         tm.append(time.perf_counter() - t0)
     ctx.close()
+    if not tm:
+        return out
     out["B1"] = {"lf_detect3d_ms": float(np.median(t) * 1e3), "lf_match_node_pair_ms": float(np.median(tm) * 1e3),
                  "frame_plus_pair_ms": float((np.median(t) + np.median(tm)) * 1e3), "calls": len(t),
                  "note": "host grey + depth in, records out; host records in, pair result out (median of the calls)"}
     if cpu_ms_per_frame:
         out["B1"]["cpu_port_single_thread_ms_per_frame_and_pair"] = cpu_ms_per_frame
     for B in (8, 64):
+        if B > len(gray):
+            continue
         c = capi.Context(640, 480, max_batch=B, params=P, device=device)
         dg, dd = torch.from_numpy(gray[:B]).cuda(), torch.from_numpy(depth[:B]).cuda()
         ids = np.arange(B, dtype=np.uint64)

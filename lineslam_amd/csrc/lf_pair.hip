@@ -58,13 +58,28 @@ __device__ double m_overlap(const lf_line_record *a, const lf_line_record *b) { 
 // go to a small list (L2 resident) and to LDS atomic minima (fp64 bit patterns of non-negative values order like
 // unsigned integers).  Two more sweeps over the list give the first arg-min (smallest index among ties, as
 // cv::minMaxLoc / the strict `<` of node.cpp:1664-1669) and the second-best values.
-#define MT_N 512                          // threads per pair
+#ifndef MT_LIGHT
+#define MT_LIGHT 1                        // round 6: 256 threads, <= 128 registers, 41 KB of LDS (only the direction members are staged; the
+#endif                                    //   survivors of the direction gate read the other 2D members from the records) -- a workgroup that fits
+#if MT_LIGHT                              //   beside the front end's wavefronts; 0 = the 512-thread / 103 KB form of rounds 3-5
+#define MT_N 256                          // threads per pair
+#define MT_CHUNK 1024                     // (query, train) pairs per direction-gate round
+#else
+#define MT_N 512
+#define MT_CHUNK 2048
+#endif
 #define MT_W (MT_N / 64)
-#define MT_CHUNK 2048                     // (query, train) pairs per direction-gate round
 #define LF_D_INF 0x7ff0000000000000ull    // +inf: "no live entry"
+#if MT_LIGHT
+#define MT_2D 2                           // staged per line: r0 r1 (the direction gate runs on all n1 n2 pairs)
+#define MT_R0 0
+#else
+#define MT_2D 9
+#define MT_R0 7
+#endif
 struct MatchShared {
-  double q2d[9][LF_MATCH_LINE_CAP];       // p0 p1 q0 q1 l0 l1 l2 r0 r1 of the query lines
-  double t2d[9][LF_MATCH_LINE_CAP];       //                          ... of the train lines
+  double q2d[MT_2D][LF_MATCH_LINE_CAP];   // (p0 p1 q0 q1 l0 l1 l2) r0 r1 of the query lines
+  double t2d[MT_2D][LF_MATCH_LINE_CAP];   //                            ... of the train lines
   unsigned long long rmin[LF_MATCH_LINE_CAP], cmin[LF_MATCH_LINE_CAP], rmin2[LF_MATCH_LINE_CAP], cmin2[LF_MATCH_LINE_CAP];
   int rarg[LF_MATCH_LINE_CAP], carg[LF_MATCH_LINE_CAP];
   unsigned char rdead[LF_MATCH_LINE_CAP], cdead[LF_MATCH_LINE_CAP];
@@ -100,7 +115,12 @@ __device__ __forceinline__ bool m_adjacent(const PairConsts &c, const PairBuffer
   return !(idd > c.P.adjacent_linematch_window);                           // as matchNodePair passes it, node.cpp:1505-1507
 }
 
-__global__ void __launch_bounds__(MT_N) k_match(PairConsts c, PairBuffers b) {
+#if MT_LIGHT
+#define MT_BOUNDS __launch_bounds__(MT_N, 3)
+#else
+#define MT_BOUNDS __launch_bounds__(MT_N)
+#endif
+__global__ void MT_BOUNDS k_match(PairConsts c, PairBuffers b) {
   __shared__ MatchShared S;
   const int pr = blockIdx.x, tid = threadIdx.x;
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];
@@ -117,16 +137,20 @@ __global__ void __launch_bounds__(MT_N) k_match(PairConsts c, PairBuffers b) {
   if (n1 == 0 || n2 == 0) { if (tid == 0) b.nmatches[pr] = 0; return; }
   for (int l = tid; l < n1; l += MT_N) {
     const lf_line_record *a = &f1[l];
+#if !MT_LIGHT
     S.q2d[0][l] = a->p[0]; S.q2d[1][l] = a->p[1]; S.q2d[2][l] = a->q[0]; S.q2d[3][l] = a->q[1];
     S.q2d[4][l] = a->lineEq2d[0]; S.q2d[5][l] = a->lineEq2d[1]; S.q2d[6][l] = a->lineEq2d[2];
-    S.q2d[7][l] = a->r[0]; S.q2d[8][l] = a->r[1];
+#endif
+    S.q2d[MT_R0][l] = a->r[0]; S.q2d[MT_R0 + 1][l] = a->r[1];
     S.rmin[l] = LF_D_INF; S.rarg[l] = 0x7fffffff; S.rmin2[l] = 0x4059000000000000ull /* 100.0 */; S.rdead[l] = 0;
   }
   for (int l = tid; l < n2; l += MT_N) {
     const lf_line_record *a = &f2[l];
+#if !MT_LIGHT
     S.t2d[0][l] = a->p[0]; S.t2d[1][l] = a->p[1]; S.t2d[2][l] = a->q[0]; S.t2d[3][l] = a->q[1];
     S.t2d[4][l] = a->lineEq2d[0]; S.t2d[5][l] = a->lineEq2d[1]; S.t2d[6][l] = a->lineEq2d[2];
-    S.t2d[7][l] = a->r[0]; S.t2d[8][l] = a->r[1];
+#endif
+    S.t2d[MT_R0][l] = a->r[0]; S.t2d[MT_R0 + 1][l] = a->r[1];
     S.cmin[l] = LF_D_INF; S.carg[l] = 0x7fffffff; S.cmin2[l] = 0x4059000000000000ull; S.cdead[l] = 0;
   }
   if (tid == 0) S.nlive = 0;
@@ -139,7 +163,7 @@ __global__ void __launch_bounds__(MT_N) k_match(PairConsts c, PairBuffers b) {
       const int idx = base + r * MT_N + tid;
       if (idx < n1 * n2) {
         const int i = idx / n2, j = idx - i * n2;
-        if (S.q2d[7][i] * S.t2d[7][j] + S.q2d[8][i] * S.t2d[8][j] > c.cos_angle_thresh) S.queue[atomicAdd(&S.qn, 1)] = idx;
+        if (S.q2d[MT_R0][i] * S.t2d[MT_R0][j] + S.q2d[MT_R0 + 1][i] * S.t2d[MT_R0 + 1][j] > c.cos_angle_thresh) S.queue[atomicAdd(&S.qn, 1)] = idx;
       }
     }
     __syncthreads();
@@ -147,8 +171,16 @@ __global__ void __launch_bounds__(MT_N) k_match(PairConsts c, PairBuffers b) {
     for (int k = tid; k < qn; k += MT_N) {
       const int idx = S.queue[k], i = idx / n2, j = idx - i * n2;
       double a[7], t[7];
+#if MT_LIGHT
+      {   // p0 p1 q0 q1 l0 l1 l2 of both lines, from their records (L2: the survivors are a fraction of the n1 n2 pairs)
+        const lf_line_record *ra = &f1[i], *rt = &f2[j];
+        a[0] = ra->p[0]; a[1] = ra->p[1]; a[2] = ra->q[0]; a[3] = ra->q[1]; a[4] = ra->lineEq2d[0]; a[5] = ra->lineEq2d[1]; a[6] = ra->lineEq2d[2];
+        t[0] = rt->p[0]; t[1] = rt->p[1]; t[2] = rt->q[0]; t[3] = rt->q[1]; t[4] = rt->lineEq2d[0]; t[5] = rt->lineEq2d[1]; t[6] = rt->lineEq2d[2];
+      }
+#else
 #pragma unroll
       for (int e = 0; e < 7; e++) { a[e] = S.q2d[e][i]; t[e] = S.t2d[e][j]; }
+#endif
       if ((0.25 * m_pl(a[0], a[1], t[4], t[5], t[6]) + 0.25 * m_pl(a[2], a[3], t[4], t[5], t[6]) +
            0.25 * m_pl(t[0], t[1], a[4], a[5], a[6]) + 0.25 * m_pl(t[2], t[3], a[4], a[5], a[6]) < lineDistThresh) &&
           (m_ov(a, t) > lineOverlapThresh)) {
@@ -454,7 +486,12 @@ __device__ __forceinline__ PoseGate r_gate(const PairConsts &c, const PairBuffer
 #ifndef RS_N
 #define RS_N 256
 #endif
-__global__ void __launch_bounds__(RS_N) k_ransac(PairConsts c, PairBuffers b) {
+#ifdef RS_WAVES
+#define RS_BOUNDS __launch_bounds__(RS_N, RS_WAVES)
+#else
+#define RS_BOUNDS __launch_bounds__(RS_N)
+#endif
+__global__ void RS_BOUNDS k_ransac(PairConsts c, PairBuffers b) {
   __shared__ RansacShared S;
   const int pr = blockIdx.x, tid = threadIdx.x, lane = p_lane();
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];
@@ -727,8 +764,16 @@ __global__ void __launch_bounds__(WV_T, LF_POSEW_WAVES) k_pose_w(PairConsts c, P
 }
 #pragma clang diagnostic pop
 
-static bool pose_resident_selected() {          // LF_POSE_RES=1: the resident workgroup-per-pair k_pose of rounds 2-5 (A/B on one box)
-  static const bool v = [] { const char *e = getenv("LF_POSE_RES"); return e && e[0] == '1'; }();
+// Which refinement kernel: the resident workgroup-per-pair k_pose (default: the faster one inside the pipelined step, measured)
+// or k_pose_w, the form that shares compute units (LF_POSE_WAVE=1; bit-identical, tests/test_pose_wave_gpu.py).  LF_POSE_RES=0
+// selects k_pose_w too (A/B scripts of round 6).
+static bool pose_resident_selected() {
+  static const bool v = [] {
+    const char *w = getenv("LF_POSE_WAVE"), *r = getenv("LF_POSE_RES");
+    if (w && w[0] == '1') return false;
+    if (r && r[0] == '0') return false;
+    return true;
+  }();
   return v;
 }
 
