@@ -32,6 +32,12 @@ import os
 import sys
 import time
 
+# HIP multiplexes its streams over GPU_MAX_HW_QUEUES hardware queues (4 by default); a stream that shares a queue with another
+# runs behind it.  This program uses one stream per pass in flight (4) plus a copy stream (the h2d leg) and a point stream per
+# context (config 3): eight queues keep them apart (measured: the h2d leg 144 -> 129 ms per step, the resident step unchanged).
+# Read by the HIP runtime when it starts, i.e. before torch is imported; a host that sets it itself keeps its value.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -843,32 +849,34 @@ def main():
     if a.h2d_steps > 0 and world == 1 and not dist_on and not a.points and rank == 0:
         rgb_h = torch.from_numpy(np.repeat(gray[..., None], 3, axis=-1)).pin_memory()
         d16_h = torch.from_numpy(np.rint(np.nan_to_num(depth, nan=0.0).astype(np.float64) * 5000.0).astype(np.uint16).view(np.int16)).pin_memory()
-        raw = [(torch.empty(rgb_h.shape, dtype=torch.uint8, device="cuda"), torch.empty(d16_h.shape, dtype=torch.int16, device="cuda"),
-                torch.empty((F, 480, 640), dtype=torch.uint8, device="cuda"), torch.empty((F, 480, 640), dtype=torch.float32, device="cuda"))
-               for _ in range(nfl)]
-
-        # the copies run on a stream of their own: the host->device transfer of a pass is enqueued as soon as its staging buffers
-        # are free (the ingest kernel of the pass that used them last has run) and overlaps the kernels of the passes in flight;
-        # the pass itself waits for "its" copy.  (Rounds 2-4 issued the copies on the pass's own stream: with the passes in
-        # lock-step all four copied at once and nothing overlapped them: 150.6 ms per step; on the copy stream 144.9, without any
-        # copy 130.5 -- the ingest from separate per-pass inputs -- against 125 ms with resident inputs, same box.)
+        # The loader is a stream of its own, as the reference's is a thread of its own (OpenNIListener::loadRawData runs in the
+        # listener, src/openni_listener.cpp:1194-1260): copy -> k_ingest_tum on the LOADER's context (a two-frame context bound to
+        # the copy stream: the conversion kernel needs no batch state), into the grey / depth buffers of the pass that will use
+        # them.  The pass only waits for "its" frames; the loader only waits for the buffers to be free (the front end of the pass
+        # that used them last has read them).  Rounds 2-5 ran the conversion at the head of the pass's own stream, where -- like
+        # every small kernel there -- it queued behind the long-lived wavefronts of the passes in flight.
         copy_stream = torch.cuda.Stream()
+        loader = capi.Context(640, 480, max_batch=2, params=P, device=local, stream=copy_stream.cuda_stream)
+        raw_rgb = torch.empty(rgb_h.shape, dtype=torch.uint8, device="cuda")
+        raw_z16 = torch.empty(d16_h.shape, dtype=torch.int16, device="cuda")
+        raw = [(torch.empty((F, 480, 640), dtype=torch.uint8, device="cuda"), torch.empty((F, 480, 640), dtype=torch.float32, device="cuda"))
+               for _ in range(nfl)]
         ev_ready = [torch.cuda.Event() for _ in range(nfl)]
         ev_free = [torch.cuda.Event() for _ in range(nfl)]
 
         def step_h2d(i):
             c = ctxs[i % nfl]
-            r_d, z16_d, g_d, z_d = raw[i % nfl]
+            g_d, z_d = raw[i % nfl]
             with torch.cuda.stream(copy_stream):
+                raw_rgb.copy_(rgb_h, non_blocking=True)                 # (the previous conversion, same stream, has read the raw frames)
+                raw_z16.copy_(d16_h, non_blocking=True)
                 copy_stream.wait_event(ev_free[i % nfl])            # (never recorded yet on first use: no wait)
-                r_d.copy_(rgb_h, non_blocking=True)
-                z16_d.copy_(d16_h, non_blocking=True)
+                loader.ingest_tum_device(raw_rgb.data_ptr(), raw_z16.data_ptr(), F, g_d.data_ptr(), z_d.data_ptr())
                 ev_ready[i % nfl].record(copy_stream)
             with torch.cuda.stream(streams[i % nfl]):
                 streams[i % nfl].wait_event(ev_ready[i % nfl])
-                c.ingest_tum_device(r_d.data_ptr(), z16_d.data_ptr(), F, g_d.data_ptr(), z_d.data_ptr())
-                ev_free[i % nfl].record(streams[i % nfl])
                 c.detect3d_batch_device(g_d.data_ptr(), z_d.data_ptr(), F, K, ids)
+                ev_free[i % nfl].record(streams[i % nfl])
                 c.match_pairs_device(pq, pt)
         for i in range(nfl):
             step_h2d(i)
@@ -878,11 +886,12 @@ def main():
             step_h2d(i)
         torch.cuda.synchronize()
         dth = time.perf_counter() - th
-        same_gray = bool(torch.equal(raw[0][2], dg))      # grey of a grey RGB triple == the grey image (CV_RGB2GRAY weights sum to 1)
+        same_gray = bool(torch.equal(raw[0][0], dg))      # grey of a grey RGB triple == the grey image (CV_RGB2GRAY weights sum to 1)
         h2d = {"value": F * a.h2d_steps / dth, "ms_per_step": dth / a.h2d_steps * 1e3, "steps": a.h2d_steps,
                "host_bytes_per_frame": int(rgb_h[0].numel() + 2 * d16_h[0].numel()), "ingested_grey_equals_input": same_gray,
-               "note": "pinned host RGB + 16-bit depth -> hipMemcpyAsync on a copy stream (event-ordered per staging buffer) -> k_ingest_tum -> the step; the copy of a pass overlaps the kernels of the passes in flight"}
-        del raw, rgb_h, d16_h
+               "note": "pinned host RGB + 16-bit depth -> hipMemcpyAsync + k_ingest_tum on the loader's stream (event-ordered per grey / depth buffer) -> the step; copy and conversion of a pass overlap the kernels of the passes in flight"}
+        loader.close()
+        del raw, raw_rgb, raw_z16, rgb_h, d16_h
     exchange_info = None
     if dist_on:
         dt_own = dt
