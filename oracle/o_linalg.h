@@ -124,4 +124,62 @@ static int o_inv3(const double *A, double *Ainv) {
   for (i = 0; i < 9; i++) Ainv[i] = E[i];
   return 1;
 }
+/* One-sided (Hestenes) Jacobi SVD of a general 3x3 (row-major): A = U diag(sg) V^T, sg descending.  Stands in for
+ * Eigen::JacobiSVD<Matrix3f> inside pcl::TransformationFromCorrespondences (src/line/motion.cpp:540-578).  Column pairs (0,1),
+ * (0,2), (1,2) are rotated until a sweep rotates nothing (at most 30 sweeps); a vanishing singular value gets its left vector
+ * from the cross product of the others (the reflection fix of the Kabsch step needs a full U). */
+static void o_svd3(const double *A, double *U, double *sg, double *V) {
+  double W[9];
+  int i, j, k, sweep, p, q;
+  for (i = 0; i < 9; i++) { W[i] = A[i]; V[i] = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0; }
+  for (sweep = 0; sweep < 30; sweep++) {
+    int any = 0;
+    for (p = 0; p < 2; p++)
+      for (q = p + 1; q < 3; q++) {
+        double pp = 0, qq = 0, pq = 0, zeta, tn, cs, sn;
+        for (k = 0; k < 3; k++) { pp += W[3 * k + p] * W[3 * k + p]; qq += W[3 * k + q] * W[3 * k + q]; pq += W[3 * k + p] * W[3 * k + q]; }
+        if (pq == 0.0 || pq * pq <= 1e-30 * pp * qq) continue;
+        zeta = (qq - pp) / (2.0 * pq);
+        tn = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        if (zeta < 0.0) tn = -tn;
+        cs = 1.0 / sqrt(1.0 + tn * tn);
+        sn = cs * tn;
+        any = 1;
+        for (k = 0; k < 3; k++) {
+          const double wp = W[3 * k + p], wq = W[3 * k + q], vp = V[3 * k + p], vq = V[3 * k + q];
+          W[3 * k + p] = cs * wp - sn * wq; W[3 * k + q] = sn * wp + cs * wq;
+          V[3 * k + p] = cs * vp - sn * vq; V[3 * k + q] = sn * vp + cs * vq;
+        }
+      }
+    if (!any) break;
+  }
+  for (j = 0; j < 3; j++) sg[j] = sqrt(W[j] * W[j] + W[3 + j] * W[3 + j] + W[6 + j] * W[6 + j]);
+  for (i = 0; i < 2; i++)                      /* stable exchange sort of the columns, descending */
+    for (j = 0; j + 1 < 3 - i; j++)
+      if (sg[j] < sg[j + 1]) {
+        double t = sg[j]; sg[j] = sg[j + 1]; sg[j + 1] = t;
+        for (k = 0; k < 3; k++) {
+          t = W[3 * k + j]; W[3 * k + j] = W[3 * k + j + 1]; W[3 * k + j + 1] = t;
+          t = V[3 * k + j]; V[3 * k + j] = V[3 * k + j + 1]; V[3 * k + j + 1] = t;
+        }
+      }
+  for (j = 0; j < 3; j++)
+    for (k = 0; k < 3; k++) U[3 * k + j] = (sg[j] > 0.0) ? W[3 * k + j] / sg[j] : 0.0;
+  if (!(sg[2] > 1e-12 * sg[0])) {
+    if (!(sg[1] > 1e-12 * sg[0])) {            /* rank <= 1: a unit vector orthogonal to u0, from the axis u0 is least aligned with */
+      const double ax = fabs(U[0]), ay = fabs(U[3]), az = fabs(U[6]);
+      const double e0 = (ax <= ay && ax <= az) ? 1.0 : 0.0, e1 = (e0 == 0.0 && ay <= az) ? 1.0 : 0.0, e2 = (e0 == 0.0 && e1 == 0.0) ? 1.0 : 0.0;
+      const double d = e0 * U[0] + e1 * U[3] + e2 * U[6];
+      const double v0 = e0 - d * U[0], v1 = e1 - d * U[3], v2 = e2 - d * U[6];
+      const double n = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+      U[1] = v0 / n; U[4] = v1 / n; U[7] = v2 / n;
+    }
+    U[2] = U[3] * U[7] - U[6] * U[4];          /* u2 = u0 x u1 */
+    U[5] = U[6] * U[1] - U[0] * U[7];
+    U[8] = U[0] * U[4] - U[3] * U[1];
+  }
+}
+static double o_det3(const double *M) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
 #endif

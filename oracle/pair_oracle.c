@@ -10,10 +10,12 @@
  *
  * Parity status: "parity unpinned" -- the reference sources for this stage need OpenCV/Eigen/g2o/PCL
  * (absent) and its tests hold no vectors.  The geometric primitives and the g2o-style LM pieces are
- * the IEEE-only functions of lineslam_amd/csrc/lf_pose.h (shared with the HIP kernels so that both
- * sides can be compared bit for bit); THIS file is the sequential composition and is pinned by
- * analytic known-answer tests (tests/test_oracle_pair.py: exact rigid motions are recovered).
- * rand() -> lf_rand31 (see front_oracle.c).
+ * the ORACLE'S OWN statements in o_pose.h / o_linalg.h (round 6; until round 5 this file compiled the
+ * product's lf_pose.h): the kernels are held to them bit for bit, and tests/test_oracle_pose_primitives.py
+ * holds them to the product's scalar functions; THIS file is the sequential composition, pinned by
+ * analytic known-answer tests (tests/test_oracle_pair.py: exact rigid motions are recovered) and by the
+ * source-independent fixtures of oracle/pose_indep.py (tests/test_pose_golden_cpu.py).
+ * rand() -> o_rand31 (see front_oracle.c).
  */
 #include <math.h>
 #include <stdint.h>
@@ -22,10 +24,7 @@
 #include <float.h>
 
 #include "../include/linefront.h"
-#ifndef ORACLE_LFMATH
-#define LF_ACOS acos   /* reference flavour: host libm, as motion.cpp:449 */
-#endif
-#include "../lineslam_amd/csrc/lf_pose.h"
+#include "o_pose.h"    /* the oracle's own primitives (its acos: host libm, or lf_math.h's under ORACLE_LFMATH) */
 
 #define O_EPS 1e-10
 #define O_PI_SHORT 3.14159265   /* lineslam.h:38  #define PI (3.14159265) */
@@ -119,11 +118,11 @@ int oracle_line_matching(const lf_line_record *f1, int n1, const lf_line_record 
  * the order of every sum below.                                                                       */
 typedef struct { const float *train, *query; int n; const int *mq, *mt; } o_points;   /* xyz1 float4 arrays + matches */
 
-static void p_meas(const lf_line_record *train, const lf_line_record *query, int tq, int tt, lf_line_meas *m) {
+static void p_meas(const lf_line_record *train, const lf_line_record *query, int tq, int tt, o_line_meas *m) {
   m->nA = query[tq].A; m->nB = query[tq].B; m->nMa = query[tq].DUa; m->nMb = query[tq].DUb;
   m->oA = train[tt].A; m->oB = train[tt].B; m->oMa = train[tt].DUa; m->oMb = train[tt].DUb;
 }
-static void o_point_model(lf_point_model *pm) {   /* misc.cpp:704-711 + misc2.h:23 */
+static void o_point_model_init(o_point_model *pm) {   /* misc.cpp:704-711 + misc2.h:23 */
   const double cam_angle_x = 58.0 / 180.0 * M_PI, cam_angle_y = 45.0 / 180.0 * M_PI;
   double sx = 3 * tan(cam_angle_x / 640), sy = 3 * tan(cam_angle_y / 480);
   pm->raster_cov_x = sx * sx; pm->raster_cov_y = sy * sy; pm->sigma_depth = 0.01;
@@ -132,26 +131,26 @@ static void o_point_model(lf_point_model *pm) {   /* misc.cpp:704-711 + misc2.h:
 int oracle_refine_hybrid(const lf_line_record *train, const lf_line_record *query, const int *mq, const int *mt,
                          int n, const o_points *pp, int npt, const int *pq, const int *pt, double focal, float *tf,
                          int iterations, const lf_params *P, double *chi_out) {
-  lf_se3 X, Xn;
+  o_se3 X, Xn;
   double *L = (double *)malloc(sizeof(double) * 6 * (size_t)(n + 1)), *Ln = (double *)malloc(sizeof(double) * 6 * (size_t)(n + 1));
-  lf_line_meas *M = (lf_line_meas *)malloc(sizeof(lf_line_meas) * (size_t)(n + 1));
-  lf_line_blocks *B = (lf_line_blocks *)malloc(sizeof(lf_line_blocks) * (size_t)(n + 1));
+  o_line_meas *M = (o_line_meas *)malloc(sizeof(o_line_meas) * (size_t)(n + 1));
+  o_line_blocks *B = (o_line_blocks *)malloc(sizeof(o_line_blocks) * (size_t)(n + 1));
   double *Vi = (double *)malloc(sizeof(double) * 36 * (size_t)(n + 1));
   /* points */
   double *Pp = (double *)malloc(sizeof(double) * 3 * (size_t)(npt + 1)), *Pn = (double *)malloc(sizeof(double) * 3 * (size_t)(npt + 1));
   double *PM = (double *)malloc(sizeof(double) * 24 * (size_t)(npt + 1));   /* mn(3) mo(3) In(9) Io(9) */
-  lf_point_meas *Pm = (lf_point_meas *)malloc(sizeof(lf_point_meas) * (size_t)(npt + 1));
-  lf_point_blocks *PB = (lf_point_blocks *)malloc(sizeof(lf_point_blocks) * (size_t)(npt + 1));
+  o_point_meas *Pm = (o_point_meas *)malloc(sizeof(o_point_meas) * (size_t)(npt + 1));
+  o_point_blocks *PB = (o_point_blocks *)malloc(sizeof(o_point_blocks) * (size_t)(npt + 1));
   double *PVi = (double *)malloc(sizeof(double) * 9 * (size_t)(npt + 1));
   double lambda = 0, ni = 2, currentChi = 0, wgt = P->g2o_line_error_weight, hd = P->g2o_BA_kernel_delta;
   int hub = P->g2o_BA_use_kernel, it, k, i, done_iters = 0;
-  lf_tf_to_older_pose(tf, &X);
+  o_tf_to_older_pose(tf, &X);
   for (k = 0; k < npt; k++) {   /* :247-292 */
     const float *qn = pp->query + 4 * (size_t)pq[k], *qo = pp->train + 4 * (size_t)pt[k];
     double *m = PM + 24 * (size_t)k;
     for (i = 0; i < 3; i++) { m[i] = (double)qn[i]; m[3 + i] = (double)qo[i]; Pp[3 * k + i] = (double)qn[i]; }
-    lf_point_information(qn, focal, P->stdev_sample_pt_imgline, P->depth_stdev_coeff_c1, P->depth_stdev_coeff_c2 + 0.0 * 0.5, P->depth_stdev_coeff_c3, m + 6);
-    lf_point_information(qo, focal, P->stdev_sample_pt_imgline, P->depth_stdev_coeff_c1, P->depth_stdev_coeff_c2 + 0.0 * 0.5, P->depth_stdev_coeff_c3, m + 15);
+    o_point_information(qn, focal, P->stdev_sample_pt_imgline, P->depth_stdev_coeff_c1, P->depth_stdev_coeff_c2 + 0.0 * 0.5, P->depth_stdev_coeff_c3, m + 6);
+    o_point_information(qo, focal, P->stdev_sample_pt_imgline, P->depth_stdev_coeff_c1, P->depth_stdev_coeff_c2 + 0.0 * 0.5, P->depth_stdev_coeff_c3, m + 15);
     Pm[k].mn = m; Pm[k].mo = m + 3; Pm[k].In = m + 6; Pm[k].Io = m + 15;
   }
   for (k = 0; k < n; k++) {
@@ -162,17 +161,17 @@ int oracle_refine_hybrid(const lf_line_record *train, const lf_line_record *quer
     double Hpp[36], bp[6], rho = 0, tempChi;
     int qmax = 0;
     currentChi = 0;
-    for (k = 0; k < npt; k++) currentChi += lf_ptmatch_chi2(&X, &Pp[3 * k], &Pm[k], hd, hub);
-    for (k = 0; k < n; k++) currentChi += lf_match_chi2(&X, &L[6 * k], &M[k], wgt, hd, hub);
+    for (k = 0; k < npt; k++) currentChi += o_ptmatch_chi2(&X, &Pp[3 * k], &Pm[k], hd, hub);
+    for (k = 0; k < n; k++) currentChi += o_match_chi2(&X, &L[6 * k], &M[k], wgt, hd, hub);
     for (i = 0; i < 36; i++) Hpp[i] = 0;
     for (i = 0; i < 6; i++) bp[i] = 0;
     for (k = 0; k < npt; k++) {
-      lf_ptmatch_blocks(&X, &Pp[3 * k], &Pm[k], hd, hub, &PB[k]);
+      o_ptmatch_blocks(&X, &Pp[3 * k], &Pm[k], hd, hub, &PB[k]);
       for (i = 0; i < 36; i++) Hpp[i] += PB[k].Hpp[i];
       for (i = 0; i < 6; i++) bp[i] += PB[k].bp[i];
     }
     for (k = 0; k < n; k++) {
-      lf_match_blocks(&X, &L[6 * k], &M[k], wgt, hd, hub, &B[k]);
+      o_match_blocks(&X, &L[6 * k], &M[k], wgt, hd, hub, &B[k]);
       for (i = 0; i < 36; i++) Hpp[i] += B[k].Hpp[i];
       for (i = 0; i < 6; i++) bp[i] += B[k].bp[i];
     }
@@ -191,36 +190,36 @@ int oracle_refine_hybrid(const lf_line_record *train, const lf_line_record *quer
       for (i = 0; i < 6; i++) { S[7 * i] += lambda; g[i] = bp[i]; }
       for (k = 0; k < npt && ok2; k++) {
         double T[36], u[6];
-        if (!lf_ptmatch_eliminate(&PB[k], lambda, &PVi[9 * k], T, u)) { ok2 = 0; break; }
+        if (!o_ptmatch_eliminate(&PB[k], lambda, &PVi[9 * k], T, u)) { ok2 = 0; break; }
         for (i = 0; i < 36; i++) S[i] -= T[i];
         for (i = 0; i < 6; i++) g[i] -= u[i];
       }
       for (k = 0; k < n && ok2; k++) {
         double T[36], u[6];
-        if (!lf_match_eliminate(&B[k], lambda, &Vi[36 * k], T, u)) { ok2 = 0; break; }
+        if (!o_match_eliminate(&B[k], lambda, &Vi[36 * k], T, u)) { ok2 = 0; break; }
         for (i = 0; i < 36; i++) S[i] -= T[i];
         for (i = 0; i < 6; i++) g[i] -= u[i];
       }
-      if (ok2) { double A[36]; for (i = 0; i < 36; i++) A[i] = S[i]; for (i = 0; i < 6; i++) dp[i] = g[i]; ok2 = lf_solve6(A, dp, 1); }
+      if (ok2) { double A[36]; for (i = 0; i < 36; i++) A[i] = S[i]; for (i = 0; i < 6; i++) dp[i] = g[i]; ok2 = o_lu_solve(6, A, 1, dp); }
       tempChi = DBL_MAX;
       if (ok2) {
-        lf_se3_oplus(&X, dp, &Xn);
+        o_se3_oplus(&X, dp, &Xn);
         for (i = 0; i < 6; i++) scale += dp[i] * (lambda * dp[i] + bp[i]);
         tempChi = 0;
         for (k = 0; k < npt; k++) {
           double dl[3], sk = 0;
-          lf_ptmatch_backsub(&PB[k], &PVi[9 * k], dp, dl);
+          o_ptmatch_backsub(&PB[k], &PVi[9 * k], dp, dl);
           for (i = 0; i < 3; i++) { Pn[3 * k + i] = Pp[3 * k + i] + dl[i]; sk += dl[i] * (lambda * dl[i] + PB[k].bl[i]); }
           scale += sk;
         }
         for (k = 0; k < n; k++) {
           double dl[6], sk = 0;
-          lf_match_backsub(&B[k], &Vi[36 * k], dp, dl);
+          o_match_backsub(&B[k], &Vi[36 * k], dp, dl);
           for (i = 0; i < 6; i++) { Ln[6 * k + i] = L[6 * k + i] + dl[i]; sk += dl[i] * (lambda * dl[i] + B[k].bl[i]); }
           scale += sk;
         }
-        for (k = 0; k < npt; k++) tempChi += lf_ptmatch_chi2(&Xn, &Pn[3 * k], &Pm[k], hd, hub);
-        for (k = 0; k < n; k++) tempChi += lf_match_chi2(&Xn, &Ln[6 * k], &M[k], wgt, hd, hub);
+        for (k = 0; k < npt; k++) tempChi += o_ptmatch_chi2(&Xn, &Pn[3 * k], &Pm[k], hd, hub);
+        for (k = 0; k < n; k++) tempChi += o_match_chi2(&Xn, &Ln[6 * k], &M[k], wgt, hd, hub);
       }
       rho = (currentChi - tempChi);
       scale += 1e-3;
@@ -244,7 +243,7 @@ int oracle_refine_hybrid(const lf_line_record *train, const lf_line_record *quer
     done_iters = it + 1;
     if (qmax == 10 || rho == 0) break;
   }
-  lf_older_pose_to_tf(&X, tf);
+  o_older_pose_to_tf(&X, tf);
   if (chi_out) *chi_out = currentChi;
   free(L); free(Ln); free(M); free(B); free(Vi); free(Pp); free(Pn); free(PM); free(Pm); free(PB); free(PVi);
   return done_iters;
@@ -255,47 +254,47 @@ int oracle_refine_hybrid(const lf_line_record *train, const lf_line_record *quer
 static int o_lns_pts_pcl(const lf_line_record *train, const lf_line_record *query, const o_points *pp,
                          const int *spq, const int *spt, int nsp, const int *slq, const int *slt, int nsl,
                          const lf_params *P, uint64_t stream, int iter, float *tf) {
-  lf_tfc t;
+  o_tfc t;
   int i, k;
   if (nsp < 1 || nsp + nsl < 3) return 0;
-  lf_tfc_reset(&t);
+  o_tfc_reset(&t);
   for (i = 0; i < nsl; ++i) {
-    int ptidx = (int)(lf_rand31(P->rng_seed, stream, (1ull << 20) + 3ull * (uint64_t)iter + (uint64_t)i) % (uint32_t)nsp);
+    int ptidx = (int)(o_rand31(P->rng_seed, stream, (1ull << 20) + 3ull * (uint64_t)iter + (uint64_t)i) % (uint32_t)nsp);
     const float *tp = pp->train + 4 * (size_t)spt[ptidx], *qp = pp->query + 4 * (size_t)spq[ptidx];
     double tpd[3] = {tp[0], tp[1], tp[2]}, qpd[3] = {qp[0], qp[1], qp[2]}, tprj[3], qprj[3];
     float from[3], to[3], w;
-    lf_project_pt_line(tpd, train[slt[i]].A, train[slt[i]].B, tprj);
-    lf_project_pt_line(qpd, query[slq[i]].A, query[slq[i]].B, qprj);
+    o_project_pt_line(tpd, train[slt[i]].A, train[slt[i]].B, tprj);
+    o_project_pt_line(qpd, query[slq[i]].A, query[slq[i]].B, qprj);
     for (k = 0; k < 3; k++) { from[k] = (float)qprj[k]; to[k] = (float)tprj[k]; }
     if (from[2] != from[2] || to[2] != to[2]) continue;
     w = 1 / (fabsf(to[2]) + fabsf(from[2]));
-    lf_tfc_add(&t, from, to, w);
+    o_tfc_add(&t, from, to, w);
   }
   for (i = 0; i < nsp; ++i) {
     const float *from = pp->query + 4 * (size_t)spq[i], *to = pp->train + 4 * (size_t)spt[i];
     float w;
     if (from[2] != from[2] || to[2] != to[2]) continue;
     w = 1 / (fabsf(to[2]) + fabsf(from[2]));
-    lf_tfc_add(&t, from, to, w);
+    o_tfc_add(&t, from, to, w);
   }
   if (t.n < 3) return 0;
-  lf_tfc_get(&t, tf);
+  o_tfc_get(&t, tf);
   return 1;
 }
 
 static int o_score(const lf_line_record *train, const lf_line_record *query, const o_points *pp, int nPt,
                    const int *pq, const int *ptm, const int *mq, const int *mt, int nLn, const float *tf,
-                   const lf_point_model *pm, double thr, int *pset, int *npin, int *lset, int *nlin,
+                   const o_point_model *pm, double thr, int *pset, int *npin, int *lset, int *nlin,
                    float *sse_f, double *sse_d) {
   int i, np = 0, nl = 0;
   float sf = 0; double sd = 0;
   for (i = 0; i < nPt; ++i) {
-    double m = lf_error_function2(pp->query + 4 * (size_t)pq[i], pp->train + 4 * (size_t)ptm[i], tf, pm);
+    double m = o_error_function2(pp->query + 4 * (size_t)pq[i], pp->train + 4 * (size_t)ptm[i], tf, pm);
     if (m < thr * thr) { pset[np++] = i; sf += m; sd += m; }
   }
   for (i = 0; i < nLn; ++i) {
     double add;
-    if (lf_line_inlier(tf, query[mq[i]].A, query[mq[i]].B, train[mt[i]].A, train[mt[i]].B, train[mt[i]].DUa,
+    if (o_line_inlier(tf, query[mq[i]].A, query[mq[i]].B, train[mt[i]].A, train[mt[i]].B, train[mt[i]].DUa,
                        train[mt[i]].DUb, thr, &add)) { lset[nl++] = i; sf += add; sd += add; }
   }
   *npin = np; *nlin = nl; *sse_f = sf; *sse_d = sd;
@@ -318,9 +317,9 @@ int oracle_pose_hybrid_ransac(const lf_line_record *train, const lf_line_record 
   uint64_t ctr = 0;
   int idd = id_train - id_query;
   o_points pp;
-  lf_point_model pm;
+  o_point_model pm;
   pp.train = train_pts; pp.query = query_pts;
-  o_point_model(&pm);
+  o_point_model_init(&pm);
   *n_pinl = 0; *n_linl = 0;
   for (i = 0; i < 16; i++) tf_out[i] = (i % 5 == 0) ? 1.0f : 0.0f;
   if (dbg) dbg[0] = dbg[1] = dbg[2] = dbg[3] = 0;
@@ -335,7 +334,7 @@ int oracle_pose_hybrid_ransac(const lf_line_record *train, const lf_line_record 
     float tf[16], sse_f; double sse_d;
     int ncp, ncl, b = 0, left = nTot, s, spq[3], spt[3], slq[3], slt[3], nsp = 0, nsl = 0, valid;
     for (s = 0; s < 3; s++) {   /* random_unique(indexes, 3) */
-      int r = b + (int)(lf_rand31(P->rng_seed, stream, ctr++) % (uint32_t)left);
+      int r = b + (int)(o_rand31(P->rng_seed, stream, ctr++) % (uint32_t)left);
       int tmp = indexes[b]; indexes[b] = indexes[r]; indexes[r] = tmp;
       ++b; --left;
     }
@@ -351,7 +350,7 @@ int oracle_pose_hybrid_ransac(const lf_line_record *train, const lf_line_record 
           la[6 * s + c] = query[slq[s]].A[c]; la[6 * s + 3 + c] = query[slq[s]].B[c];
           lb[6 * s + c] = train[slt[s]].A[c]; lb[6 * s + 3 + c] = train[slt[s]].B[c];
         }
-      valid = lf_rel_motion_lines(la, lb, 3, R, t);
+      valid = o_rel_motion_lines(la, lb, 3, R, t);
       for (i = 0; i < 3; i++) { for (c = 0; c < 3; c++) tf[4 * i + c] = (float)R[3 * i + c]; tf[4 * i + 3] = (float)t[i]; }
       tf[12] = tf[13] = tf[14] = 0.0f; tf[15] = 1.0f;
     } else
@@ -415,9 +414,9 @@ int oracle_refine_g2o(const lf_line_record *train, const lf_line_record *query, 
 }
 
 /* exported primitive wrappers for known-answer tests */
-int oracle_rel_motion_lines(const double *la, const double *lb, int n, double *R, double *t) { return lf_rel_motion_lines(la, lb, n, R, t); }
-double oracle_error_function2(const float *x1, const float *x2, const float *tf) { lf_point_model pm; o_point_model(&pm); return lf_error_function2(x1, x2, tf, &pm); }
-void oracle_kabsch(const float *from, const float *to, const float *w, int n, float *tf) { lf_tfc t; int i; lf_tfc_reset(&t); for (i = 0; i < n; i++) lf_tfc_add(&t, from + 3 * i, to + 3 * i, w[i]); lf_tfc_get(&t, tf); }
+int oracle_rel_motion_lines(const double *la, const double *lb, int n, double *R, double *t) { return o_rel_motion_lines(la, lb, n, R, t); }
+double oracle_error_function2(const float *x1, const float *x2, const float *tf) { o_point_model pm; o_point_model_init(&pm); return o_error_function2(x1, x2, tf, &pm); }
+void oracle_kabsch(const float *from, const float *to, const float *w, int n, float *tf) { o_tfc t; int i; o_tfc_reset(&t); for (i = 0; i < n; i++) o_tfc_add(&t, from + 3 * i, to + 3 * i, w[i]); o_tfc_get(&t, tf); }
 
 
 /* ---------------------------------------------------------------------------------------------
@@ -436,10 +435,10 @@ static void o_relmot_cost(const double *p, double *error, int m, int n, void *ad
   double R[9];
   int i;
   (void)m;
-  lf_q2r(p, R);
+  o_q2r(p, R);
   for (i = 0; i < n; i++) {
     const lf_line_record *a = &d->a[d->ia[i]], *b = &d->b[d->ib[i]];
-    error[i] = lf_relmotion_residual(R, p + 4, a->A, a->B, a->DUa, a->DUb, b->A, b->B, b->DUa, b->DUb);
+    error[i] = o_relmotion_residual(R, p + 4, a->A, a->B, a->DUa, a->DUb, b->A, b->B, b->DUa, b->DUb);
   }
 }
 static int o_optimize_relmotion(const lf_line_record *a, const lf_line_record *b, const int *ia, const int *ib, int n,
@@ -447,10 +446,10 @@ static int o_optimize_relmotion(const lf_line_record *a, const lf_line_record *b
   double opts[5] = {1E-03, 1E-10, 1E-20, 1E-20, 1E-06}, info[10], para[7];
   o_relmot_data d;
   d.a = a; d.b = b; d.ia = ia; d.ib = ib;
-  lf_r2q(R, para);
+  o_r2q(R, para);
   para[4] = t[0]; para[5] = t[1]; para[6] = t[2];
   oracle_levmar_dif(o_relmot_cost, para, 7, n, 50, opts, info, &d);
-  lf_q2r(para, R);
+  o_q2r(para, R);
   t[0] = para[4]; t[1] = para[5]; t[2] = para[6];
   return (int)info[5];
 }
@@ -458,7 +457,7 @@ static int o_relmot_consensus(const lf_line_record *a, const lf_line_record *b, 
                               const double *R, const double *t, const lf_params *P, int *set) {
   int i, c = 0;
   for (i = 0; i < n; ++i)
-    if (lf_relmotion_inlier(R, t, a[mq[i]].A, a[mq[i]].B, b[mt[i]].A, b[mt[i]].B, P->pt2line3d_dist_relmotion,
+    if (o_relmotion_inlier(R, t, a[mq[i]].A, a[mq[i]].B, b[mt[i]].A, b[mt[i]].B, P->pt2line3d_dist_relmotion,
                             P->line3d_angle_relmotion)) set[c++] = i;
   return c;
 }
@@ -481,7 +480,7 @@ int oracle_relmotion_ransac(const lf_line_record *train, const lf_line_record *q
     int bpos = 0, left = n, s, c, nc;
     iter++;
     for (s = 0; s < 3; s++) {   /* random_unique(indexes, 3) */
-      int r = bpos + (int)(lf_rand31(P->rng_seed, stream, ctr++) % (uint32_t)left);
+      int r = bpos + (int)(o_rand31(P->rng_seed, stream, ctr++) % (uint32_t)left);
       int tmp = indexes[bpos]; indexes[bpos] = indexes[r]; indexes[r] = tmp;
       ++bpos; --left;
     }
@@ -490,10 +489,10 @@ int oracle_relmotion_ransac(const lf_line_record *train, const lf_line_record *q
         la[6 * s + c] = a[mq[indexes[s]]].A[c]; la[6 * s + 3 + c] = a[mq[indexes[s]]].B[c];
         lb[6 * s + c] = b[mt[indexes[s]]].A[c]; lb[6 * s + 3 + c] = b[mt[indexes[s]]].B[c];
       }
-    if (lf_relmotion_degenerate(la, cos_deg)) continue;
+    if (o_relmotion_degenerate(la, cos_deg)) continue;
     /* the reference ignores a failed computeRelativeMotion_svd (:440) and would go on with empty matrices;
      * here such a sample is skipped */
-    if (!lf_rel_motion_lines(la, lb, 3, Rs, ts)) continue;
+    if (!o_rel_motion_lines(la, lb, 3, Rs, ts)) continue;
     nc = o_relmot_consensus(a, b, mq, mt, n, Rs, ts, P, cur);
     if (nc > nmax) {
       memcpy(maxset, cur, sizeof(int) * (size_t)nc); nmax = nc; best_iter = iter - 1;
@@ -529,17 +528,48 @@ int oracle_relmotion_ransac(const lf_line_record *train, const lf_line_record *q
   free(indexes);
   return nprev;
 }
-double oracle_acos(double x) { return lf_acos(x); }
-void oracle_sincos_cr(double x, double *s, double *c) { lf_sincos_cr(x, s, c); }
-double oracle_atan2_cr(double y, double x) { return lf_atan2_cr(y, x); }
-/* sin / cos of theta = atan2_cr(y, x) (+ LF_PI if flip) through lf_sincos_cr_near; returns theta */
-double oracle_r2r_angle(double y, double x, int flip, double *s, double *c) {
-  double t0, th, theta;
-  lf_dd s0, c0;
-  th = lf_atan2_cr_sc(y, x, &t0, &s0, &c0);
-  theta = flip ? th + LF_PI : th;
-  lf_sincos_cr_near(theta, flip, th, t0, s0, c0, s, c);
-  return theta;
+/* ---- the oracle's own primitives (o_pose.h, o_linalg.h), flat signatures: the twin of product_prim (product_hooks.c); the
+ * two are held bit for bit on random inputs by tests/test_oracle_pose_primitives.py */
+int oracle_prim(int which, const double *in, const float *fin, double *out, float *fout) {
+  switch (which) {
+    case 0: { double R[9], t[3]; int ok = o_rel_motion_lines(in, in + 18, (int)in[36], R, t); memcpy(out, R, sizeof R); memcpy(out + 9, t, sizeof t); return ok; }
+    case 1: out[0] = o_mah_dist(in, in + 3, in + 12, in + 15); return 1;
+    case 2: { double add; int r = o_line_inlier(fin, in, in + 3, in + 6, in + 9, in + 12, in + 21, in[30], &add); out[0] = add; return r; }
+    case 3: o_line_edge_error(in, in + 9, in + 18, in + 21, in + 24, in + 27, out); return 1;
+    case 4: { o_se3 X, Y; memcpy(&X, in, sizeof X); o_se3_oplus(&X, in + 12, &Y); memcpy(out, &Y, sizeof Y); return 1; }
+    case 5: { o_se3 X; o_tf_to_older_pose(fin, &X); memcpy(out, &X, sizeof X); o_older_pose_to_tf(&X, fout); return 1; }
+    case 6: { o_se3 X; o_line_meas m; o_line_blocks B; double Vi[36], T[36], u[6], dl[6]; int ok;
+              memcpy(&X, in, sizeof X);
+              m.nA = in + 18; m.nB = in + 21; m.nMa = in + 24; m.nMb = in + 33; m.oA = in + 42; m.oB = in + 45; m.oMa = in + 48; m.oMb = in + 57;
+              o_match_blocks(&X, in + 12, &m, in[66], in[67], (int)in[68], &B);
+              memcpy(out, &B, sizeof B);
+              out[120] = o_match_chi2(&X, in + 12, &m, in[66], in[67], (int)in[68]);
+              ok = o_match_eliminate(&B, in[69], Vi, T, u);
+              memcpy(out + 121, Vi, sizeof Vi); memcpy(out + 157, T, sizeof T); memcpy(out + 193, u, sizeof u);
+              o_match_backsub(&B, Vi, in + 70, dl); memcpy(out + 199, dl, sizeof dl);
+              return ok; }
+    case 7: out[0] = (double)o_relmotion_inlier(in, in + 9, in + 12, in + 15, in + 18, in + 21, in[24], in[25]);
+            out[1] = o_relmotion_residual(in, in + 9, in + 12, in + 15, in + 26, in + 35, in + 18, in + 21, in + 44, in + 53);
+            out[2] = (double)o_relmotion_degenerate(in + 62, in[80]);
+            { double q[4], R2[9]; o_r2q(in, q); o_q2r(q, R2); memcpy(out + 3, q, sizeof q); memcpy(out + 7, R2, sizeof R2); }
+            return 1;
+    case 8: { o_point_model pm; pm.raster_cov_x = in[0]; pm.raster_cov_y = in[1]; pm.sigma_depth = in[2]; out[0] = o_error_function2(fin, fin + 4, fin + 8, &pm);
+              o_project_pt_line(in + 3, in + 6, in + 9, out + 1);
+              return o_point_information(fin, in[12], in[13], in[14], in[15], in[16], out + 4); }
+    case 9: { o_tfc t; int i, n = (int)in[0]; o_tfc_reset(&t); for (i = 0; i < n; i++) o_tfc_add(&t, fin + 7 * i, fin + 7 * i + 3, fin[7 * i + 6]); o_tfc_get(&t, fout); return t.n; }
+    case 10: { o_se3 X; o_point_meas m; o_point_blocks B; double Vi[9], T[36], u[6], dl[3]; int ok;
+               memcpy(&X, in, sizeof X);
+               m.mn = in + 15; m.mo = in + 18; m.In = in + 21; m.Io = in + 30;
+               o_ptmatch_blocks(&X, in + 12, &m, in[39], (int)in[40], &B);
+               memcpy(out, &B, sizeof B);
+               out[72] = o_ptmatch_chi2(&X, in + 12, &m, in[39], (int)in[40]);
+               ok = o_ptmatch_eliminate(&B, in[41], Vi, T, u);
+               memcpy(out + 73, Vi, sizeof Vi); memcpy(out + 82, T, sizeof T); memcpy(out + 118, u, sizeof u);
+               o_ptmatch_backsub(&B, Vi, in + 42, dl); memcpy(out + 124, dl, sizeof dl);
+               return ok; }
+    case 11: { double U[9], sg[3], V[9]; o_svd3(in, U, sg, V); memcpy(out, U, sizeof U); memcpy(out + 9, sg, sizeof sg); memcpy(out + 12, V, sizeof V); out[21] = o_det3(in); return 1; }
+  }
+  return -1;
 }
 
 /* ================================================================ legacy point-feature RANSAC
@@ -549,7 +579,7 @@ double oracle_r2r_angle(double y, double x, int flip, double *s, double *c) {
  * (draw d of iteration n = counter 20002 n + d), std::sort's tie order -> stable.  pts: float4 per feature.
  * Returns found; out_inl = indices into the caller's match arrays, in the kept (ascending distance) order. */
 static int o_legacy_score(const float *pq, const float *pt, const int *mq, const int *mt, const int *perm, int n, const float *tf,
-                          double thr2, const lf_point_model *pm, int *list, double *err_out) {
+                          double thr2, const o_point_model *pm, int *list, double *err_out) {
   int i, cnt = 0;
   double mean = 0.0;
   for (i = 0; i < n; i++) {
@@ -557,7 +587,7 @@ static int o_legacy_score(const float *pq, const float *pt, const int *mq, const
     const float *x1 = pq + 4 * (size_t)mq[m], *x2 = pt + 4 * (size_t)mt[m];
     double e;
     if (x1[2] == 0.0f || x2[2] == 0.0f) continue;
-    e = lf_error_function2(x1, x2, tf, pm);
+    e = o_error_function2(x1, x2, tf, pm);
     if (e > thr2) continue;
     if (!(e >= 0.0)) continue;
     mean += e;
@@ -568,10 +598,10 @@ static int o_legacy_score(const float *pq, const float *pt, const int *mq, const
 }
 static int o_legacy_transform(const float *pq, const float *pt, const int *mq, const int *mt, const int *perm, const int *list,
                               int cnt, float max_dist_m, float *tf) {
-  lf_tfc t;
+  o_tfc t;
   int k, c, have_prev = 0;
   float pf[3] = {0, 0, 0}, pp[3] = {0, 0, 0};
-  lf_tfc_reset(&t);
+  o_tfc_reset(&t);
   for (k = 0; k < cnt; k++) {
     int m = perm[list[k]];
     const float *from = pq + 4 * (size_t)mq[m], *to = pt + 4 * (size_t)mt[m];
@@ -588,20 +618,20 @@ static int o_legacy_transform(const float *pq, const float *pt, const int *mq, c
       for (c = 0; c < 3; c++) { pf[c] = from[c]; pp[c] = to[c]; }
       have_prev = 1;
     }
-    lf_tfc_add(&t, from, to, w);
+    o_tfc_add(&t, from, to, w);
   }
-  lf_tfc_get(&t, tf);
+  o_tfc_get(&t, tf);
   return 1;
 }
 int oracle_legacy_ransac(const float *pts_q, const float *pts_t, const int *mq, const int *mt, const float *md, int n,
                          int min_matches, int iterations, double max_dist_for_inliers, uint64_t seed, uint64_t stream, float *T,
                          float *rmse_out, int *out_inl, int *n_inl, int *dbg /* [3] valid iterations, best iteration, iterations run */) {
-  lf_point_model pm;
+  o_point_model pm;
   const float max_dist_m = (float)max_dist_for_inliers;
   float rmse = 1e6f;
   int i, it, nbest = 0, valid_iterations = 0, best_iter = -1, real_iterations = 0, enough = 0;
   int *perm, *cur, *ref, *best;
-  o_point_model(&pm);
+  o_point_model_init(&pm);
   for (i = 0; i < 16; i++) T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
   *n_inl = 0; *rmse_out = rmse;
   if (dbg) { dbg[0] = 0; dbg[1] = -1; dbg[2] = 0; }
@@ -625,7 +655,7 @@ int oracle_legacy_ransac(const float *pts_q, const float *pts_t, const int *mq, 
         int ids[4], ns = 0, safety = 0, k;
         uint64_t ctr = (uint64_t)it * 20002ull;
         while (ns < 4) {
-          int id1 = (int)(lf_rand31(seed, stream, ctr) % (uint32_t)n), id2 = (int)(lf_rand31(seed, stream, ctr + 1) % (uint32_t)n), pos = 0, dup = 0;
+          int id1 = (int)(o_rand31(seed, stream, ctr) % (uint32_t)n), id2 = (int)(o_rand31(seed, stream, ctr + 1) % (uint32_t)n), pos = 0, dup = 0;
           ctr += 2;
           if (id1 > id2) id1 = id2;
           while (pos < ns && ids[pos] <= id1) { if (ids[pos] == id1) dup = 1; pos++; }
