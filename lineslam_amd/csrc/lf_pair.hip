@@ -58,32 +58,28 @@ __device__ double m_overlap(const lf_line_record *a, const lf_line_record *b) { 
 // go to a small list (L2 resident) and to LDS atomic minima (fp64 bit patterns of non-negative values order like
 // unsigned integers).  Two more sweeps over the list give the first arg-min (smallest index among ties, as
 // cv::minMaxLoc / the strict `<` of node.cpp:1664-1669) and the second-best values.
-#ifndef MT_LIGHT
-#define MT_LIGHT 1                        // round 6: 256 threads, <= 128 registers, 41 KB of LDS (only the direction members are staged; the
-#endif                                    //   survivors of the direction gate read the other 2D members from the records) -- a workgroup that fits
-#if MT_LIGHT                              //   beside the front end's wavefronts; 0 = the 512-thread / 103 KB form of rounds 3-5
-#define MT_N 256                          // threads per pair
-#define MT_CHUNK 1024                     // (query, train) pairs per direction-gate round
-#else
-#define MT_N 512
-#define MT_CHUNK 2048
-#endif
-#define MT_W (MT_N / 64)
+// Two forms of the kernel, same arithmetic, same results:
+//   light (round 6)  256 threads, 78 registers, 42 KB of LDS: only the direction members r0 r1 are staged, the survivors of the
+//                    direction gate read p, q, lineEq2d from the records (L2) -- a workgroup that fits beside the front end's
+//                    wavefronts; used for the big batches that run inside a pipelined step (>= LF_MATCH_LIGHT_PAIRS pairs + pose)
+//   heavy (rounds 3-5) 512 threads, 172 registers, all nine 2D members staged (103 KB): faster when the launch has the chip to
+//                    itself (BASELINE config 4: 256 pairs in 0.38 ms against 0.66), a near-empty-CU requirement in a full chip
+#define LF_MATCH_LIGHT_PAIRS 1000
 #define LF_D_INF 0x7ff0000000000000ull    // +inf: "no live entry"
-#if MT_LIGHT
-#define MT_2D 2                           // staged per line: r0 r1 (the direction gate runs on all n1 n2 pairs)
-#define MT_R0 0
-#else
-#define MT_2D 9
-#define MT_R0 7
-#endif
-struct MatchShared {
-  double q2d[MT_2D][LF_MATCH_LINE_CAP];   // (p0 p1 q0 q1 l0 l1 l2) r0 r1 of the query lines
-  double t2d[MT_2D][LF_MATCH_LINE_CAP];   //                            ... of the train lines
+template <bool LIGHT> struct MatchCfg {
+  static constexpr int N = LIGHT ? 256 : 512;          // threads per pair
+  static constexpr int W = N / 64;
+  static constexpr int CHUNK = LIGHT ? 1024 : 2048;    // (query, train) pairs per direction-gate round
+  static constexpr int D2 = LIGHT ? 2 : 9;             // staged per line: r0 r1 | p0 p1 q0 q1 l0 l1 l2 r0 r1
+  static constexpr int R0 = LIGHT ? 0 : 7;
+};
+template <bool LIGHT> struct MatchSharedT {
+  double q2d[MatchCfg<LIGHT>::D2][LF_MATCH_LINE_CAP];   // (p0 p1 q0 q1 l0 l1 l2) r0 r1 of the query lines
+  double t2d[MatchCfg<LIGHT>::D2][LF_MATCH_LINE_CAP];   //                            ... of the train lines
   unsigned long long rmin[LF_MATCH_LINE_CAP], cmin[LF_MATCH_LINE_CAP], rmin2[LF_MATCH_LINE_CAP], cmin2[LF_MATCH_LINE_CAP];
   int rarg[LF_MATCH_LINE_CAP], carg[LF_MATCH_LINE_CAP];
   unsigned char rdead[LF_MATCH_LINE_CAP], cdead[LF_MATCH_LINE_CAP];
-  int queue[MT_CHUNK], qn, nlive, wbase[MT_W];
+  int queue[MatchCfg<LIGHT>::CHUNK], qn, nlive, wbase[MatchCfg<LIGHT>::W];
 };
 __device__ __forceinline__ double m_pl(double px, double py, double l0, double l1, double l2) {   // pt_to_line_dist2d
   return lf_fabs((l0 * px + l1 * py + l2)) / lf_sqrt(l0 * l0 + l1 * l1);
@@ -115,13 +111,10 @@ __device__ __forceinline__ bool m_adjacent(const PairConsts &c, const PairBuffer
   return !(idd > c.P.adjacent_linematch_window);                           // as matchNodePair passes it, node.cpp:1505-1507
 }
 
-#if MT_LIGHT
-#define MT_BOUNDS __launch_bounds__(MT_N, 3)
-#else
-#define MT_BOUNDS __launch_bounds__(MT_N)
-#endif
-__global__ void MT_BOUNDS k_match(PairConsts c, PairBuffers b) {
-  __shared__ MatchShared S;
+template <bool LIGHT>
+__global__ void __launch_bounds__(MatchCfg<LIGHT>::N) k_match(PairConsts c, PairBuffers b) {
+  constexpr int MT_N = MatchCfg<LIGHT>::N, MT_W = MatchCfg<LIGHT>::W, MT_CHUNK = MatchCfg<LIGHT>::CHUNK, MT_R0 = MatchCfg<LIGHT>::R0;
+  __shared__ MatchSharedT<LIGHT> S;
   const int pr = blockIdx.x, tid = threadIdx.x;
   const int fq = b.pair_q[pr], ft = b.pair_t[pr];
   int n1 = b.nlines[fq], n2 = b.nlines_t[ft];
@@ -137,19 +130,19 @@ __global__ void MT_BOUNDS k_match(PairConsts c, PairBuffers b) {
   if (n1 == 0 || n2 == 0) { if (tid == 0) b.nmatches[pr] = 0; return; }
   for (int l = tid; l < n1; l += MT_N) {
     const lf_line_record *a = &f1[l];
-#if !MT_LIGHT
+    if constexpr (!LIGHT) {
     S.q2d[0][l] = a->p[0]; S.q2d[1][l] = a->p[1]; S.q2d[2][l] = a->q[0]; S.q2d[3][l] = a->q[1];
     S.q2d[4][l] = a->lineEq2d[0]; S.q2d[5][l] = a->lineEq2d[1]; S.q2d[6][l] = a->lineEq2d[2];
-#endif
+    }
     S.q2d[MT_R0][l] = a->r[0]; S.q2d[MT_R0 + 1][l] = a->r[1];
     S.rmin[l] = LF_D_INF; S.rarg[l] = 0x7fffffff; S.rmin2[l] = 0x4059000000000000ull /* 100.0 */; S.rdead[l] = 0;
   }
   for (int l = tid; l < n2; l += MT_N) {
     const lf_line_record *a = &f2[l];
-#if !MT_LIGHT
+    if constexpr (!LIGHT) {
     S.t2d[0][l] = a->p[0]; S.t2d[1][l] = a->p[1]; S.t2d[2][l] = a->q[0]; S.t2d[3][l] = a->q[1];
     S.t2d[4][l] = a->lineEq2d[0]; S.t2d[5][l] = a->lineEq2d[1]; S.t2d[6][l] = a->lineEq2d[2];
-#endif
+    }
     S.t2d[MT_R0][l] = a->r[0]; S.t2d[MT_R0 + 1][l] = a->r[1];
     S.cmin[l] = LF_D_INF; S.carg[l] = 0x7fffffff; S.cmin2[l] = 0x4059000000000000ull; S.cdead[l] = 0;
   }
@@ -171,16 +164,14 @@ __global__ void MT_BOUNDS k_match(PairConsts c, PairBuffers b) {
     for (int k = tid; k < qn; k += MT_N) {
       const int idx = S.queue[k], i = idx / n2, j = idx - i * n2;
       double a[7], t[7];
-#if MT_LIGHT
-      {   // p0 p1 q0 q1 l0 l1 l2 of both lines, from their records (L2: the survivors are a fraction of the n1 n2 pairs)
+      if constexpr (LIGHT) {   // p0 p1 q0 q1 l0 l1 l2 of both lines, from their records (L2: the survivors are a fraction of the n1 n2 pairs)
         const lf_line_record *ra = &f1[i], *rt = &f2[j];
         a[0] = ra->p[0]; a[1] = ra->p[1]; a[2] = ra->q[0]; a[3] = ra->q[1]; a[4] = ra->lineEq2d[0]; a[5] = ra->lineEq2d[1]; a[6] = ra->lineEq2d[2];
         t[0] = rt->p[0]; t[1] = rt->p[1]; t[2] = rt->q[0]; t[3] = rt->q[1]; t[4] = rt->lineEq2d[0]; t[5] = rt->lineEq2d[1]; t[6] = rt->lineEq2d[2];
-      }
-#else
+      } else {
 #pragma unroll
-      for (int e = 0; e < 7; e++) { a[e] = S.q2d[e][i]; t[e] = S.t2d[e][j]; }
-#endif
+        for (int e = 0; e < 7; e++) { a[e] = S.q2d[e][i]; t[e] = S.t2d[e][j]; }
+      }
       if ((0.25 * m_pl(a[0], a[1], t[4], t[5], t[6]) + 0.25 * m_pl(a[2], a[3], t[4], t[5], t[6]) +
            0.25 * m_pl(t[0], t[1], a[4], a[5], a[6]) + 0.25 * m_pl(t[2], t[3], a[4], a[5], a[6]) < lineDistThresh) &&
           (m_ov(a, t) > lineOverlapThresh)) {
@@ -778,7 +769,11 @@ static bool pose_resident_selected() {
 }
 
 void lf_pair_launch(const PairConsts &c, const PairBuffers &b, int n_pairs, hipStream_t st, int solver, bool run_match) {
-  if (run_match) hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(MT_N), 0, st, c, b);
+  if (run_match) {
+    static const int form = [] { const char *e = getenv("LF_MATCH_FORM"); return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'h' ? 2 : 0)); }();   // tests: force one form
+    if (form == 1 || (form == 0 && n_pairs >= LF_MATCH_LIGHT_PAIRS && solver != LF_SOLVER_NONE)) hipLaunchKernelGGL(k_match<true>, dim3(n_pairs), dim3(MatchCfg<true>::N), 0, st, c, b);
+    else hipLaunchKernelGGL(k_match<false>, dim3(n_pairs), dim3(MatchCfg<false>::N), 0, st, c, b);
+  }
   if (solver == LF_SOLVER_NONE) return;
   if (solver == LF_SOLVER_HYBRID) lf_pair_hybrid_launch(c, b, n_pairs, st);
   else if (solver == LF_SOLVER_RELMOTION) lf_pair_relmotion_launch(c, b, n_pairs, st);

@@ -49,3 +49,14 @@ sys.stdout.buffer.write(np.frombuffer(out[0], np.uint8).tobytes().hex().encode()
     assert a.returncode == 0, a.stderr[-3000:]
     assert b.returncode == 0, b.stderr[-3000:]
     assert a.stdout == b.stdout and len(a.stdout) > 1000
+
+
+@pytest.mark.parametrize("form", ["light", "heavy"])
+def test_both_forms_of_k_match_pass_the_matching_tests(built_lib, form):
+    """k_match exists in two forms with the same arithmetic (csrc/lf_pair.hip: light = 256 threads / 42 KB for the big batches of a
+    pipelined step, heavy = 512 threads / 103 KB for launches that have the chip to themselves); the library picks by launch size,
+    LF_MATCH_FORM forces one: the matching fixtures, the loop-closure launches and the pair tests under each."""
+    r = _run(["-m", "pytest", "tests/test_match_golden_gpu.py", "tests/test_loopclosure_gpu.py", "tests/test_pair_gpu.py", "tests/test_pair_sizes_gpu.py",
+              "-m", "gpu", "-x", "-q"], LF_MATCH_FORM=form)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

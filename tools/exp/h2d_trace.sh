@@ -2,7 +2,7 @@
 # GPU box: how long do the host->device copies of the h2d leg take inside the pipelined run? (memory-copy trace)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$1; mkdir -p $OUT
-timeout 900 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/trace -o t -- python bench.py --no-cpu --no-config4 --steps 2 --warmup 1 --h2d-steps 6 > $OUT/bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/trace -o t -- python bench.py --no-cpu --no-config4 --no-legs --steps 2 --warmup 1 --h2d-steps 6 > $OUT/bench.log 2>&1
 F=$(find $OUT/trace -name "*memory_copy_trace.csv" | head -1)
 python - <<PY
 import csv

@@ -16,7 +16,7 @@ P5="TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pass$i -o p -- python bench.py --steps 1 --warmup 0 --no-cpu --no-config4 --inflight 1 --h2d-steps 0 ${BENCH_EXTRA:-} > $OUT/pass$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pass$i -o p -- python bench.py --steps 1 --warmup 0 --no-cpu --no-config4 --no-legs --inflight 1 --h2d-steps 0 ${BENCH_EXTRA:-} > $OUT/pass$i.log 2>&1
   echo "pass $i exit $?" >> $OUT/passes.txt
 done
 python tools/sq_summary.py $OUT $TAG
