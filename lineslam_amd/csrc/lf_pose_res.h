@@ -28,6 +28,9 @@
 #ifndef RQ
 #define RQ 1                          // passes a lane runs TOGETHER in the elimination and the back-substitution: RQ independent
 #endif                                // 6x6 solves in one instruction stream hide each other's fp64 latency (one wavefront per SIMD)
+#ifndef R_COLS
+#define R_COLS 1                      // round 6: the landmark systems are eliminated with one matrix column per lane (p_solve6_cols, lf_pose_wg.h)
+#endif
 #define R_CM 48                       // compact measurement: nA nB nMa nMb oA oB oMa oMb
 static_assert(RP_N * RP_ROWS >= LF_MAX_MATCHES, "four passes cover the match list");
 
@@ -371,7 +374,7 @@ __device__ int r_eliminate(ResShared &S, int n, double lambda, ResRegs &R, const
       wbrow[q] = S.wb + (t[q].act ? t[q].i : 0) * R_ROW;
     }
     const int d = t[0].d;
-    double A[RQ][36], x[RQ][6], wvc[RQ][6], wv[RQ][6];
+    double x[RQ][6], wvc[RQ][6], wv[RQ][6];
     int ok[RQ];
 #pragma unroll
     for (int q = 0; q < RQ; q++) {
@@ -384,7 +387,30 @@ __device__ int r_eliminate(ResShared &S, int n, double lambda, ResRegs &R, const
     }
     p_wave_order();
     double W[RQ][R_ROW];      // W | bl of the match, fetched with the V gather: the LDS latency of the products after the solve
-#pragma unroll                //   would otherwise be exposed read by read (one wavefront per SIMD: nothing else to issue)
+#if R_COLS                    //   would otherwise be exposed read by read (one wavefront per SIMD: nothing else to issue)
+    double a_[RQ][6];         // round 6: column d of V only -- the system is eliminated with one column per lane (p_solve6_cols)
+#pragma unroll
+    for (int q = 0; q < RQ; q++) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) a_[q][k] = row[q][6 * k + d];
+#pragma unroll
+      for (int k = 0; k < R_ROW; k++) W[q][k] = wbrow[q][k];
+    }
+    p_wave_order();
+#pragma unroll
+    for (int q = 0; q < RQ; q++)
+#pragma unroll
+      for (int k = 0; k < R_ROW; k++) asm volatile("" : "+v"(W[q][k]));   // (in registers from here on, not re-read later)
+    PTE(1);
+#pragma unroll
+    for (int q = 0; q < RQ; q++) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) { if (k == d) a_[q][k] += lambda; x[q][k] = (k == d) ? 1.0 : 0.0; }
+      ok[q] = p_solve6_cols(a_[q], x[q], 6 * t[q].g, d, p_lane() < 6 * PG_N, row[q]);
+    }
+#else
+    double A[RQ][36];
+#pragma unroll
     for (int q = 0; q < RQ; q++) {
 #pragma unroll
       for (int k = 0; k < 36; k++) A[q][k] = row[q][k];
@@ -402,6 +428,7 @@ __device__ int r_eliminate(ResShared &S, int n, double lambda, ResRegs &R, const
 #pragma unroll
       for (int k = 0; k < 6; k++) { A[q][7 * k] += lambda; x[q][k] = (k == d) ? 1.0 : 0.0; }
     r_solve6q<RQ>(A, x, ok);
+#endif
     PTE(2);
 #pragma unroll
     for (int q = 0; q < RQ; q++) {
@@ -482,7 +509,7 @@ __device__ void r_backsub(ResShared &S, int n, const double *dp, double lambda, 
         }
       }
     } else {   // beyond the kept passes: column a of Vi again, by the arithmetic of r_eliminate (same bits)
-      double A[RQ][36], xc[RQ][6];
+      double xc[RQ][6];
       int ok[RQ];
 #pragma unroll
       for (int q = 0; q < RQ; q++) {
@@ -494,6 +521,19 @@ __device__ void r_backsub(ResShared &S, int n, const double *dp, double lambda, 
         }
       }
       p_wave_order();
+#if R_COLS
+#pragma unroll
+      for (int q = 0; q < RQ; q++) {
+        double ac[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { ac[k] = row[q][6 * k + a]; xc[q][k] = (k == a) ? 1.0 : 0.0; }
+        p_wave_order();
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k == a) ac[k] += lambda;
+        ok[q] = p_solve6_cols(ac, xc[q], 6 * t[q].g, a, p_lane() < 6 * PG_N, row[q]);
+      }
+#else
+      double A[RQ][36];
 #pragma unroll
       for (int q = 0; q < RQ; q++)
 #pragma unroll
@@ -504,6 +544,7 @@ __device__ void r_backsub(ResShared &S, int n, const double *dp, double lambda, 
 #pragma unroll
         for (int k = 0; k < 6; k++) { A[q][7 * k] += lambda; xc[q][k] = (k == a) ? 1.0 : 0.0; }
       r_solve6q<RQ>(A, xc, ok);
+#endif
 #pragma unroll
       for (int q = 0; q < RQ; q++)
         if (t[q].act) {

@@ -84,3 +84,61 @@ __device__ unsigned long long g_pprof[16], g_pprev;
 // wavefront, forty per pass of the workgroup (lf_pose_res.h).
 #define PG_N 10                    // matches per wavefront pass
 __device__ __forceinline__ void p_wave_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+// lf_solve6 (lf_linalg.h: partial pivoting, reciprocal pivots, row-oriented back-substitution) with one column per lane:
+// lane (g, d) holds column d of A in a[] and ONE column of the right-hand side in b[] (its own column of a six-column
+// right-hand side, or a copy of the only one).  Step k: column k is fetched from lane k of the group; the pivot search, the
+// reciprocal and the multipliers are computed by all six lanes alike; each lane swaps / updates rows k+1.. of its own two
+// columns.  Entries the sequential code never reads again (rows > d of column d after step d) are not maintained.  The upper
+// triangle is published through `urow` (36 doubles of LDS per group) for the back-substitution.  Each entry goes through
+// the operations lf_solve6 applies to it, in its order: same bits.  Returns 0 for a singular system (b is garbage then).
+__device__ __forceinline__ int p_solve6_cols(double (&a)[6], double (&b)[6], int base, int d, bool lane_ok, double *urow) {
+  double rp[6];
+  int ok = 1;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double ck[6];
+#pragma unroll
+    for (int i = k; i < 6; i++) ck[i] = __shfl(a[i], base + k, 64);
+    int piv = k;
+    double big = lf_fabs(ck[k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const double v = lf_fabs(ck[i]);
+      if (v > big) { big = v; piv = i; }
+    }
+    if (!(big > 0.0)) ok = 0;
+    if (LF_ANY(piv != k)) {
+#pragma unroll
+      for (int i = k + 1; i < 6; i++) {
+        const bool sw = i == piv;
+        { const double x = a[k], y = a[i]; a[k] = sw ? y : x; a[i] = sw ? x : y; }
+        { const double x = b[k], y = b[i]; b[k] = sw ? y : x; b[i] = sw ? x : y; }
+        { const double x = ck[k], y = ck[i]; ck[k] = sw ? y : x; ck[i] = sw ? x : y; }
+      }
+    }
+    rp[k] = 1.0 / ck[k];
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const double f = ck[i] * rp[k];
+      const bool nz = f != 0.0;
+      { const double v = a[i] - f * a[k]; a[i] = nz ? v : a[i]; }
+      { const double v = b[i] - f * b[k]; b[i] = nz ? v : b[i]; }
+    }
+  }
+  if (lane_ok) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) urow[6 * i + d] = a[i];      // (rows i < d are the final U entries of column d; the rest is not read)
+  }
+  p_wave_order();
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double s = b[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) s -= urow[6 * i + k] * b[k];
+    b[i] = s * rp[i];
+  }
+  p_wave_order();
+  return ok;
+}
+
