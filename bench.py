@@ -409,7 +409,7 @@ def config4_leg(steps=50, warmup=5, keyframes=256, device=0, queries=8):
     return out
 
 
-def side_leg(kind, gray, depth, device, steps=4, warmup=2, nfl=4):
+def side_leg(kind, gray, depth, device, steps=4, warmup=2, nfl=4, streams=None):
     """A BASELINE configuration that is not the headline, timed in this process on the headline's frames, pipelined as the
     headline (`nfl` passes in flight), inputs resident:
       "config3"  BASELINE configs[2]: fused point + line odometry -- ORB (600 key points, second HIP stream) + projectTo3D +
@@ -423,7 +423,7 @@ def side_leg(kind, gray, depth, device, steps=4, warmup=2, nfl=4):
     P = capi.default_params(launch=True)
     if kind == "edlines":
         P.line_detector = 1
-    streams = [torch.cuda.Stream() for _ in range(nfl)]
+    streams = list(streams[:nfl]) if streams else [torch.cuda.Stream() for _ in range(nfl)]   # (the headline's pass streams: they own hardware queues)
     ctxs = []
     for st in streams:
         if ctxs:
@@ -1124,8 +1124,8 @@ def main():
     if rank == 0 and world == 1 and not dist_on and not a.no_legs and not a.points and a.detector == "lsd" and not strong:
         # the BASELINE configurations and call shapes the headline does not cover, on the driver's record (each guarded: a side leg
         # must never cost the headline line)
-        for name, fn in (("config3", lambda: side_leg("config3", gray, depth, local, nfl=nfl)),
-                         ("edlines", lambda: side_leg("edlines", gray, depth, local, nfl=nfl)),
+        for name, fn in (("config3", lambda: side_leg("config3", gray, depth, local, nfl=nfl, streams=streams)),
+                         ("edlines", lambda: side_leg("edlines", gray, depth, local, nfl=nfl, streams=streams)),
                          ("latency", lambda: latency_leg(gray, depth, P, local,
                                                          cpu_ms_per_frame=(1e3 / out["cpu_baseline"]["variants"]["single_thread"]["value"]) if "cpu_baseline" in out else None))):
             try:
