@@ -603,30 +603,35 @@ __global__ void __launch_bounds__(RT_N) LF_POSE_ATTR k_pose(PairConsts c, PairBu
     if (0 + nbest >= 3) {                                                                    // :725-728
       float tf_best[16], sse_best = 0;
       r_model(s3, cm, tf_best);                // recompute the winning model (uniform) and its inlier list / sse
-      double sse_unused;
-      int nb = r_score(S.rs, cm, nLn, tf_best, thr, S.set, &sse_best, &sse_unused);
       float refined_tf[16];
 #pragma unroll
       for (int i = 0; i < 16; i++) refined_tf[i] = tf_best[i];
       PT(12);
-      r_refine(S.rs, cm, P, S.set, nb, refined_tf, 25);                                      // :730
-      double refined_rmse = lf_sqrt(sse_best / (0 + nb));                                    // :731
+      double refined_rmse = 0;
       int nref = 0;
-      for (int iter = 0; iter < 20; ++iter) {                                                // :775-839
-        float tmp_sse_f;
-        double tmp_sse;
-        int *inl = b.inliers + (size_t)pr * LF_MAX_MATCHES;
-        // score into a scratch list first (kept only if it improves)
-        __syncthreads();
-        int ncur = r_score(S.rs, cm, nLn, refined_tf, thr, S.idx, &tmp_sse_f, &tmp_sse);
-        if (0 + ncur * lw > 0 + nref * lw) {
+      int *inl = b.inliers + (size_t)pr * LF_MAX_MATCHES;
+      // round -1: the refinement of the RANSAC winner's inliers (25 iterations, :730-731); rounds 0..19: the re-scoring loop
+      // (:775-839).  ONE call site of r_refine: inlined twice the kernel is 22 k instructions, twice the instruction cache
+      for (int iter = -1; iter < 20; ++iter) {
+        int nset;
+        if (iter < 0) {
+          double sse_unused;
+          nset = r_score(S.rs, cm, nLn, tf_best, thr, S.set, &sse_best, &sse_unused);
+          refined_rmse = lf_sqrt(sse_best / (0 + nset));                                     // :731
+        } else {
+          float tmp_sse_f;
+          double tmp_sse;
+          __syncthreads();
+          const int ncur = r_score(S.rs, cm, nLn, refined_tf, thr, S.idx, &tmp_sse_f, &tmp_sse);   // into a scratch list first (kept only if it improves)
+          if (!(0 + ncur * lw > 0 + nref * lw)) break;
           for (int i = tid; i < ncur; i += RT_N) { S.set[i] = S.idx[i]; inl[i] = S.idx[i]; }
           __syncthreads();
           nref = ncur;
           refined_rmse = lf_sqrt(tmp_sse / (0 + ncur));
-          r_refine(S.rs, cm, P, S.set, nref, refined_tf, 20);
           rounds++;
-        } else break;
+          nset = nref;
+        }
+        r_refine(S.rs, cm, P, S.set, nset, refined_tf, iter < 0 ? 25 : 20);
       }
       n_inl = nref;
       rmse_out = (float)refined_rmse;
