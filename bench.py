@@ -100,7 +100,7 @@ def parse():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N > 1: weak = one sequence per rank (BASELINE configs[4]); strong = ONE sequence, round-robin blocks of 64 "
                          "frames per rank, block-boundary line maps carried by the step's one all-gather (SURVEY.md 8e)")
-    ap.add_argument("--h2d-steps", type=int, default=4,
+    ap.add_argument("--h2d-steps", type=int, default=8,
                     help="steps of the extra leg that starts from raw TUM frames in pinned host memory (value_including_h2d); 0 = skip")
     ap.add_argument("--keyframes", type=int, default=32, help="keyframes per rank exchanged by the all-gather")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
