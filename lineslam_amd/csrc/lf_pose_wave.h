@@ -87,7 +87,11 @@ __device__ __forceinline__ wv_gd *w_uni_g(wv_gd *p) { return (wv_gd *)w_uni_g((c
 // w_order: the workgroup's LDS and workspace writes are visible to all its threads.  w_order_wave: the same inside one
 // wavefront (the six lanes of a match always sit in one wavefront).
 #if WV_W > 1
+#ifdef WV_DIAG_AGENT_FENCE
+__device__ __forceinline__ void w_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
+#else
 __device__ __forceinline__ void w_order() { __syncthreads(); }
+#endif
 #else
 __device__ __forceinline__ void w_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 #endif
