@@ -362,8 +362,15 @@ def config4_leg(steps=50, warmup=5, keyframes=256, device=0, queries=8):
         kernel_ms = ev[0].elapsed_time(ev[1]) / steps
         leg = {"value": NK * steps / dt, "unit": "pairs/s", "ms_per_step": dt / steps * 1e3, "launch_ms_hip_events": kernel_ms}
         if not pose:
+            c4t, c4src = None, _latest_profile("_config4_match_pmc.json")
+            if c4src:
+                try:
+                    c4t = json.load(open(c4src)).get("hbm_bytes_per_launch")       # PMC FETCH_SIZE + WRITE_SIZE of one 256-pair launch (tools/config4_pmc.sh)
+                except Exception:
+                    c4t = None
             leg["roofline"] = {"bound": "hbm", "kernel": "k_match", "achieved": algo / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": algo / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "frac": algo / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": c4t,
+                               "traffic_source": os.path.relpath(c4src, ROOT) if (c4src and c4t) else None,
                                "note": "one 512-thread block per pair, 256 blocks on 256 CUs: a single partial wave of blocks -- launch / latency "
                                        "sized, bound by the gates' fp64 / LDS work on n1 n2 line pairs, not by these bytes"}
             out["matches_total"] = int(sum(len(ctx.pair_matches(i)[0]) for i in range(NK)))
