@@ -23,6 +23,9 @@
 
 typedef unsigned long long u64;
 #define F_EPS 1e-10   // lineslam.h:37
+#ifndef LF_PIVOT_FAST
+#define LF_PIVOT_FAST 1
+#endif
 
 #ifndef LF_MLE_PAIR64
 #define LF_MLE_PAIR64 0    // 33..64-point lines two per wavefront (two rows per lane): measured slower again in round 3 (19.6 + 11.0 ms vs 20.8 ms)
@@ -580,11 +583,28 @@ __device__ __forceinline__ int f_lu6_cols(double (&c)[6], const MleGroup &g) {
     for (int i = k; i < 6; i++) col[i] = g_get<G>(c[i], g, k);
     int piv = k;
     double big = lf_fabs(col[k]);
+#if LF_PIVOT_FAST
+    // the pivot is the FIRST maximum of |col[k..5]|: it is row k unless a later entry is strictly larger -- one running maximum and
+    // one compare say so; the search with its selects runs only in the wavefronts where some lane has to swap
+    if (k < 5) {
+      double mx = lf_fabs(col[k + 1]);
+#pragma unroll
+      for (int i = k + 2; i < 6; i++) mx = __builtin_fmax(mx, lf_fabs(col[i]));
+      if (LF_ANY(mx > big)) {
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) {
+          const double v = lf_fabs(col[i]);
+          if (v > big) { big = v; piv = i; }
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int i = k + 1; i < 6; i++) {
       const double v = lf_fabs(col[i]);
       if (v > big) { big = v; piv = i; }
     }
+#endif
     if constexpr (G == 64) piv = __builtin_amdgcn_readfirstlane(piv);
     if (!(big > 0.0)) ok = 0;
     if (LF_ANY(piv != k)) {
